@@ -1,0 +1,93 @@
+"""CPU: pins oracle/mvsgi_oracle.py against the golden vectors produced by the
+reference's own modules (tools/make_goldens.py).  Tolerances: the oracle runs the
+same ATen CPU kernels as the reference, so stage outputs agree to float rounding."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_cases import SMALL_CASES
+from mvs_gi_amd import synth
+from oracle import mvsgi_oracle as O
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("name", list(SMALL_CASES))
+def test_small_case_matches_reference(golden_dir, name):
+    case = SMALL_CASES[name]
+    cfg = case["cfg"]
+    z = _load(golden_dir, name)
+    inp = synth.make_inputs(cfg, seed=case["seed"], batch=case["batch"], grid_kind=case["grid_kind"],
+                            grid_mask_dtype=case["grid_mask_dtype"])
+    assert synth.digest(inp) == str(z["inputs_sha256"]), "regenerated inputs differ from the golden run's"
+    t = O.to_torch(inp)
+    for gain in case["gains"]:
+        w = synth.make_weights(cfg, seed=case["seed"], gain=gain)
+        st = O.hot_path(t["feats"], t["grids"], t["grid_masks"], t["masks"], O.to_torch(w), cfg.builder,
+                        cfg.dist_cands, cfg.bf, cfg.interp_scale_factor, cfg.pre_interp, return_stages=True)
+        tag = f"g{gain:g}"
+        assert _rel(st["inv_dist"].numpy(), z[f"inv_dist_{tag}"]) <= 1e-5
+        if "vol_raw" in z and gain == case["gains"][0]:
+            assert np.array_equal(st["vol_raw"].numpy(), z["vol_raw"]), "sweep must be bit-exact"
+            assert _rel(st["vol"].numpy(), z["vol"]) <= 1e-6
+            assert _rel(st["costs"].numpy(), z["costs"]) <= 1e-5
+            assert _rel(st["norm_costs"].numpy(), z["norm_costs"]) <= 1e-5
+
+
+def test_sweep_edge_cases(golden_dir):
+    z = _load(golden_dir, "sweep_edges")
+    f, g, m = (torch.from_numpy(z[k]) for k in ("feats", "grids", "masks"))
+    gm = torch.from_numpy(z["grid_masks_bool"])
+    assert np.array_equal(O.sweep_std_masked(f, g, gm, m).numpy(), z["vol_raw_std_bool"])
+    assert np.array_equal(O.sweep_std_masked(f, g, gm.float(), m).numpy(), z["vol_raw_std_bool"])
+    assert np.array_equal(O.sweep_concat(f, g).numpy(), z["vol_raw_cat"])
+
+
+def test_sampler_equals_aten_grid_sample():
+    rng = np.random.default_rng(5)
+    im = torch.from_numpy(rng.standard_normal((2, 3, 7, 9)).astype(np.float32))
+    grid = torch.from_numpy(rng.uniform(-1.2, 1.2, (2, 5, 6, 2)).astype(np.float32))
+    ref = torch.nn.functional.grid_sample(im, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    assert torch.allclose(O.bilinear_sample_zeros(im, grid), ref, atol=2e-6)
+
+
+def test_regressor_variants(golden_dir):
+    z = _load(golden_dir, "regress_variants")
+    costs = torch.from_numpy(z["costs"])
+    cands = list(z["dist_cands"])
+    for tag, kw in dict(s2_pre=dict(interp_scale_factor=2, pre_interp=True),
+                        s0_pre=dict(interp_scale_factor=0, pre_interp=True),
+                        s2_post=dict(interp_scale_factor=2, pre_interp=False)).items():
+        inv, pr = O.soft_argmin(costs, cands, 96.0, **kw)
+        assert _rel(inv.numpy(), z[f"inv_{tag}"]) <= 1e-6
+        assert _rel(pr.numpy(), z[f"pr_{tag}"]) <= 1e-6
+    inv, _ = O.soft_argmin(costs, list(z["updated_cands"]), 96.0, 2, True)
+    assert _rel(inv.numpy(), z["inv_updated"]) <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["full_G16V", "full_E8"])
+def test_full_size_matches_reference(golden_dir, name):
+    """BASELINE.json configs[1] (G16V) and configs[0] (E8) at full size: inv_dist only."""
+    from golden_cases import FULL_CASES
+    case = FULL_CASES[name]
+    cfg = case["cfg"]
+    z = _load(golden_dir, name)
+    inp = synth.make_inputs(cfg, seed=case["seed"], batch=case["batch"], grid_kind=case["grid_kind"],
+                            grid_mask_dtype=case["grid_mask_dtype"])
+    assert synth.digest(inp) == str(z["inputs_sha256"])
+    t = O.to_torch(inp)
+    gain = case["gains"][-1]
+    w = synth.make_weights(cfg, seed=case["seed"], gain=gain)
+    inv = O.hot_path(t["feats"], t["grids"], t["grid_masks"], t["masks"], O.to_torch(w), cfg.builder,
+                     cfg.dist_cands, cfg.bf, cfg.interp_scale_factor, cfg.pre_interp)
+    assert _rel(inv.numpy(), z[f"inv_dist_g{gain:g}"]) <= 1e-5

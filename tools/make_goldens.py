@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules (imported
+from /root/reference, build container only) on the seeded cases in
+tests/golden_cases.py and on a few hand-built edge cases.
+
+Only data leaves this script: inputs' sha256 digests, hand-built inputs, and the
+reference's outputs.  The reference's code is imported, never copied; nothing here
+is used at test/bench time on the GPU box.
+
+Import recipe: SURVEY.md Appendix C (torchvision stub for common_modules.py:9).
+"""
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+REF = os.environ.get("MVSGI_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+tv, ops = types.ModuleType("torchvision"), types.ModuleType("torchvision.ops")
+def _absent(*a, **k):
+    raise NotImplementedError("torchvision not installed")
+ops.deform_conv2d = _absent
+tv.ops = ops
+sys.modules["torchvision"], sys.modules["torchvision.ops"] = tv, ops
+
+from dsta_mvs.model.cost_volume_builder import SphericalSweepStdMasked, SphericalSweep  # noqa: E402
+from dsta_mvs.model.cost_volume_regulator.unet_regulator import (  # noqa: E402
+    UNetCostVolumeRegulatorBase, UNetCostVolumeRegulator)
+from dsta_mvs.model.distance_regressor.distance_regressor import DistanceRegressorWithFixedCandidates  # noqa: E402
+
+from mvs_gi_amd import synth  # noqa: E402
+from golden_cases import SMALL_CASES, FULL_CASES  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.manual_seed(0)
+
+
+def build_reference(cfg, weights):
+    Builder = SphericalSweepStdMasked if cfg.builder == "std" else SphericalSweep
+    cvb = Builder(num_cams=cfg.num_cams, feat_chs=cfg.vol_chs if cfg.builder == "cat" else cfg.feat_chs,
+                  post_k_sz=3)
+    reg = UNetCostVolumeRegulatorBase(in_chs=cfg.reg_in_chs, f_int_chs=cfg.reg_f_int_chs)
+    dr = DistanceRegressorWithFixedCandidates(bf=cfg.bf, dist_cands=list(cfg.dist_cands),
+                                              interp_scale_factor=cfg.interp_scale_factor,
+                                              pre_interp=cfg.pre_interp)
+    cvb.load_state_dict({k: torch.from_numpy(v) for k, v in weights["cv_builder"].items()}, strict=True)
+    reg.load_state_dict({k: torch.from_numpy(v) for k, v in weights["cv_regulator"].items()}, strict=True)
+    return cvb.eval(), reg.eval(), dr.eval()
+
+
+def run_case(name, case, full):
+    cfg = case["cfg"]
+    inp = synth.make_inputs(cfg, seed=case["seed"], batch=case["batch"], grid_kind=case["grid_kind"],
+                            grid_mask_dtype=case["grid_mask_dtype"])
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    out = {"inputs_sha256": np.asarray(synth.digest(inp))}
+    for gain in case["gains"]:
+        w = synth.make_weights(cfg, seed=case["seed"], gain=gain)
+        cvb, reg, dr = build_reference(cfg, w)
+        with torch.no_grad():
+            if cfg.builder == "std":
+                vol_raw = cvb.sweep(t["feats"], t["grids"], t["grid_masks"], t["masks"])
+            else:
+                vol_raw = cvb.sweep(t["feats"], t["grids"], t["masks"])
+            vol = cvb(t["feats"], t["grids"], t["grid_masks"], t["masks"])
+            costs = reg(vol)
+            inv, pr = dr(costs)
+        tag = f"g{gain:g}"
+        out[f"inv_dist_{tag}"] = inv.numpy()
+        out[f"weights_sha256_{tag}"] = np.asarray(synth.digest({**w["cv_builder"],
+                                                               **{"r." + k: v for k, v in w["cv_regulator"].items()}}))
+        if not full and case.get("stages") and gain == case["gains"][0]:
+            out["vol_raw"] = vol_raw.numpy()
+            out["vol"] = vol.numpy()
+            out["costs"] = costs.numpy()
+            out["norm_costs"] = pr.numpy()
+        print(f"  {name} gain={gain}: inv_dist {tuple(inv.shape)} range [{inv.min():.4f}, {inv.max():.4f}] "
+              f"costs std {costs.std():.3f} maxprob {pr.max(1)[0].mean():.3f}")
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+
+
+def sweep_edges():
+    """Hand-built sampler/sweep corner cases: grid exactly on +-1, beyond the image,
+    on texel centres; 0, 1, 2 and 3 valid cameras; bool and float grid masks; B=2."""
+    rng = np.random.default_rng(77)
+    B, N, C, Hi, Wi, Hm, Wm, D, Ho, Wo = 2, 3, 5, 4, 6, 8, 12, 3, 4, 7
+    feats = rng.standard_normal((B, N, C, Hi, Wi)).astype(np.float32)
+    grids = rng.uniform(-1.3, 1.3, (B, N, D, Ho, Wo, 2)).astype(np.float32)
+    special = np.array([-1.0, 1.0, 0.0, -1.0 + 1.0 / Wi, 1.0 - 1.0 / Wi, 1.0 + 2.0 / Wi, -1.5, 0.5], np.float32)
+    grids[0, :, 0, 0, :, 0] = special[:Wo]
+    grids[0, :, 0, 1, :, 1] = special[1:Wo + 1]
+    grids[1, :, 1, :, 0, :] = -1.0
+    grids[1, :, 1, :, 1, :] = 1.0
+    masks = (rng.random((B, N, 1, Hm, Wm)) < 0.6).astype(np.float32)
+    masks[0, 0] = 0.0                                   # camera 0 never valid in batch 0
+    masks[1, :, :, :, : Wm // 2] = 0.0                  # left half invalid for all cams
+    gm = rng.random((B, N, D, Ho, Wo, 1)) < 0.7
+    gm[0, :, 2, 0, 0] = False                           # n = 0
+    gm[0, 1:, 2, 0, 1] = False                          # at most one valid -> 0
+    out = dict(feats=feats, grids=grids, masks=masks, grid_masks_bool=gm)
+    cvb = SphericalSweepStdMasked(num_cams=N, feat_chs=C, post_k_sz=3).eval()
+    cat = SphericalSweep(num_cams=N, feat_chs=N * C, post_k_sz=3).eval()
+    t = {k: torch.from_numpy(v) for k, v in out.items()}
+    with torch.no_grad():
+        out["vol_raw_std_bool"] = cvb.sweep(t["feats"], t["grids"], t["grid_masks_bool"], t["masks"]).numpy()
+        out["vol_raw_std_f32"] = cvb.sweep(t["feats"], t["grids"], t["grid_masks_bool"].float(), t["masks"]).numpy()
+        out["vol_raw_cat"] = cat.sweep(t["feats"], t["grids"], t["masks"]).numpy()
+    assert np.array_equal(out["vol_raw_std_bool"], out["vol_raw_std_f32"])
+    del out["vol_raw_std_f32"]
+    np.savez_compressed(os.path.join(OUT, "sweep_edges.npz"), **out)
+    print("  sweep_edges: zero fraction", float((out["vol_raw_std_bool"] == 0).mean()))
+
+
+def regress_variants():
+    rng = np.random.default_rng(78)
+    costs = (rng.standard_normal((2, 1, 5, 6, 7)) * 3).astype(np.float32)
+    cands = [0.5, 1.0, 2.0, 10.0, 100.0]
+    out = dict(costs=costs, dist_cands=np.asarray(cands, np.float64))
+    for tag, kw in dict(s2_pre=dict(interp_scale_factor=2, pre_interp=True),
+                        s0_pre=dict(interp_scale_factor=0, pre_interp=True),
+                        s2_post=dict(interp_scale_factor=2, pre_interp=False)).items():
+        dr = DistanceRegressorWithFixedCandidates(bf=96, dist_cands=cands, **kw).eval()
+        with torch.no_grad():
+            inv, pr = dr(torch.from_numpy(costs))
+        out[f"inv_{tag}"] = inv.numpy()
+        out[f"pr_{tag}"] = pr.numpy()
+    # update_dist_cands path (distance_regressor.py:33-49)
+    dr = DistanceRegressorWithFixedCandidates(bf=96, dist_cands=cands, interp_scale_factor=2, pre_interp=True)
+    new = [1.0, 2.0, 3.0, 4.0, 5.0]
+    dr.update_dist_cands(new)
+    with torch.no_grad():
+        inv, _ = dr(torch.from_numpy(costs))
+    out["inv_updated"] = inv.numpy()
+    out["updated_cands"] = np.asarray(new, np.float64)
+    out["updated_minmax"] = np.asarray([dr.inv_dist_idx_min, dr.inv_dist_idx_max])
+    np.savez_compressed(os.path.join(OUT, "regress_variants.npz"), **out)
+    print("  regress_variants done")
+
+
+def old_class_equivalence():
+    """UNetCostVolumeRegulator (older class, unet_regulator.py:142-270) with
+    only_one_cam=True has the same state dict and output as Base(in, 2*in)."""
+    rng = np.random.default_rng(79)
+    old = UNetCostVolumeRegulator(in_chs=4, final_chs=1, u_depth=3, blk_width=4, stage_factor=2, cost_k_sz=3,
+                                  keep_last_chs=[], deconv_k_sz=3, sweep_fuse_ch_reduce=2, num_cams=3,
+                                  only_one_cam=True).eval()
+    base = UNetCostVolumeRegulatorBase(in_chs=4, f_int_chs=8).eval()
+    sd = {}
+    for k, v in base.state_dict().items():
+        if v.dtype == torch.float32:
+            if k.endswith("running_var"):
+                sd[k] = torch.from_numpy(rng.uniform(0.5, 1.5, tuple(v.shape)).astype(np.float32))
+            else:
+                sd[k] = torch.from_numpy((rng.standard_normal(tuple(v.shape)) * 0.2).astype(np.float32))
+        else:
+            sd[k] = v
+    base.load_state_dict(sd, strict=True)
+    old.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(rng.standard_normal((1, 4, 8, 8, 16)).astype(np.float32))
+    with torch.no_grad():
+        yb, yo = base(x), old(x)
+    assert torch.equal(yb, yo)
+    # also exported as the unpickle-compat fixture: whole modules pickled the way
+    # Lightning's save_hyperparameters() stores them (spherical_sweep_stereo.py:74)
+    cvb = SphericalSweepStdMasked(num_cams=3, feat_chs=4, post_k_sz=3).eval()
+    cvb_sd = {}
+    for k, v in cvb.state_dict().items():
+        if v.dtype == torch.float32:
+            if k.endswith("running_var"):
+                cvb_sd[k] = torch.from_numpy(rng.uniform(0.5, 1.5, tuple(v.shape)).astype(np.float32))
+            else:
+                cvb_sd[k] = torch.from_numpy((rng.standard_normal(tuple(v.shape)) * 0.2).astype(np.float32))
+        else:
+            cvb_sd[k] = v
+    cvb.load_state_dict(cvb_sd, strict=True)
+    cands = [0.5, 1.0, 2.0, 4.0, 8.0, 16.0, 32.0, 100.0]
+    dr = DistanceRegressorWithFixedCandidates(bf=96, dist_cands=cands, interp_scale_factor=2, pre_interp=True).eval()
+    feats = torch.from_numpy(rng.standard_normal((1, 3, 4, 8, 16)).astype(np.float32))
+    grids = torch.from_numpy(rng.uniform(-1.05, 1.05, (1, 3, 8, 8, 16, 2)).astype(np.float32))
+    gmask = torch.from_numpy(rng.random((1, 3, 8, 8, 16, 1)) < 0.9)
+    masks = torch.from_numpy((rng.random((1, 3, 1, 16, 32)) < 0.9).astype(np.float32))
+    with torch.no_grad():
+        vol = cvb(feats, grids, gmask, masks)
+        costs = old(vol)
+        inv, _ = dr(costs)
+    buf = io.BytesIO()
+    torch.save({"hyper_parameters": {"cv_builder": cvb, "cv_regulator": old, "dist_regressor": dr}}, buf)
+    with open(os.path.join(OUT, "pickled_modules_tiny.pt"), "wb") as f:
+        f.write(buf.getvalue())
+    np.savez_compressed(os.path.join(OUT, "pickled_modules_tiny_io.npz"), feats=feats.numpy(), grids=grids.numpy(),
+                        grid_masks=gmask.numpy(), masks=masks.numpy(), vol=vol.numpy(), costs=costs.numpy(),
+                        inv_dist=inv.numpy(), x_reg=x.numpy(), y_reg=yb.numpy())
+    print("  old-class equivalence + pickled module fixture done;", len(buf.getvalue()), "bytes")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["small", "full", "edges"]
+    if "edges" in which:
+        sweep_edges()
+        regress_variants()
+        old_class_equivalence()
+    if "small" in which:
+        for n, c in SMALL_CASES.items():
+            run_case(n, c, full=False)
+    if "full" in which:
+        for n, c in FULL_CASES.items():
+            run_case(n, c, full=True)
