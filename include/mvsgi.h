@@ -1,0 +1,115 @@
+/*
+ * mvsgi.h -- C ABI of the MI355X (gfx950) plane-sweep hot path of castacks/mvs_gi.
+ *
+ * The reference is pure Python/PyTorch and has no FFI of its own; the precedent for
+ * handing this path raw device pointers is its TensorRT back end
+ * (api/inference_trt.py:128-142, context.execute_async_v2 with device addresses).
+ * Each entry point below replaces one stage of
+ *   dsta_mvs/model/mvs_model/torch_only.py:32-34
+ *     vol   = cv_builder(feats, grids, grid_masks, masks)
+ *     costs = cv_regulator(vol)
+ *     inv_dist, norm_costs = dist_regressor(costs)
+ * and is what a ctypes / cgo / JNI binding on the reference side would bind
+ * (INTEGRATION.md shows the ctypes stub that mvs_gi_amd/_lib.py uses).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM), caller-owned, never freed or retained;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); all work is
+ *     enqueued on it and nothing synchronises the host;
+ *   - activations are fp32, channels-last: [B][D][H][W][C] ("NDHWC"); the 2-D inputs of
+ *     the sweep keep the reference's own layouts (stated per function);
+ *   - return value: 0 = enqueued, non-zero = rejected (nothing enqueued);
+ *     mvsgi_last_error() returns a thread-local description of the last failure
+ *     (the Python layer raises RuntimeError with it, mirroring the reference's
+ *     assert/exception behaviour, e.g. backports.py:32).
+ *   - no global mutable state: every call is re-entrant per stream, one process per GPU.
+ */
+#ifndef MVSGI_H
+#define MVSGI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVSGI_ABI_VERSION 1
+
+typedef void* mvsgi_stream_t;
+
+/* conv3d implementation selector */
+#define MVSGI_CONV_AUTO   0   /* MFMA implicit GEMM when Cin%16==0 && Cout%16==0, else direct */
+#define MVSGI_CONV_DIRECT 1   /* VALU direct convolution (any channel counts; Cout==1 head)   */
+#define MVSGI_CONV_MFMA   2   /* v_mfma_f32_16x16x4_f32 implicit GEMM (exact fp32)            */
+
+int         mvsgi_abi_version(void);
+const char* mvsgi_last_error(void);
+
+/* ---- K1: fused spherical sweep -------------------------------------------------------
+ * Replaces SphericalSweepStdMasked.sweep (cost_volume_builder/spherical_sweep_avg.py:38-136)
+ * including both bilinear_grid_sample calls per candidate (backports/backports.py:34-86).
+ *   feats      [B][N][C][Hi][Wi]      fp32 (the feature extractor's NCHW output)
+ *   grids      [B][N][D][Ho][Wo][2]   fp32 normalised (x, y), align_corners=False
+ *   grid_masks [B][N][D][Ho][Wo][1]   uint8/bool (grid_mask_is_f32 == 0) or fp32 (== 1)
+ *   masks      [B][N][1][Hm][Wm]      fp32
+ *   vol        [B][D][Ho][Wo][C]      fp32 out: population variance over the valid cameras,
+ *                                     0 where fewer than two cameras are valid
+ */
+int mvsgi_sweep_std_f32(const float* feats, const float* grids, const void* grid_masks,
+                        int grid_mask_is_f32, const float* masks, float* vol,
+                        int B, int N, int C, int Hi, int Wi, int Hm, int Wm,
+                        int D, int Ho, int Wo, mvsgi_stream_t stream);
+
+/* Replaces SphericalSweep.sweep (cost_volume_builder/spherical_sweep.py:38-68):
+ *   vol [B][D][Ho][Wo][N*C], channel = cam*C + c (spherical_sweep.py:60-61). */
+int mvsgi_sweep_cat_f32(const float* feats, const float* grids, float* vol,
+                        int B, int N, int C, int Hi, int Wi,
+                        int D, int Ho, int Wo, mvsgi_stream_t stream);
+
+/* ---- K2: 3x3x3 convolution block -----------------------------------------------------
+ * Replaces BaseConvBlk3d.forward (common/common_modules.py:107-115):
+ *   y = act( conv3d(x, w, pad=1, stride) * scale[co] + shift[co] (+ res) )
+ * eval-mode BatchNorm3d is the per-channel (scale, shift); a conv bias is shift with
+ * scale = 1; act(v) = v > 0 ? v : v * neg_slope  (LeakyReLU: 0.01, ReLU: 0, identity: 1).
+ *   x   [B][Din][Hin][Win][Cin]   y / res [B][Do][Ho][Wo][Cout],  Do = (Din-1)/stride+1 ...
+ *   w_packed: output of mvsgi_conv3d_pack_weights_f32 (needed by the MFMA path; may be
+ *             NULL when impl == MVSGI_CONV_DIRECT);  w_oidhw: the PyTorch [Cout][Cin][3][3][3]
+ *             tensor (needed by the direct path; may be NULL when impl == MVSGI_CONV_MFMA).
+ */
+size_t mvsgi_conv3d_packed_weight_floats(int Cout, int Cin);
+int mvsgi_conv3d_pack_weights_f32(const float* w_oidhw, float* w_packed, int Cout, int Cin,
+                                  mvsgi_stream_t stream);
+int mvsgi_conv3d_f32(const float* x, const float* w_oidhw, const float* w_packed,
+                     const float* scale, const float* shift, const float* res, float* y,
+                     int B, int Cin, int Din, int Hin, int Win, int Cout,
+                     int stride, float neg_slope, int impl, mvsgi_stream_t stream);
+
+/* ---- K3: trilinear resize ------------------------------------------------------------
+ * Replaces F.interpolate(mode='trilinear', align_corners=False, size=...) inside
+ * ResizeConv3d.forward (common/common_modules.py:333-350), for x2 and for the odd-size
+ * re-interpolation to the skip tensor's shape.  x [B][Di][Hi][Wi][C] -> y [B][Do][Ho][Wo][C]. */
+int mvsgi_resize_trilinear_f32(const float* x, float* y, int B, int C,
+                               int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                               mvsgi_stream_t stream);
+
+/* ---- K4: fused upsample + soft-argmin ------------------------------------------------
+ * Replaces DistanceRegressorWithFixedCandidates.forward (distance_regressor/
+ * distance_regressor.py:51-79): bilinear x`scale` (scale in {1,2}; 1 = no interpolation),
+ * softmax over D, expectation of inv_idx[d] = bf / dist[d].
+ *   costs [B][D][H][W] (the C==1 volume), inv_idx [D],
+ *   inv_dist [B][1][sH][sW], norm_costs [B][D][sH][sW] or NULL (inference discards it). */
+int mvsgi_softargmin_f32(const float* costs, const float* inv_idx, float* inv_dist,
+                         float* norm_costs, int B, int D, int H, int W, int scale,
+                         mvsgi_stream_t stream);
+
+/* ---- layout helpers for the module boundary ------------------------------------------
+ * [B][C][D*H*W] <-> [B][D*H*W][C]; V = D*H*W.  Used when a caller hands the regulator a
+ * contiguous NCDHW tensor (e.g. produced by the reference's own cv_builder). */
+int mvsgi_ncv_to_nvc_f32(const float* x, float* y, int B, int C, long long V, mvsgi_stream_t stream);
+int mvsgi_nvc_to_ncv_f32(const float* x, float* y, int B, int C, long long V, mvsgi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVSGI_H */

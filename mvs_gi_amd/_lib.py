@@ -1,0 +1,65 @@
+"""ctypes binding of libmvsgi_hip.so (include/mvsgi.h).
+
+The library is the product path: there is no CPU or PyTorch fallback.  If the shared
+object has not been built (`python -c "import __graft_entry__ as g; g.build()"` or
+`make -C mvs_gi_amd/csrc`) every op raises MvsgiLibraryMissing.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvsgi_hip.so")
+
+ABI_VERSION = 1
+
+
+class MvsgiLibraryMissing(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/mvsgi.h
+_P = c_void_p
+SIGNATURES = {
+    "mvsgi_abi_version": (c_int, []),
+    "mvsgi_last_error": (c_char_p, []),
+    "mvsgi_sweep_std_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 10 + [_P]),
+    "mvsgi_sweep_cat_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P]),
+    "mvsgi_conv3d_packed_weight_floats": (c_size_t, [c_int, c_int]),
+    "mvsgi_conv3d_pack_weights_f32": (c_int, [_P, _P, c_int, c_int, _P]),
+    "mvsgi_conv3d_f32": (c_int, [_P] * 7 + [c_int] * 7 + [c_float, c_int, _P]),
+    "mvsgi_resize_trilinear_f32": (c_int, [_P, _P] + [c_int] * 8 + [_P]),
+    "mvsgi_softargmin_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
+    "mvsgi_ncv_to_nvc_f32": (c_int, [_P, _P, c_int, c_int, c_longlong, _P]),
+    "mvsgi_nvc_to_ncv_f32": (c_int, [_P, _P, c_int, c_int, c_longlong, _P]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise MvsgiLibraryMissing(
+            f"{LIB_PATH} not found: build the HIP library first (__graft_entry__.build()). "
+            "mvs_gi_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.mvsgi_abi_version()
+    if got != ABI_VERSION:
+        raise MvsgiLibraryMissing(f"{LIB_PATH}: ABI version {got}, expected {ABI_VERSION}; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().mvsgi_last_error()
+        raise RuntimeError(f"{what}: {msg.decode() if msg else 'unknown error'}")

@@ -1,0 +1,326 @@
+// K2: 3x3x3 convolution block for gfx950 -- conv3d(pad 1, stride 1|2) * scale + shift
+// (+ residual) -> LeakyReLU, channels-last fp32.  Replaces BaseConvBlk3d.forward
+// (dsta_mvs/model/common/common_modules.py:107-115) with eval-mode BatchNorm3d applied as
+// the per-channel (scale, shift) of the epilogue.
+//
+// Two implementations behind one entry point:
+//
+//  * conv3d_mfma_kernel -- implicit GEMM on the exact-fp32 matrix instruction
+//    v_mfma_f32_16x16x4_f32.  A workgroup owns a TD x TH x TW brick of output voxels and
+//    a block of output channels; per 16-input-channel slice it stages the brick's halo
+//    ((T-1)*stride+3 per axis) into LDS once and then runs the 27 taps as shifted LDS reads:
+//         D[cout 16][voxel 16] += W[cout 16][k 4] * X[k 4][voxel 16]
+//    A (weights) comes straight from HBM/L2 in a pre-packed, lane-ordered layout (one
+//    coalesced 16-byte load per lane gives the 4 k-steps of a tap), B (activations) is one
+//    ds_read_b128 per lane per tap (its 4 channels feed the same 4 k-steps), and the
+//    accumulator tile leaves each lane holding 4 consecutive output channels of one voxel,
+//    so the epilogue is a single 16-byte residual load and store per tile.
+//    The MFMA result is bit-for-bit a k-ordered fmaf chain, i.e. plain fp32 arithmetic.
+//
+//  * conv3d_direct_kernel -- one thread per (voxel, group of CO output channels), any channel
+//    counts; used for the Cout == 1 cost head (unet_regulator.py:61-68) and as the on-device
+//    cross-check of the MFMA path.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+    const float* x;
+    const float* w_oidhw;
+    const f32x4* wp;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* y;
+    int B, Cin, Din, Hin, Win, Cout, Do, Ho, Wo, stride;
+    float neg_slope;   // act(v) = v > 0 ? v : v * neg_slope; 1.0 = identity
+    int tiles_d, tiles_h, tiles_w;
+};
+
+constexpr int kVS = 20;           // LDS floats per staged voxel: 16 channels + 4 pad
+
+// ----------------------------------------------------------------------------------------
+// weight packing: [Cout][Cin][27] -> [Cin/16][27][Cout/16][64 lanes][4]
+//   lane = (kg << 4) | i  holds  W[cout = ct*16 + i][cin = cc*16 + 4*kg + e][tap], e = 0..3
+// ----------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ w, f32x4* __restrict__ wp, int Cout, int Cin) {
+    const int CT = Cout / 16;
+    const long long total = (long long)(Cin / 16) * 27 * CT * 64;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    long long r = idx >> 6;
+    const int ct = (int)(r % CT);
+    r /= CT;
+    const int tap = (int)(r % 27);
+    const int cc = (int)(r / 27);
+    const int co = ct * 16 + (lane & 15);
+    const int ci = cc * 16 + 4 * (lane >> 4);
+    f32x4 v;
+    for (int e = 0; e < 4; ++e) v[e] = w[((long long)co * Cin + ci + e) * 27 + tap];
+    wp[idx] = v;
+}
+
+// ----------------------------------------------------------------------------------------
+// MFMA implicit GEMM
+//   NW x MW : 16-cout x 16-voxel accumulator tiles per wave
+//   WM x WN : the 4 waves of the workgroup along voxels x couts
+//   TD,TH,TW: output brick (TD*TH*TW == WM*MW*16);  S: stride
+// ----------------------------------------------------------------------------------------
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S>
+__global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(WM * MW * 16 == TD * TH * TW, "brick must be covered by the voxel tiles");
+    constexpr int ITD = (TD - 1) * S + 3, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
+    constexpr int IV = ITD * ITH * ITW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int col = lane & 15, kg = lane >> 4;
+
+    int t = blockIdx.x;
+    const int tw_i = t % a.tiles_w;
+    t /= a.tiles_w;
+    const int th_i = t % a.tiles_h;
+    t /= a.tiles_h;
+    const int td_i = t % a.tiles_d;
+    const int b = t / a.tiles_d;
+    const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
+    const int id0 = od0 * S - 1, ih0 = oh0 * S - 1, iw0 = ow0 * S - 1;   // padding = 1
+
+    const int CT = a.Cout / 16;
+    const int ct0 = (blockIdx.y * WN + wn) * NW;
+
+    int base[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+        const int v = (wm * MW + i) * 16 + col;
+        const int w_ = v % TW, h_ = (v / TW) % TH, d_ = v / (TW * TH);
+        base[i] = (((d_ * S) * ITH + h_ * S) * ITW + w_ * S) * kVS + kg * 4;
+    }
+
+    f32x4 acc[MW][NW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = a.Cin / 16;
+    const float* xb_base = a.x + (long long)b * a.Din * a.Hin * a.Win * a.Cin;
+    for (int cc = 0; cc < nchunks; ++cc) {
+        __syncthreads();
+        for (int e = tid; e < IV * 4; e += 256) {
+            const int v = e >> 2, q = e & 3;
+            const int iw = v % ITW, ih = (v / ITW) % ITH, id = v / (ITW * ITH);
+            const int gd = id0 + id, gh = ih0 + ih, gw = iw0 + iw;
+            f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (gd >= 0 && gd < a.Din && gh >= 0 && gh < a.Hin && gw >= 0 && gw < a.Win)
+                val = *reinterpret_cast<const f32x4*>(
+                    xb_base + (((long long)gd * a.Hin + gh) * a.Win + gw) * a.Cin + cc * 16 + q * 4);
+            *reinterpret_cast<f32x4*>(&lds[v * kVS + q * 4]) = val;
+        }
+        __syncthreads();
+        const f32x4* wp = a.wp + (long long)cc * 27 * CT * 64 + lane;
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            const int off = ((kd * ITH + kh) * ITW + kw) * kVS;
+            f32x4 wa[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const int ct = ct0 + j;
+                wa[j] = (ct < CT) ? wp[(long long)(tap * CT + ct) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            f32x4 xv[MW];
+#pragma unroll
+            for (int i = 0; i < MW; ++i) xv[i] = *reinterpret_cast<const f32x4*>(&lds[base[i] + off]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < MW; ++i)
+#pragma unroll
+                    for (int j = 0; j < NW; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][k], xv[i][k], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: lane (col, kg) of tile (i, j) holds couts ct*16 + 4*kg + 0..3 of voxel i*16 + col
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+        const int v = (wm * MW + i) * 16 + col;
+        const int w_ = v % TW, h_ = (v / TW) % TH, d_ = v / (TW * TH);
+        const int od = od0 + d_, oh = oh0 + h_, ow = ow0 + w_;
+        if (od >= a.Do || oh >= a.Ho || ow >= a.Wo) continue;
+        const long long vox = (((long long)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int ct = ct0 + j;
+            if (ct >= CT) continue;
+            const int co = ct * 16 + kg * 4;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + co);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + co);
+            f32x4 r = acc[i][j] * sc + sh;
+            if (a.res) r += *reinterpret_cast<const f32x4*>(a.res + vox * a.Cout + co);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : r[e] * a.neg_slope;
+            *reinterpret_cast<f32x4*>(a.y + vox * a.Cout + co) = r;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// direct convolution: thread = (voxel, CO consecutive couts); weights in PyTorch OIDHW order
+// ----------------------------------------------------------------------------------------
+template <int CO>
+__global__ __launch_bounds__(256) void conv3d_direct_kernel(ConvArgs a) {
+    const int groups = (a.Cout + CO - 1) / CO;
+    const long long total = (long long)a.B * a.Do * a.Ho * a.Wo * groups;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cg = (int)(idx % groups);
+    const long long vox = idx / groups;
+    const int ow = (int)(vox % a.Wo);
+    const int oh = (int)((vox / a.Wo) % a.Ho);
+    const int od = (int)((vox / ((long long)a.Wo * a.Ho)) % a.Do);
+    const int b = (int)(vox / ((long long)a.Wo * a.Ho * a.Do));
+    const int co0 = cg * CO;
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+    for (int kd = 0; kd < 3; ++kd) {
+        const int id = od * a.stride - 1 + kd;
+        if (id < 0 || id >= a.Din) continue;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * a.stride - 1 + kh;
+            if (ih < 0 || ih >= a.Hin) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * a.stride - 1 + kw;
+                if (iw < 0 || iw >= a.Win) continue;
+                const int tap = (kd * 3 + kh) * 3 + kw;
+                const float* xp = a.x + ((((long long)b * a.Din + id) * a.Hin + ih) * a.Win + iw) * a.Cin;
+                for (int ci = 0; ci < a.Cin; ++ci) {
+                    const float xv = xp[ci];
+#pragma unroll
+                    for (int o = 0; o < CO; ++o) {
+                        const int co = co0 + o;
+                        if (co < a.Cout) acc[o] = fmaf(xv, a.w_oidhw[((long long)co * a.Cin + ci) * 27 + tap], acc[o]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+        const int co = co0 + o;
+        if (co >= a.Cout) break;
+        float r = acc[o] * a.scale[co] + a.shift[co];
+        if (a.res) r += a.res[vox * a.Cout + co];
+        r = r > 0.f ? r : r * a.neg_slope;
+        a.y[vox * a.Cout + co] = r;
+    }
+}
+
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S>
+int launch_mfma(ConvArgs a, hipStream_t st) {
+    constexpr int ITD = (TD - 1) * S + 3, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
+    constexpr size_t lds_bytes = (size_t)ITD * ITH * ITW * kVS * sizeof(float);
+    static_assert(lds_bytes <= 160 * 1024, "LDS tile too large");
+    auto kern = conv3d_mfma_kernel<NW, MW, WM, WN, TD, TH, TW, S>;
+    static bool attr_done = false;   // benign race: idempotent
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return mvsgi::fail("conv3d: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    a.tiles_d = (int)mvsgi::cdiv(a.Do, TD);
+    a.tiles_h = (int)mvsgi::cdiv(a.Ho, TH);
+    a.tiles_w = (int)mvsgi::cdiv(a.Wo, TW);
+    const long long nt = (long long)a.B * a.tiles_d * a.tiles_h * a.tiles_w;
+    MVSGI_REQUIRE(nt < (1ll << 31), "conv3d: too many tiles");
+    const int CT = a.Cout / 16;
+    dim3 grid((unsigned)nt, (unsigned)mvsgi::cdiv(CT, WN * NW));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
+    return mvsgi::check_launch("mvsgi_conv3d_f32(mfma)");
+}
+
+int dispatch_mfma(const ConvArgs& a, hipStream_t st) {
+    const int CT = a.Cout / 16;
+    const long long vox = (long long)a.B * a.Do * a.Ho * a.Wo;
+    if (a.stride == 1) {
+        if (CT == 1) return launch_mfma<1, 4, 4, 1, 4, 8, 8, 1>(a, st);
+        if (CT <= 3) {
+            if (vox >= 256ll * 512) return launch_mfma<2, 4, 4, 1, 4, 8, 8, 1>(a, st);
+            return launch_mfma<2, 1, 4, 1, 2, 4, 8, 1>(a, st);
+        }
+        if (vox * CT >= 128ll * 4 * 1024) return launch_mfma<2, 4, 2, 2, 2, 8, 8, 1>(a, st);
+        return launch_mfma<2, 2, 2, 2, 2, 4, 8, 1>(a, st);
+    }
+    if (CT <= 3) return launch_mfma<2, 1, 4, 1, 2, 4, 8, 2>(a, st);
+    return launch_mfma<2, 2, 2, 2, 2, 4, 8, 2>(a, st);
+}
+
+}  // namespace
+
+extern "C" size_t mvsgi_conv3d_packed_weight_floats(int Cout, int Cin) {
+    return (size_t)27 * (size_t)Cout * (size_t)Cin;
+}
+
+extern "C" int mvsgi_conv3d_pack_weights_f32(const float* w_oidhw, float* w_packed, int Cout, int Cin,
+                                             mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(w_oidhw && w_packed, "mvsgi_conv3d_pack_weights_f32: null pointer");
+    MVSGI_REQUIRE(Cout > 0 && Cin > 0 && Cout % 16 == 0 && Cin % 16 == 0,
+                  "mvsgi_conv3d_pack_weights_f32: Cout=%d Cin=%d must be positive multiples of 16", Cout, Cin);
+    const long long total = (long long)(Cin / 16) * 27 * (Cout / 16) * 64;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0,
+                       mvsgi::as_stream(stream), w_oidhw, reinterpret_cast<f32x4*>(w_packed), Cout, Cin);
+    return mvsgi::check_launch("mvsgi_conv3d_pack_weights_f32");
+}
+
+extern "C" int mvsgi_conv3d_f32(const float* x, const float* w_oidhw, const float* w_packed, const float* scale,
+                                const float* shift, const float* res, float* y, int B, int Cin, int Din, int Hin,
+                                int Win, int Cout, int stride, float neg_slope, int impl, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(x && y && scale && shift, "mvsgi_conv3d_f32: null pointer");
+    MVSGI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Din > 0 && Hin > 0 && Win > 0, "mvsgi_conv3d_f32: bad dims");
+    MVSGI_REQUIRE(stride == 1 || stride == 2, "mvsgi_conv3d_f32: stride %d not in {1, 2}", stride);
+    ConvArgs a{};
+    a.x = x;
+    a.w_oidhw = w_oidhw;
+    a.wp = reinterpret_cast<const f32x4*>(w_packed);
+    a.scale = scale;
+    a.shift = shift;
+    a.res = res;
+    a.y = y;
+    a.B = B;
+    a.Cin = Cin;
+    a.Din = Din;
+    a.Hin = Hin;
+    a.Win = Win;
+    a.Cout = Cout;
+    a.stride = stride;
+    a.neg_slope = neg_slope;
+    a.Do = (Din - 1) / stride + 1;   // k=3, pad=1
+    a.Ho = (Hin - 1) / stride + 1;
+    a.Wo = (Win - 1) / stride + 1;
+    const bool mfma_ok = (Cin % 16 == 0) && (Cout % 16 == 0);
+    if (impl == MVSGI_CONV_AUTO) impl = mfma_ok ? MVSGI_CONV_MFMA : MVSGI_CONV_DIRECT;
+    hipStream_t st = mvsgi::as_stream(stream);
+    if (impl == MVSGI_CONV_MFMA) {
+        MVSGI_REQUIRE(mfma_ok, "mvsgi_conv3d_f32: MFMA path needs Cin, Cout multiples of 16 (got %d, %d)", Cin, Cout);
+        MVSGI_REQUIRE(w_packed, "mvsgi_conv3d_f32: MFMA path needs w_packed");
+        return dispatch_mfma(a, st);
+    }
+    MVSGI_REQUIRE(impl == MVSGI_CONV_DIRECT, "mvsgi_conv3d_f32: unknown impl %d", impl);
+    MVSGI_REQUIRE(w_oidhw, "mvsgi_conv3d_f32: direct path needs w_oidhw");
+    const long long vox = (long long)B * a.Do * a.Ho * a.Wo;
+    if (Cout == 1) {
+        hipLaunchKernelGGL((conv3d_direct_kernel<1>), dim3((unsigned)mvsgi::cdiv(vox, 256)), dim3(256), 0, st, a);
+    } else {
+        const long long total = vox * mvsgi::cdiv(Cout, 4);
+        hipLaunchKernelGGL((conv3d_direct_kernel<4>), dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0, st, a);
+    }
+    return mvsgi::check_launch("mvsgi_conv3d_f32(direct)");
+}

@@ -1,0 +1,88 @@
+// K4: fused bilinear upsample + softmax over D + expectation, fp32.
+// Replaces DistanceRegressorWithFixedCandidates.forward
+// (dsta_mvs/model/distance_regressor/distance_regressor.py:51-79):
+//   c = costs[:, 0]; c = interpolate(c, scale_factor=s, bilinear); p = softmax(c, 1);
+//   inv_dist = sum_d p_d * inv_idx_d.
+// One thread per output pixel walks the D candidates twice (max, then exp-sum and the
+// weighted sum); the upsampled [B, D, sH, sW] volume and the probabilities never touch
+// HBM unless the caller asks for norm_costs (training only; inference discards it,
+// spherical_sweep_stereo.py:266).  The 4 source pixels of neighbouring lanes coincide or
+// are adjacent, so every candidate plane is read once from HBM and served from L1/L2 after.
+#include "common.hpp"
+
+namespace {
+
+struct Axis2 {
+    int i0, i1;
+    float l0, l1;
+};
+
+__device__ __forceinline__ Axis2 axis2(int dst, int in, int scale) {
+    Axis2 a;
+    if (scale == 1) {
+        a.i0 = a.i1 = dst;
+        a.l0 = 1.f;
+        a.l1 = 0.f;
+        return a;
+    }
+    // F.interpolate(scale_factor=s) uses 1/s as the coordinate scale
+    float src = ((float)dst + 0.5f) * (1.0f / (float)scale) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    a.i0 = (int)src;
+    if (a.i0 > in - 1) a.i0 = in - 1;
+    a.i1 = a.i0 + (a.i0 < in - 1 ? 1 : 0);
+    a.l1 = src - (float)a.i0;
+    a.l0 = 1.0f - a.l1;
+    return a;
+}
+
+__global__ __launch_bounds__(256) void softargmin_kernel(const float* __restrict__ costs,
+                                                         const float* __restrict__ inv_idx,
+                                                         float* __restrict__ inv_dist, float* __restrict__ norm_costs,
+                                                         int B, int D, int H, int W, int scale) {
+    const int OH = H * scale, OW = W * scale;
+    const long long total = (long long)B * OH * OW;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ox = (int)(idx % OW);
+    const int oy = (int)((idx / OW) % OH);
+    const int b = (int)(idx / ((long long)OW * OH));
+    const Axis2 ay = axis2(oy, H, scale), ax = axis2(ox, W, scale);
+    const long long HW = (long long)H * W;
+    const float* cb = costs + (long long)b * D * HW;
+    const long long o00 = (long long)ay.i0 * W + ax.i0, o01 = (long long)ay.i0 * W + ax.i1;
+    const long long o10 = (long long)ay.i1 * W + ax.i0, o11 = (long long)ay.i1 * W + ax.i1;
+
+    auto sample = [&](int d) {
+        const float* p = cb + d * HW;
+        return ay.l0 * (ax.l0 * p[o00] + ax.l1 * p[o01]) + ay.l1 * (ax.l0 * p[o10] + ax.l1 * p[o11]);
+    };
+
+    float m = -INFINITY;
+    for (int d = 0; d < D; ++d) m = fmaxf(m, sample(d));
+    float s = 0.f, t = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const float e = expf(sample(d) - m);
+        s += e;
+        t = fmaf(e, inv_idx[d], t);
+    }
+    inv_dist[idx] = t / s;
+    if (norm_costs) {
+        const long long OHW = (long long)OH * OW;
+        float* np = norm_costs + (long long)b * D * OHW + (long long)oy * OW + ox;
+        for (int d = 0; d < D; ++d) np[d * OHW] = expf(sample(d) - m) / s;
+    }
+}
+
+}  // namespace
+
+extern "C" int mvsgi_softargmin_f32(const float* costs, const float* inv_idx, float* inv_dist, float* norm_costs,
+                                    int B, int D, int H, int W, int scale, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(costs && inv_idx && inv_dist, "mvsgi_softargmin_f32: null pointer");
+    MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_softargmin_f32: non-positive dimension");
+    MVSGI_REQUIRE(scale == 1 || scale == 2, "mvsgi_softargmin_f32: scale %d not in {1, 2}", scale);
+    const long long total = (long long)B * H * scale * W * scale;
+    hipLaunchKernelGGL(softargmin_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0,
+                       mvsgi::as_stream(stream), costs, inv_idx, inv_dist, norm_costs, B, D, H, W, scale);
+    return mvsgi::check_launch("mvsgi_softargmin_f32");
+}

@@ -1,0 +1,206 @@
+"""Host-side mirror of the 3-D building blocks of dsta_mvs/model/common/common_modules.py
+(NoOp :13-16, BaseConvBlk3d :82-115, ResConvBlk3d :186-244, ResizeConv3d :305-355) and of
+the registries in dsta_mvs/model/common/__init__.py:7-23.
+
+The classes keep the reference's constructor arguments, attribute names and child-module
+names, so state dicts load unchanged and module objects pickled by the reference
+(Lightning `save_hyperparameters()`, spherical_sweep_stereo.py:74) unpickle into them.
+Their `forward` runs the hand-written HIP kernels through the C ABI; nothing here
+computes on the CPU.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Dict, Optional, Type
+
+import torch
+from torch import nn, Tensor
+
+from .. import hip_ops as H
+
+
+class NoOp(nn.Identity):
+    """Alias of nn.Identity, as in the reference (common_modules.py:13-16)."""
+    def infer_size(self, in_size):
+        return in_size
+
+
+RELU_TYPE: Dict[str, Type[nn.Module]] = {"original": nn.ReLU, "leaky": nn.LeakyReLU, "none": NoOp}
+NORM2D_TYPE: Dict[str, Type[nn.Module]] = {"batch": nn.BatchNorm2d, "instance": nn.InstanceNorm2d, "none": NoOp}
+NORM3D_TYPE: Dict[str, Type[nn.Module]] = {"batch": nn.BatchNorm3d, "instance": nn.InstanceNorm3d, "none": NoOp}
+
+
+# ------------------------------------------------------------------------------------------
+# lowering of one conv block to the arguments of mvsgi_conv3d_f32
+# ------------------------------------------------------------------------------------------
+class ConvLaunch:
+    """Device-resident launch arguments of one BaseConvBlk3d: PyTorch-layout weight, packed
+    MFMA weight (or None), per-channel scale/shift (eval BatchNorm3d or bias), stride, slope."""
+    __slots__ = ("w", "wp", "scale", "shift", "stride", "neg_slope", "cin", "cout", "key")
+
+    def run(self, x_ndhwc: Tensor, res: Optional[Tensor] = None, impl: int = H.CONV_AUTO) -> Tensor:
+        return H.conv3d(x_ndhwc, self.w, self.wp, self.scale, self.shift, res=res, stride=self.stride,
+                        neg_slope=self.neg_slope, impl=impl)
+
+
+def _is_identity(m) -> bool:
+    return m is None or isinstance(m, nn.Identity)
+
+
+def _fingerprint(blk) -> tuple:
+    conv = blk.conv_layer
+    parts = [conv.weight.data_ptr(), conv.weight._version]
+    if conv.bias is not None:
+        parts += [conv.bias.data_ptr(), conv.bias._version]
+    norm = blk.norm_layer
+    if isinstance(norm, nn.BatchNorm3d):
+        for t in (norm.weight, norm.bias, norm.running_mean, norm.running_var):
+            if t is not None:
+                parts += [t.data_ptr(), t._version]
+    return tuple(parts)
+
+
+def lower_conv_block(blk) -> ConvLaunch:
+    """Build (and cache on the module, keyed by parameter identity/version) the launch
+    arguments of a BaseConvBlk3d-shaped module {conv_layer, norm_layer, activation}."""
+    key = _fingerprint(blk)
+    cached = blk.__dict__.get("_mvsgi_launch")
+    if cached is not None and cached.key == key:
+        return cached
+    conv: nn.Conv3d = blk.conv_layer
+    if not isinstance(conv, nn.Conv3d):
+        raise NotImplementedError(f"conv_layer is {type(conv).__name__}, expected nn.Conv3d")
+    if tuple(conv.kernel_size) != (3, 3, 3) or tuple(conv.padding) != (1, 1, 1) or tuple(conv.dilation) != (1, 1, 1) \
+            or conv.groups != 1 or conv.padding_mode != "zeros" or len(set(conv.stride)) != 1 \
+            or conv.stride[0] not in (1, 2):
+        raise NotImplementedError(
+            f"HIP conv3d supports kernel 3, padding 1, stride 1|2, dense; got kernel {tuple(conv.kernel_size)}, "
+            f"padding {tuple(conv.padding)}, stride {tuple(conv.stride)}, groups {conv.groups}")
+    w = conv.weight.detach()
+    if not w.is_cuda:
+        raise RuntimeError("mvs_gi_amd modules run on the GPU only: call .cuda() on the model "
+                           "(there is no CPU fallback)")
+    w = w.to(torch.float32).contiguous()
+    cout = w.shape[0]
+    norm = blk.norm_layer
+    if isinstance(norm, nn.BatchNorm3d):
+        if norm.training:
+            raise RuntimeError("HIP path implements eval-mode BatchNorm3d only: call model.eval()")
+        if norm.running_mean is None or norm.running_var is None:
+            raise NotImplementedError("BatchNorm3d without running statistics")
+        gamma = norm.weight.detach().float() if norm.weight is not None else torch.ones(cout, device=w.device)
+        beta = norm.bias.detach().float() if norm.bias is not None else torch.zeros(cout, device=w.device)
+        # ATen eval batch_norm: alpha = gamma / sqrt(var + eps); y = x * alpha + (beta - mean * alpha)
+        alpha = gamma / torch.sqrt(norm.running_var.detach().float() + norm.eps)
+        scale = alpha
+        shift = beta - norm.running_mean.detach().float() * alpha
+        if conv.bias is not None:
+            shift = shift + conv.bias.detach().float() * alpha
+    elif _is_identity(norm):
+        scale = torch.ones(cout, device=w.device, dtype=torch.float32)
+        shift = conv.bias.detach().float().clone() if conv.bias is not None \
+            else torch.zeros(cout, device=w.device, dtype=torch.float32)
+    else:
+        raise NotImplementedError(f"norm layer {type(norm).__name__} has no HIP implementation "
+                                  "(only BatchNorm3d in eval mode and NoOp)")
+    act = blk.activation
+    if isinstance(act, nn.LeakyReLU):
+        slope = float(act.negative_slope)
+    elif isinstance(act, nn.ReLU):
+        slope = 0.0
+    elif _is_identity(act):
+        slope = 1.0
+    else:
+        raise NotImplementedError(f"activation {type(act).__name__} has no HIP implementation")
+    L = ConvLaunch()
+    L.w = w
+    L.wp = H.pack_conv_weights(w)
+    L.scale = scale.contiguous()
+    L.shift = shift.contiguous()
+    L.stride = int(conv.stride[0])
+    L.neg_slope = slope
+    L.cin, L.cout = int(w.shape[1]), int(cout)
+    L.key = key
+    blk.__dict__["_mvsgi_launch"] = L
+    return L
+
+
+def _to_ncdhw_view(y_ndhwc: Tensor) -> Tensor:
+    """[B, D, H, W, C] storage presented with the reference's [B, C, D, H, W] shape
+    (channels_last_3d strides; no copy)."""
+    return y_ndhwc.permute(0, 4, 1, 2, 3)
+
+
+# ------------------------------------------------------------------------------------------
+# blocks (ndhwc-level helpers are used by the regulator / builder forwards)
+# ------------------------------------------------------------------------------------------
+class BaseConvBlk3d(nn.Module):
+    def __init__(self, in_chs: int, out_chs: int, kernel_size: int, stride: int = 1, extra_pad: int = 0,
+                 bias_on: bool = False, norm_layer: nn.Module = NoOp(), activation: nn.Module = NoOp()):
+        super().__init__()
+        self.conv_layer = nn.Conv3d(in_chs, out_chs, kernel_size, padding=(kernel_size // 2) + extra_pad,
+                                    bias=bias_on, stride=stride)
+        self.norm_layer = norm_layer
+        self.activation = activation
+
+    def forward_ndhwc(self, x: Tensor, res: Optional[Tensor] = None) -> Tensor:
+        return lower_conv_block(self).run(x, res)
+
+    def forward(self, x: Tensor, res: Optional[Tensor] = None) -> Tensor:
+        r = None if res is None else H.as_ndhwc(res)
+        return _to_ncdhw_view(self.forward_ndhwc(H.as_ndhwc(x), r))
+
+
+def res_block_ndhwc(blk, x: Tensor) -> Tensor:
+    """ResConvBlk3d.forward (common_modules.py:231-244) for in_chs == out_chs."""
+    if not _is_identity(blk.one_by_one):
+        raise NotImplementedError("ResConvBlk3d with a 1x1x1 projection (in_chs != out_chs) is not on the hot path")
+    if getattr(blk, "out_pad", 0) != 0:
+        raise NotImplementedError("ResConvBlk3d out_pad != 0")
+    r = lower_conv_block(blk.blk1).run(x)
+    return lower_conv_block(blk.blk2).run(r, res=x)
+
+
+class ResConvBlk3d(nn.Module):
+    def __init__(self, in_chs: int, out_chs: int, kernel_size: int = 3, in_stride: int = 1, out_stride: int = 1,
+                 out_pad: int = 0, activation: nn.Module = NoOp(), norm_layer: nn.Module = NoOp()):
+        super().__init__()
+        self.in_chs, self.out_chs, self.k_sz = in_chs, out_chs, kernel_size
+        self.in_stride, self.out_stride, self.out_pad = in_stride, out_stride, out_pad
+        self.blk1 = BaseConvBlk3d(in_chs, out_chs, kernel_size, stride=in_stride,
+                                  activation=copy.deepcopy(activation), norm_layer=copy.deepcopy(norm_layer))
+        self.blk2 = BaseConvBlk3d(out_chs, out_chs, kernel_size, stride=out_stride,
+                                  activation=copy.deepcopy(activation), norm_layer=copy.deepcopy(norm_layer))
+        if in_chs != out_chs:
+            self.one_by_one = BaseConvBlk3d(in_chs, out_chs, 1, stride=out_stride * in_stride,
+                                            activation=copy.deepcopy(activation),
+                                            norm_layer=copy.deepcopy(norm_layer))
+        else:
+            self.one_by_one = NoOp()
+
+    def forward(self, x: Tensor) -> Tensor:
+        return _to_ncdhw_view(res_block_ndhwc(self, H.as_ndhwc(x)))
+
+
+def resize_conv_ndhwc(blk, x: Tensor, res: Optional[Tensor] = None) -> Tensor:
+    """ResizeConv3d.forward (common_modules.py:332-355): trilinear to int(scale*s)+out_pad,
+    optional second resize to the skip's size, then conv(+res)."""
+    up = [int(blk.scale * s) + blk.out_pad for s in x.shape[1:4]]
+    x = H.resize_trilinear(x, up)
+    if res is not None and tuple(x.shape[1:4]) != tuple(res.shape[1:4]):
+        x = H.resize_trilinear(x, res.shape[1:4])
+    return lower_conv_block(blk.conv).run(x, res)
+
+
+class ResizeConv3d(nn.Module):
+    def __init__(self, in_chs: int, out_chs: int, kernel_size: int, stride: int = 1, extra_pad: int = 0,
+                 out_pad: int = 0, activation: nn.Module = NoOp(), norm_layer: nn.Module = NoOp()):
+        super().__init__()
+        self.scale = stride
+        self.out_pad = out_pad
+        self.conv = BaseConvBlk3d(in_chs, out_chs, kernel_size, stride=1, extra_pad=extra_pad,
+                                  activation=copy.deepcopy(activation), norm_layer=copy.deepcopy(norm_layer))
+
+    def forward(self, x: Tensor, res: Optional[Tensor] = None) -> Tensor:
+        r = None if res is None else H.as_ndhwc(res)
+        return _to_ncdhw_view(resize_conv_ndhwc(self, H.as_ndhwc(x), r))

@@ -1,0 +1,65 @@
+"""Drop-in cv_builder modules: same names, constructor arguments, child names and forward
+signatures as dsta_mvs/model/cost_volume_builder/spherical_sweep_avg.py:9-167
+(SphericalSweepStdMasked) and spherical_sweep.py:9-102 (SphericalSweep); the sweep and
+post_vol run as HIP kernels (mvsgi_sweep_*_f32, mvsgi_conv3d_f32).
+
+forward(feats [B,N,C,Hi,Wi], grids [B,N,D,Ho,Wo,2], grid_masks [B,N,D,Ho,Wo,1] bool|f32,
+        masks [B,N,1,Hm,Wm]) -> vol [B,Cv,D,Ho,Wo]
+The returned tensor has the reference's shape and channels_last_3d strides (its storage is
+[B,D,Ho,Wo,Cv]); `.contiguous()` gives the reference's memory order if a caller needs it.
+"""
+from __future__ import annotations
+
+from torch import nn, Tensor
+
+from .. import hip_ops as H
+from . import common_modules as cm
+from .common_modules import NORM3D_TYPE, RELU_TYPE
+
+
+class _SweepBase(nn.Module):
+    def __init__(self, num_cams: int, feat_chs: int, post_k_sz: int, norm_type: str = "batch",
+                 relu_type: str = "leaky"):
+        super().__init__()
+        self.num_cams = num_cams
+        self.feat_chs = feat_chs
+        self.norm_type = NORM3D_TYPE[norm_type]
+        self.relu_type = RELU_TYPE[relu_type]
+        self.grid_sample_mode = "bilinear"
+        self.post_vol = cm.BaseConvBlk3d(in_chs=feat_chs, out_chs=feat_chs, kernel_size=post_k_sz,
+                                         activation=self.relu_type(), norm_layer=self.norm_type(feat_chs))
+
+
+def std_sweep_ndhwc(feats, grids, grid_masks, masks) -> Tensor:
+    return H.sweep_std(feats, grids, grid_masks, masks)
+
+
+def cat_sweep_ndhwc(feats, grids) -> Tensor:
+    return H.sweep_cat(feats, grids)
+
+
+def std_forward(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor) -> Tensor:
+    vol_raw = std_sweep_ndhwc(feats, grids, grid_masks, masks)
+    return cm._to_ncdhw_view(cm.lower_conv_block(self.post_vol).run(vol_raw))
+
+
+def cat_forward(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor) -> Tensor:
+    # grid_masks / masks are accepted and ignored, as in the reference (spherical_sweep.py:80)
+    vol_raw = cat_sweep_ndhwc(feats, grids)
+    return cm._to_ncdhw_view(cm.lower_conv_block(self.post_vol).run(vol_raw))
+
+
+class SphericalSweepStdMasked(_SweepBase):
+    def sweep(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor) -> Tensor:
+        """vol_raw [B, C, D, Ho, Wo] (spherical_sweep_avg.py:38-136)."""
+        return cm._to_ncdhw_view(std_sweep_ndhwc(feats, grids, grid_masks, masks))
+
+    forward = std_forward
+
+
+class SphericalSweep(_SweepBase):
+    def sweep(self, feats: Tensor, grids: Tensor, masks: Tensor = None) -> Tensor:
+        """vol_raw [B, N*C, D, Ho, Wo], channel = cam*C + c (spherical_sweep.py:38-68)."""
+        return cm._to_ncdhw_view(cat_sweep_ndhwc(feats, grids))
+
+    forward = cat_forward

@@ -1,0 +1,138 @@
+"""Drop-in cv_regulator: UNetCostVolumeRegulatorBase (dsta_mvs/model/cost_volume_regulator/
+unet_regulator.py:16-140), the older UNetCostVolumeRegulator (:142-270; widths in*2/4/8,
+identical state dict and output to Base(in, 2*in), SURVEY.md §8 note) and UNetDownBlk
+(:273-310).  forward(vol [B,C,D,H,W]) -> costs [B,final_chs,D,H,W]; every layer is one
+mvsgi_conv3d_f32 / mvsgi_resize_trilinear_f32 launch on the current stream.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Sequence
+
+from torch import nn, Tensor
+
+from .. import hip_ops as H
+from . import common_modules as cm
+from .common_modules import NORM3D_TYPE, RELU_TYPE
+
+
+class UNetDownBlk(nn.Module):
+    def __init__(self, in_chs: int, out_chs: int, kernel_size: int, width: int,
+                 activation: nn.Module = cm.NoOp(), norm_layer: nn.Module = cm.NoOp()):
+        super().__init__()
+        self.k_sz = kernel_size
+        self.first = cm.BaseConvBlk3d(in_chs, out_chs, kernel_size, stride=2,
+                                      activation=copy.deepcopy(activation), norm_layer=copy.deepcopy(norm_layer))
+        self.blks = nn.Sequential(*[
+            cm.ResConvBlk3d(out_chs, out_chs, kernel_size, activation=copy.deepcopy(activation),
+                            norm_layer=copy.deepcopy(norm_layer)) for _ in range(width - 1)])
+
+    def forward(self, x: Tensor) -> Tensor:
+        return cm._to_ncdhw_view(down_block_ndhwc(self, H.as_ndhwc(x)))
+
+
+def down_block_ndhwc(blk, x: Tensor) -> Tensor:
+    x = cm.lower_conv_block(blk.first).run(x)
+    for rb in blk.blks:
+        x = cm.res_block_ndhwc(rb, x)
+    return x
+
+
+def regulator_forward_ndhwc(self, x: Tensor) -> Tensor:
+    """unet_regulator.py:120-140 on channels-last tensors."""
+    skips = []
+    n_down = len(self.down_blks)
+    for i, blk in enumerate(self.down_blks):
+        x = down_block_ndhwc(blk, x)
+        if i != n_down - 1:
+            skips.append(x)
+    skips.reverse()
+    for i, up in enumerate(self.upBlks):
+        x = cm.resize_conv_ndhwc(up, x, res=skips[i])
+    x = cm.resize_conv_ndhwc(self.out_costs[0], x)
+    return cm.lower_conv_block(self.out_costs[1]).run(x)
+
+
+def regulator_forward(self, x: Tensor) -> Tensor:
+    return cm._to_ncdhw_view(regulator_forward_ndhwc(self, H.as_ndhwc(x)))
+
+
+class UNetCostVolumeRegulatorBase(nn.Module):
+    def __init__(self, in_chs: int = 16, f_int_chs: int = 32, final_chs: int = 1, u_depth: int = 3,
+                 blk_width: int = 4, stage_factor: int = 2, cost_k_sz: int = 3, keep_last_chs: Sequence[int] = [],
+                 deconv_k_sz: int = 3, norm_type: str = "batch", relu_type: str = "leaky"):
+        super().__init__()
+        self.in_chs, self.f_int_chs, self.final_chs = in_chs, f_int_chs, final_chs
+        self.u_depth, self.blkWidth, self.stage_factor = u_depth, blk_width, stage_factor
+        self.k_sz, self.keep_last_chs, self.deconv_k_sz = cost_k_sz, keep_last_chs, deconv_k_sz
+        self.norm_type = NORM3D_TYPE[norm_type]
+        self.relu_type = RELU_TYPE[relu_type]
+
+        # channel plan: f_int at level 0, multiplied by stage_factor per level unless kept
+        self._int_chs = []
+        downs = []
+        cin, cout = in_chs, f_int_chs
+        for lvl in range(u_depth):
+            if lvl != 0 and lvl not in keep_last_chs:
+                cout *= stage_factor
+            downs.append(UNetDownBlk(cin, cout, cost_k_sz, blk_width, activation=self.relu_type(),
+                                     norm_layer=self.norm_type(cout)))
+            self._int_chs.append(cout)
+            cin = cout
+        self.down_blks = nn.ModuleList(downs)
+
+        rev = self._int_chs[::-1]
+        self.upBlks = nn.ModuleList([
+            cm.ResizeConv3d(rev[i], rev[i + 1], deconv_k_sz, stride=2, activation=self.relu_type(),
+                            norm_layer=self.norm_type(rev[i + 1])) for i in range(u_depth - 1)])
+        self.out_costs = nn.Sequential(
+            cm.ResizeConv3d(self._int_chs[0], in_chs, deconv_k_sz, stride=2, activation=self.relu_type(),
+                            norm_layer=self.norm_type(in_chs)),
+            cm.BaseConvBlk3d(in_chs, final_chs, deconv_k_sz, bias_on=True, activation=cm.NoOp(),
+                             norm_layer=cm.NoOp()))
+
+    forward = regulator_forward
+
+
+class UNetCostVolumeRegulator(nn.Module):
+    """Older class named by un-suffixed recipes (configs/base_model.yaml:11-26 passes its kwargs)."""
+    def __init__(self, in_chs: int, final_chs: int, u_depth: int, blk_width: int, stage_factor: int,
+                 cost_k_sz: int, keep_last_chs: Sequence[int], deconv_k_sz: int, sweep_fuse_ch_reduce: int = 2,
+                 num_cams: int = 3, only_one_cam: bool = False, norm_type: str = "batch", relu_type: str = "leaky"):
+        super().__init__()
+        self.in_chs = in_chs if only_one_cam else (in_chs * num_cams) // sweep_fuse_ch_reduce
+        self.final_chs, self.u_depth, self.blkWidth = final_chs, u_depth, blk_width
+        self.stage_factor, self.k_sz = stage_factor, cost_k_sz
+        self.keep_last_chs, self.deconv_k_sz = keep_last_chs, deconv_k_sz
+        self.norm_type = NORM3D_TYPE[norm_type]
+        self.relu_type = RELU_TYPE[relu_type]
+
+        downs = []
+        cin = cout = self.in_chs
+        for lvl in range(u_depth):
+            if lvl not in keep_last_chs:
+                cout *= stage_factor
+            downs.append(UNetDownBlk(cin, cout, cost_k_sz, blk_width, activation=self.relu_type(),
+                                     norm_layer=self.norm_type(cout)))
+            if lvl not in keep_last_chs:
+                cin *= stage_factor
+        self.down_blks = nn.ModuleList(downs)
+
+        top = self.in_chs * stage_factor ** (u_depth - len(keep_last_chs))
+        ups = []
+        cin = cout = top
+        for i in range(u_depth - 1):
+            if i + 1 not in keep_last_chs:
+                cout //= stage_factor
+            ups.append(cm.ResizeConv3d(cin, cout, deconv_k_sz, stride=2, activation=self.relu_type(),
+                                       norm_layer=self.norm_type(cout)))
+            if i + 1 not in keep_last_chs:
+                cin //= stage_factor
+        self.upBlks = nn.ModuleList(ups)
+        self.out_costs = nn.Sequential(
+            cm.ResizeConv3d(2 * self.in_chs, self.in_chs, deconv_k_sz, stride=2, activation=self.relu_type(),
+                            norm_layer=self.norm_type(self.in_chs)),
+            cm.BaseConvBlk3d(self.in_chs, final_chs, deconv_k_sz, bias_on=True, activation=cm.NoOp(),
+                             norm_layer=cm.NoOp()))
+
+    forward = regulator_forward

@@ -1,0 +1,178 @@
+"""Tensor-level wrappers over the C ABI: argument checking, output allocation (PyTorch is
+only the device allocator and stream provider here) and the call through ctypes.
+
+All activations are channels-last fp32 ("NDHWC": [B, D, H, W, C]) unless stated.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+CONV_AUTO, CONV_DIRECT, CONV_MFMA = 0, 1, 2
+
+
+def _stream_ptr(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: mvs_gi_amd runs on the GPU only (tensor is on {t.device}); "
+                           "there is no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------------------
+def sweep_std(feats, grids, grid_masks, masks) -> torch.Tensor:
+    """-> vol_raw [B, D, Ho, Wo, C] (masked variance over cameras)."""
+    lib = _lib.load()
+    feats = _dev(feats, "feats")
+    grids = _dev(grids, "grids")
+    masks = _dev(masks, "masks")
+    if grid_masks.dtype == torch.bool:
+        gm = _dev(grid_masks, "grid_masks", torch.bool)
+        gm_f32 = 0
+    elif grid_masks.dtype == torch.uint8:
+        gm = _dev(grid_masks, "grid_masks", torch.uint8)
+        gm_f32 = 0
+    else:
+        gm = _dev(grid_masks.to(torch.float32) if grid_masks.dtype != torch.float32 else grid_masks, "grid_masks")
+        gm_f32 = 1
+    B, N, C, Hi, Wi = feats.shape
+    Bg, Ng, D, Ho, Wo, two = grids.shape
+    if (Bg, Ng, two) != (B, N, 2):
+        raise AssertionError(f"grids {tuple(grids.shape)} do not match feats {tuple(feats.shape)}")
+    if tuple(gm.shape[:5]) != (B, N, D, Ho, Wo) or gm.numel() != B * N * D * Ho * Wo:
+        raise AssertionError(f"grid_masks {tuple(gm.shape)} do not match grids {tuple(grids.shape)}")
+    if masks.shape[0] != B or masks.shape[1] != N or masks.numel() != B * N * masks.shape[-2] * masks.shape[-1]:
+        raise AssertionError(f"masks {tuple(masks.shape)} do not match feats {tuple(feats.shape)}")
+    Hm, Wm = masks.shape[-2:]
+    vol = torch.empty((B, D, Ho, Wo, C), device=feats.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_sweep_std_f32(feats.data_ptr(), grids.data_ptr(), gm.data_ptr(), gm_f32, masks.data_ptr(),
+                                       vol.data_ptr(), B, N, C, Hi, Wi, Hm, Wm, D, Ho, Wo, _stream_ptr(feats)),
+               "mvsgi_sweep_std_f32")
+    return vol
+
+
+def sweep_cat(feats, grids) -> torch.Tensor:
+    """-> vol_raw [B, D, Ho, Wo, N*C] (channel = cam*C + c)."""
+    lib = _lib.load()
+    feats = _dev(feats, "feats")
+    grids = _dev(grids, "grids")
+    B, N, C, Hi, Wi = feats.shape
+    Bg, Ng, D, Ho, Wo, two = grids.shape
+    if (Bg, Ng, two) != (B, N, 2):
+        raise AssertionError(f"grids {tuple(grids.shape)} do not match feats {tuple(feats.shape)}")
+    vol = torch.empty((B, D, Ho, Wo, N * C), device=feats.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_sweep_cat_f32(feats.data_ptr(), grids.data_ptr(), vol.data_ptr(), B, N, C, Hi, Wi, D, Ho, Wo,
+                                       _stream_ptr(feats)), "mvsgi_sweep_cat_f32")
+    return vol
+
+
+def pack_conv_weights(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
+    """[Cout, Cin, 3, 3, 3] -> MFMA lane-ordered layout, or None when the channel counts
+    are not multiples of 16 (the direct kernel then reads w_oidhw itself)."""
+    lib = _lib.load()
+    w = _dev(w_oidhw, "conv weight")
+    Cout, Cin = w.shape[:2]
+    if tuple(w.shape[2:]) != (3, 3, 3):
+        raise NotImplementedError(f"only 3x3x3 kernels are supported, got {tuple(w.shape[2:])}")
+    if Cout % 16 or Cin % 16:
+        return None
+    wp = torch.empty(lib.mvsgi_conv3d_packed_weight_floats(Cout, Cin), device=w.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_conv3d_pack_weights_f32(w.data_ptr(), wp.data_ptr(), Cout, Cin, _stream_ptr(w)),
+               "mvsgi_conv3d_pack_weights_f32")
+    return wp
+
+
+def conv3d(x, w_oidhw, w_packed, scale, shift, res=None, stride=1, neg_slope=0.01, impl=CONV_AUTO, out=None):
+    """x [B, D, H, W, Cin] -> y [B, Do, Ho, Wo, Cout] = act(conv(x) * scale + shift (+ res));
+    act(v) = v if v > 0 else v * neg_slope (1.0 = no activation)."""
+    lib = _lib.load()
+    x = _dev(x, "x")
+    B, Din, Hin, Win, Cin = x.shape
+    Cout = scale.numel()
+    Do, Ho, Wo = (Din - 1) // stride + 1, (Hin - 1) // stride + 1, (Win - 1) // stride + 1
+    if res is not None:
+        res = _dev(res, "res")
+        if tuple(res.shape) != (B, Do, Ho, Wo, Cout):
+            raise AssertionError(f"residual {tuple(res.shape)} does not match output {(B, Do, Ho, Wo, Cout)}")
+    y = out if out is not None else torch.empty((B, Do, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_conv3d_f32(x.data_ptr(), _ptr(w_oidhw), _ptr(w_packed), scale.data_ptr(), shift.data_ptr(),
+                                    _ptr(res), y.data_ptr(), B, Cin, Din, Hin, Win, Cout, stride, float(neg_slope),
+                                    impl, _stream_ptr(x)), "mvsgi_conv3d_f32")
+    return y
+
+
+def resize_trilinear(x, size) -> torch.Tensor:
+    lib = _lib.load()
+    x = _dev(x, "x")
+    B, Di, Hi, Wi, C = x.shape
+    Do, Ho, Wo = (int(s) for s in size)
+    y = torch.empty((B, Do, Ho, Wo, C), device=x.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_resize_trilinear_f32(x.data_ptr(), y.data_ptr(), B, C, Di, Hi, Wi, Do, Ho, Wo,
+                                              _stream_ptr(x)), "mvsgi_resize_trilinear_f32")
+    return y
+
+
+def softargmin(costs_bdhw, inv_idx, scale: int, want_norm_costs: bool):
+    """costs [B, D, H, W], inv_idx [D] -> inv_dist [B, 1, sH, sW], norm_costs [B, D, sH, sW] | None."""
+    lib = _lib.load()
+    c = _dev(costs_bdhw, "costs")
+    inv_idx = _dev(inv_idx.reshape(-1), "inv_dist_idx")
+    B, D, H, W = c.shape
+    if inv_idx.numel() != D:
+        raise AssertionError(f"{D} cost planes but {inv_idx.numel()} distance candidates")
+    inv = torch.empty((B, 1, H * scale, W * scale), device=c.device, dtype=torch.float32)
+    pr = torch.empty((B, D, H * scale, W * scale), device=c.device, dtype=torch.float32) if want_norm_costs else None
+    _lib.check(lib.mvsgi_softargmin_f32(c.data_ptr(), inv_idx.data_ptr(), inv.data_ptr(), _ptr(pr), B, D, H, W, scale,
+                                        _stream_ptr(c)), "mvsgi_softargmin_f32")
+    return inv, pr
+
+
+def ncdhw_to_ndhwc(x) -> torch.Tensor:
+    """contiguous [B, C, D, H, W] -> [B, D, H, W, C]."""
+    lib = _lib.load()
+    x = _dev(x, "x")
+    B, C, D, H, W = x.shape
+    y = torch.empty((B, D, H, W, C), device=x.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_ncv_to_nvc_f32(x.data_ptr(), y.data_ptr(), B, C, D * H * W, _stream_ptr(x)),
+               "mvsgi_ncv_to_nvc_f32")
+    return y
+
+
+def ndhwc_to_ncdhw(x) -> torch.Tensor:
+    lib = _lib.load()
+    x = _dev(x, "x")
+    B, D, H, W, C = x.shape
+    y = torch.empty((B, C, D, H, W), device=x.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_nvc_to_ncv_f32(x.data_ptr(), y.data_ptr(), B, C, D * H * W, _stream_ptr(x)),
+               "mvsgi_nvc_to_ncv_f32")
+    return y
+
+
+def as_ndhwc(vol: torch.Tensor) -> torch.Tensor:
+    """Accepts the module-boundary volume [B, C, D, H, W] in either memory format and returns the
+    [B, D, H, W, C] view (no copy when it already is channels-last, which is what our
+    cv_builder hands over) or a transposed copy (contiguous NCDHW from another producer)."""
+    if vol.dim() != 5:
+        raise AssertionError(f"expected a [B, C, D, H, W] volume, got {tuple(vol.shape)}")
+    v = vol.permute(0, 2, 3, 4, 1)
+    if v.is_contiguous():
+        return v
+    return ncdhw_to_ndhwc(vol.contiguous())

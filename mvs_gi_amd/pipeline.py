@@ -1,0 +1,61 @@
+"""Build-owned counterpart of the reference's inference facade for this path
+(api/inference_pytorch.py:49-122 + api/inference_class.py:111-127): constant
+grids/grid_masks/masks moved to the device once, the four-stage call under no_grad, and
+inv_dist / bf post-processing.  Used by bench.py, the tests and __graft_entry__.smoke().
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .configs import PathConfig
+from . import dropin
+
+
+def build_modules(cfg: PathConfig, weights: Optional[Dict[str, Dict[str, np.ndarray]]] = None, device="cuda"):
+    """Instantiate the three drop-in modules for a config and (optionally) load state dicts
+    keyed with the reference's names."""
+    Builder = dropin.SphericalSweepStdMasked if cfg.builder == "std" else dropin.SphericalSweep
+    cvb = Builder(num_cams=cfg.num_cams, feat_chs=cfg.vol_chs, post_k_sz=3)
+    reg = dropin.UNetCostVolumeRegulatorBase(in_chs=cfg.reg_in_chs, f_int_chs=cfg.reg_f_int_chs)
+    dr = dropin.DistanceRegressorWithFixedCandidates(bf=cfg.bf, dist_cands=list(cfg.dist_cands),
+                                                     interp_scale_factor=cfg.interp_scale_factor,
+                                                     pre_interp=cfg.pre_interp)
+    if weights is not None:
+        cvb.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in weights["cv_builder"].items()},
+                            strict=True)
+        reg.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in weights["cv_regulator"].items()},
+                            strict=True)
+    mods = [m.eval().to(device) for m in (cvb, reg, dr)]
+    return tuple(mods)
+
+
+class HotPath:
+    """feats -> inv_dist with the rig constants resident on the device."""
+
+    def __init__(self, cfg: PathConfig, weights, consts: Dict[str, np.ndarray], device="cuda"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.cv_builder, self.cv_regulator, self.dist_regressor = build_modules(cfg, weights, device)
+        self.grids = torch.from_numpy(consts["grids"]).to(self.device)
+        self.grid_masks = torch.from_numpy(consts["grid_masks"]).to(self.device)
+        self.masks = torch.from_numpy(consts["masks"]).to(self.device)
+
+    @torch.no_grad()
+    def __call__(self, feats: torch.Tensor):
+        B = feats.shape[0]
+        g, gm, m = self.grids, self.grid_masks, self.masks
+        if g.shape[0] != B:          # rig constants are per-frame identical: replicate for a batch
+            g = g[:1].expand(B, *g.shape[1:]).contiguous()
+            gm = gm[:1].expand(B, *gm.shape[1:]).contiguous()
+            m = m[:1].expand(B, *m.shape[1:]).contiguous()
+            self.grids, self.grid_masks, self.masks = g, gm, m
+        vol = self.cv_builder(feats, g, gm, m)
+        costs = self.cv_regulator(vol)
+        return self.dist_regressor(costs)
+
+    def postprocess(self, inv_dist: torch.Tensor) -> np.ndarray:
+        """inverse-distance index -> 1/m, on the host (api/inference_class.py:111-114)."""
+        return (inv_dist / self.cfg.bf).cpu().numpy()

@@ -1,0 +1,127 @@
+"""CPU: host logic of the drop-in modules -- constructor/state-dict compatibility with the
+reference's names, unpickling of module objects pickled by the reference, install modes,
+and the no-CPU-fallback rule."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+from mvs_gi_amd import dropin, synth
+from mvs_gi_amd.configs import CONFIGS, regulator_conv_specs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("tag", ["G16V", "G16VV", "E8", "4cam-32"])
+def test_state_dict_names_match_reference(tag):
+    cfg = CONFIGS[tag]
+    w = synth.make_weights(cfg, seed=0)
+    Builder = dropin.SphericalSweepStdMasked if cfg.builder == "std" else dropin.SphericalSweep
+    cvb = Builder(num_cams=cfg.num_cams, feat_chs=cfg.vol_chs, post_k_sz=3)
+    reg = dropin.UNetCostVolumeRegulatorBase(in_chs=cfg.reg_in_chs, f_int_chs=cfg.reg_f_int_chs)
+    # synth weights are keyed with the reference's names (checked against the reference
+    # itself by tools/make_goldens.py: strict load_state_dict)
+    cvb.load_state_dict({k: torch.from_numpy(v) for k, v in w["cv_builder"].items()}, strict=True)
+    reg.load_state_dict({k: torch.from_numpy(v) for k, v in w["cv_regulator"].items()}, strict=True)
+    assert len(reg.state_dict()) == 146
+    assert len(regulator_conv_specs(cfg.reg_in_chs, cfg.reg_f_int_chs)) == 25
+
+
+def test_old_regulator_class_is_base_in_2in():
+    old = dropin.UNetCostVolumeRegulator(in_chs=16, final_chs=1, u_depth=3, blk_width=4, stage_factor=2, cost_k_sz=3,
+                                         keep_last_chs=[], deconv_k_sz=3, sweep_fuse_ch_reduce=2, num_cams=3,
+                                         only_one_cam=True)
+    base = dropin.UNetCostVolumeRegulatorBase(16, 32)
+    so, sb = old.state_dict(), base.state_dict()
+    assert list(so) == list(sb)
+    assert all(so[k].shape == sb[k].shape for k in so)
+    cat = dropin.UNetCostVolumeRegulator(in_chs=32, final_chs=1, u_depth=3, blk_width=4, stage_factor=2, cost_k_sz=3,
+                                         keep_last_chs=[], deconv_k_sz=3)   # (32*3)//2 = 48 -> Base(48, 96)
+    assert [tuple(v.shape) for v in cat.state_dict().values()] == \
+           [tuple(v.shape) for v in dropin.UNetCostVolumeRegulatorBase(48, 96).state_dict().values()]
+
+
+def test_regressor_attributes_and_update():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "regress_variants.npz"))
+    dr = dropin.DistanceRegressorWithFixedCandidates(bf=96, dist_cands=list(z["dist_cands"]), interp_scale_factor=2,
+                                                     pre_interp=True)
+    assert list(dr.state_dict()) == ["inv_dist_idx"] and tuple(dr.inv_dist_idx.shape) == (1, 5, 1, 1)
+    dr.update_dist_cands(list(z["updated_cands"]))
+    assert np.allclose([dr.inv_dist_idx_min, dr.inv_dist_idx_max], z["updated_minmax"])
+    assert dropin.DistanceRegressorWithFixedCandidates(interp_scale_factor=-1).interp_scale_factor == 0
+
+
+def test_no_cpu_fallback():
+    cfg = CONFIGS["G16V"].scaled(feat_hw=(8, 16), mask_hw=(16, 32), cv_hw=(4, 8), dist_cands=(0.5, 1, 2, 4))
+    inp = synth.make_inputs(cfg, seed=0)
+    cvb = dropin.SphericalSweepStdMasked(3, 16, 3).eval()
+    with pytest.raises(RuntimeError, match="GPU only"):
+        cvb(*(torch.from_numpy(inp[k]) for k in ("feats", "grids", "grid_masks", "masks")))
+    reg = dropin.UNetCostVolumeRegulatorBase(16, 32).eval()
+    with pytest.raises(RuntimeError, match="GPU only"):
+        reg(torch.zeros(1, 16, 4, 4, 8))
+    dr = dropin.DistanceRegressorWithFixedCandidates(dist_cands=[1, 2, 3, 4], interp_scale_factor=2, pre_interp=True)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        dr(torch.zeros(1, 1, 4, 4, 8))
+
+
+def _run(code: str, extra_path=()):
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, *extra_path])
+    r = subprocess.run([sys.executable, "-c", textwrap.dedent(code)], capture_output=True, text=True, env=env,
+                       cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def test_unpickle_reference_modules_into_dropin_alias_mode():
+    """tests/golden/pickled_modules_tiny.pt holds module OBJECTS pickled by the reference
+    (the way Lightning's save_hyperparameters stores them); with the alias install they
+    unpickle into the drop-in classes without the reference on the path."""
+    out = _run("""
+        import torch, mvs_gi_amd
+        assert mvs_gi_amd.install() == "alias"
+        hp = torch.load("tests/golden/pickled_modules_tiny.pt", weights_only=False)["hyper_parameters"]
+        from mvs_gi_amd import dropin
+        assert type(hp["cv_builder"]) is dropin.SphericalSweepStdMasked, type(hp["cv_builder"])
+        assert type(hp["cv_regulator"]) is dropin.UNetCostVolumeRegulator
+        assert type(hp["dist_regressor"]) is dropin.DistanceRegressorWithFixedCandidates
+        assert type(hp["cv_regulator"].down_blks[0].blks[0].blk1) is dropin.BaseConvBlk3d
+        assert len(hp["cv_regulator"].state_dict()) == 146
+        assert hp["cv_builder"].post_vol.conv_layer.weight.shape == (4, 4, 3, 3, 3)
+        hp["dist_regressor"].update_dist_cands([1, 2, 3, 4, 5, 6, 7, 8])
+        print("OK")
+    """)
+    assert "OK" in out
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/dsta_mvs"), reason="reference checkout not present")
+def test_patch_mode_rebinds_reference_classes():
+    out = _run("""
+        import sys, types
+        tv, ops = types.ModuleType("torchvision"), types.ModuleType("torchvision.ops")
+        ops.deform_conv2d = lambda *a, **k: None; tv.ops = ops
+        sys.modules["torchvision"], sys.modules["torchvision.ops"] = tv, ops
+        import torch, mvs_gi_amd
+        assert mvs_gi_amd.install() == "patch"
+        from dsta_mvs.model.cost_volume_regulator.unet_regulator import UNetCostVolumeRegulatorBase
+        from dsta_mvs.model.cost_volume_builder import SphericalSweepStdMasked
+        assert UNetCostVolumeRegulatorBase.__module__.startswith("dsta_mvs.")
+        reg = UNetCostVolumeRegulatorBase(16, 32).eval()
+        try:
+            reg(torch.zeros(1, 16, 4, 4, 8))
+        except RuntimeError as e:
+            assert "GPU only" in str(e)       # the reference class now routes to the HIP path
+        else:
+            raise SystemExit("reference forward still runs on CPU")
+        from mvs_gi_amd.dropin.install import uninstall
+        uninstall()
+        y = reg(torch.zeros(1, 16, 8, 8, 8))  # original forward restored
+        assert tuple(y.shape) == (1, 1, 8, 8, 8)
+        print("OK")
+    """, extra_path=["/root/reference"])
+    assert "OK" in out
