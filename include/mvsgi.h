@@ -41,7 +41,8 @@ typedef void* mvsgi_stream_t;
 /* conv3d implementation selector */
 #define MVSGI_CONV_AUTO   0   /* MFMA implicit GEMM when Cin%16==0 && Cout%16==0, else direct */
 #define MVSGI_CONV_DIRECT 1   /* VALU direct convolution (any channel counts; Cout==1 head)   */
-#define MVSGI_CONV_MFMA   2   /* v_mfma_f32_16x16x4_f32 implicit GEMM (exact fp32)            */
+#define MVSGI_CONV_MFMA   2   /* LDS-tiled: v_mfma_f32_16x16x4_f32 implicit GEMM (exact fp32),
+                                 or the LDS-tiled VALU head kernel when Cout == 1               */
 
 int         mvsgi_abi_version(void);
 const char* mvsgi_last_error(void);
@@ -73,9 +74,13 @@ int mvsgi_sweep_cat_f32(const float* feats, const float* grids, float* vol,
  * eval-mode BatchNorm3d is the per-channel (scale, shift); a conv bias is shift with
  * scale = 1; act(v) = v > 0 ? v : v * neg_slope  (LeakyReLU: 0.01, ReLU: 0, identity: 1).
  *   x   [B][Din][Hin][Win][Cin]   y / res [B][Do][Ho][Wo][Cout],  Do = (Din-1)/stride+1 ...
- *   w_packed: output of mvsgi_conv3d_pack_weights_f32 (needed by the MFMA path; may be
- *             NULL when impl == MVSGI_CONV_DIRECT);  w_oidhw: the PyTorch [Cout][Cin][3][3][3]
- *             tensor (needed by the direct path; may be NULL when impl == MVSGI_CONV_MFMA).
+ *   w_packed: output of mvsgi_conv3d_pack_weights_f32 (needed by the tiled paths -- MFMA, and
+ *             the Cout == 1 cost head; may be NULL when impl == MVSGI_CONV_DIRECT);
+ *   w_oidhw:  the PyTorch [Cout][Cin][3][3][3] tensor (needed by the direct path; may be NULL
+ *             when impl == MVSGI_CONV_MFMA).
+ * mvsgi_conv3d_variant_f32 names the kernel the dispatcher will launch for a problem (the
+ * demangled kernel name as rocprofv3 prints it; NULL + last_error when unservable), so that
+ * a benchmark can attribute time to the kernel that actually ran.
  */
 size_t mvsgi_conv3d_packed_weight_floats(int Cout, int Cin);
 int mvsgi_conv3d_pack_weights_f32(const float* w_oidhw, float* w_packed, int Cout, int Cin,
@@ -84,6 +89,8 @@ int mvsgi_conv3d_f32(const float* x, const float* w_oidhw, const float* w_packed
                      const float* scale, const float* shift, const float* res, float* y,
                      int B, int Cin, int Din, int Hin, int Win, int Cout,
                      int stride, float neg_slope, int impl, mvsgi_stream_t stream);
+const char* mvsgi_conv3d_variant_f32(int B, int Cin, int Din, int Hin, int Win, int Cout,
+                                     int stride, int impl);
 
 /* ---- K3: trilinear resize ------------------------------------------------------------
  * Replaces F.interpolate(mode='trilinear', align_corners=False, size=...) inside

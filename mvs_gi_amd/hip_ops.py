@@ -92,7 +92,7 @@ def pack_conv_weights(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
     Cout, Cin = w.shape[:2]
     if tuple(w.shape[2:]) != (3, 3, 3):
         raise NotImplementedError(f"only 3x3x3 kernels are supported, got {tuple(w.shape[2:])}")
-    if Cout % 16 or Cin % 16:
+    if Cin % 16 or not (Cout % 16 == 0 or Cout == 1):
         return None
     wp = torch.empty(lib.mvsgi_conv3d_packed_weight_floats(Cout, Cin), device=w.device, dtype=torch.float32)
     _lib.check(lib.mvsgi_conv3d_pack_weights_f32(w.data_ptr(), wp.data_ptr(), Cout, Cin, _stream_ptr(w)),
@@ -117,6 +117,15 @@ def conv3d(x, w_oidhw, w_packed, scale, shift, res=None, stride=1, neg_slope=0.0
                                     _ptr(res), y.data_ptr(), B, Cin, Din, Hin, Win, Cout, stride, float(neg_slope),
                                     impl, _stream_ptr(x)), "mvsgi_conv3d_f32")
     return y
+
+
+def conv3d_variant(B, Cin, Din, Hin, Win, Cout, stride=1, impl=CONV_AUTO) -> str:
+    """Name of the kernel mvsgi_conv3d_f32 will launch for this problem (as rocprofv3 prints it)."""
+    lib = _lib.load()
+    name = lib.mvsgi_conv3d_variant_f32(B, Cin, Din, Hin, Win, Cout, stride, impl)
+    if name is None:
+        raise RuntimeError("mvsgi_conv3d_variant_f32: " + lib.mvsgi_last_error().decode())
+    return name.decode()
 
 
 def resize_trilinear(x, size) -> torch.Tensor:

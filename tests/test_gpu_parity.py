@@ -125,11 +125,20 @@ def test_conv3d_mfma_and_direct_vs_oracle(shape):
 
 def test_conv3d_direct_odd_channels_and_cost_head():
     rng = np.random.default_rng(3)
-    for (Cin, Cout) in ((4, 8), (16, 1), (5, 3)):
-        x, w, scale, shift, r, yref = _conv_case(rng, 1, Cin, Cout, 5, 7, 9, 1, False, 1.0)
-        xg = _g(x).permute(0, 2, 3, 4, 1).contiguous()
-        y = H.conv3d(xg, _g(w), H.pack_conv_weights(_g(w)), _g(scale), _g(shift), neg_slope=1.0)
-        assert _rel(_ncdhw(y), yref) <= 2e-5
+    for (Cin, Cout) in ((4, 8), (16, 1), (5, 3), (48, 1), (64, 1)):
+        for dims in ((5, 7, 9), (8, 16, 24)):
+            x, w, scale, shift, r, yref = _conv_case(rng, 2, Cin, Cout, *dims, 1, False, 1.0)
+            xg = _g(x).permute(0, 2, 3, 4, 1).contiguous()
+            wp = H.pack_conv_weights(_g(w))
+            y = H.conv3d(xg, _g(w), wp, _g(scale), _g(shift), neg_slope=1.0)
+            assert _rel(_ncdhw(y), yref) <= 2e-5
+            name = H.conv3d_variant(2, Cin, *dims, Cout)
+            if Cout == 1 and Cin % 16 == 0:
+                assert "head" in name     # LDS-tiled cost head
+                yd = H.conv3d(xg, _g(w), wp, _g(scale), _g(shift), neg_slope=1.0, impl=H.CONV_DIRECT)
+                assert _rel(_ncdhw(y), _ncdhw(yd)) <= 2e-5
+            else:
+                assert "direct" in name
 
 
 # ------------------------------------------------------------------------------ K3 resize
