@@ -43,6 +43,10 @@ typedef void* mvsgi_stream_t;
 #define MVSGI_CONV_DIRECT 1   /* VALU direct convolution (any channel counts; Cout==1 head)   */
 #define MVSGI_CONV_MFMA   2   /* LDS-tiled: v_mfma_f32_16x16x4_f32 implicit GEMM (exact fp32),
                                  or the LDS-tiled VALU head kernel when Cout == 1               */
+#define MVSGI_CONV_BF16X3 3   /* split-bf16 implicit GEMM on v_mfma_f32_16x16x32_bf16: x = hi + lo,
+                                 hi*hi + hi*lo + lo*hi, fp32 accumulate (~2^-16 per product);
+                                 w_packed must come from mvsgi_conv3d_pack_weights_bf16x3.
+                                 Falls back to the exact paths for Cout == 1 / odd channel counts */
 
 int         mvsgi_abi_version(void);
 const char* mvsgi_last_error(void);
@@ -85,6 +89,9 @@ int mvsgi_sweep_cat_f32(const float* feats, const float* grids, float* vol,
 size_t mvsgi_conv3d_packed_weight_floats(int Cout, int Cin);
 int mvsgi_conv3d_pack_weights_f32(const float* w_oidhw, float* w_packed, int Cout, int Cin,
                                   mvsgi_stream_t stream);
+size_t mvsgi_conv3d_packed_weight_bytes_bf16x3(int Cout, int Cin);
+int mvsgi_conv3d_pack_weights_bf16x3(const float* w_oidhw, void* w_packed, int Cout, int Cin,
+                                     mvsgi_stream_t stream);
 int mvsgi_conv3d_f32(const float* x, const float* w_oidhw, const float* w_packed,
                      const float* scale, const float* shift, const float* res, float* y,
                      int B, int Cin, int Din, int Hin, int Win, int Cout,

@@ -36,10 +36,21 @@ NORM3D_TYPE: Dict[str, Type[nn.Module]] = {"batch": nn.BatchNorm3d, "instance": 
 class ConvLaunch:
     """Device-resident launch arguments of one BaseConvBlk3d: PyTorch-layout weight, packed
     MFMA weight (or None), per-channel scale/shift (eval BatchNorm3d or bias), stride, slope."""
-    __slots__ = ("w", "wp", "scale", "shift", "stride", "neg_slope", "cin", "cout", "key")
+    __slots__ = ("w", "wp", "wp_b3", "scale", "shift", "stride", "neg_slope", "cin", "cout", "key")
 
-    def run(self, x_ndhwc: Tensor, res: Optional[Tensor] = None, impl: int = H.CONV_AUTO) -> Tensor:
-        return H.conv3d(x_ndhwc, self.w, self.wp, self.scale, self.shift, res=res, stride=self.stride,
+    def run(self, x_ndhwc: Tensor, res: Optional[Tensor] = None, impl: Optional[int] = None) -> Tensor:
+        wp = self.wp
+        if impl is None:
+            impl = H.CONV_AUTO
+            if H.get_conv_mode() == "bf16x3" and self.cin % 16 == 0 and self.cout % 16 == 0:
+                if self.wp_b3 is None:
+                    self.wp_b3 = H.pack_conv_weights_bf16x3(self.w)
+                impl, wp = H.CONV_BF16X3, self.wp_b3
+        elif impl == H.CONV_BF16X3:
+            if self.wp_b3 is None:
+                self.wp_b3 = H.pack_conv_weights_bf16x3(self.w)
+            wp = self.wp_b3
+        return H.conv3d(x_ndhwc, self.w, wp, self.scale, self.shift, res=res, stride=self.stride,
                         neg_slope=self.neg_slope, impl=impl)
 
 
@@ -115,6 +126,7 @@ def lower_conv_block(blk) -> ConvLaunch:
     L = ConvLaunch()
     L.w = w
     L.wp = H.pack_conv_weights(w)
+    L.wp_b3 = None
     L.scale = scale.contiguous()
     L.shift = shift.contiguous()
     L.stride = int(conv.stride[0])

@@ -11,7 +11,24 @@ import torch
 
 from . import _lib
 
-CONV_AUTO, CONV_DIRECT, CONV_MFMA = 0, 1, 2
+import os
+
+CONV_AUTO, CONV_DIRECT, CONV_MFMA, CONV_BF16X3 = 0, 1, 2, 3
+
+# Arithmetic of the conv layers: "f32" = exact fp32 MFMA (v_mfma_f32_16x16x4_f32),
+# "bf16x3" = split-bf16 MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate; ~2^-16 per product).
+_CONV_MODE = os.environ.get("MVSGI_CONV_MODE", "f32")
+
+
+def set_conv_mode(mode: str) -> None:
+    global _CONV_MODE
+    if mode not in ("f32", "bf16x3"):
+        raise ValueError(f"conv mode {mode!r} not in ('f32', 'bf16x3')")
+    _CONV_MODE = mode
+
+
+def get_conv_mode() -> str:
+    return _CONV_MODE
 
 
 def _stream_ptr(t: torch.Tensor) -> int:
@@ -97,6 +114,19 @@ def pack_conv_weights(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
     wp = torch.empty(lib.mvsgi_conv3d_packed_weight_floats(Cout, Cin), device=w.device, dtype=torch.float32)
     _lib.check(lib.mvsgi_conv3d_pack_weights_f32(w.data_ptr(), wp.data_ptr(), Cout, Cin, _stream_ptr(w)),
                "mvsgi_conv3d_pack_weights_f32")
+    return wp
+
+
+def pack_conv_weights_bf16x3(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
+    """[Cout, Cin, 3, 3, 3] -> split-bf16 (hi | lo) MFMA layout, or None when unsupported."""
+    lib = _lib.load()
+    w = _dev(w_oidhw, "conv weight")
+    Cout, Cin = w.shape[:2]
+    if tuple(w.shape[2:]) != (3, 3, 3) or Cin % 16 or Cout % 16:
+        return None
+    wp = torch.empty(lib.mvsgi_conv3d_packed_weight_bytes_bf16x3(Cout, Cin), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.mvsgi_conv3d_pack_weights_bf16x3(w.data_ptr(), wp.data_ptr(), Cout, Cin, _stream_ptr(w)),
+               "mvsgi_conv3d_pack_weights_bf16x3")
     return wp
 
 

@@ -123,6 +123,23 @@ def test_conv3d_mfma_and_direct_vs_oracle(shape):
     assert _rel(outs["mfma"], outs["direct"]) <= 2e-5
 
 
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3d_bf16x3_vs_oracle(shape):
+    """Split-bf16 MFMA path: 16-bit operands, fp32 accumulation -> 1e-4 of the tensor max
+    (the fp32 paths above hold 2e-5)."""
+    rng = np.random.default_rng(hash(shape) % (2 ** 31))
+    B, Cin, Cout, D, Hh, W, stride, res, slope = shape
+    x, w, scale, shift, r, yref = _conv_case(rng, *shape)
+    xg = _g(x).permute(0, 2, 3, 4, 1).contiguous()
+    rg = None if r is None else _g(r).permute(0, 2, 3, 4, 1).contiguous()
+    wg = _g(w)
+    wp = H.pack_conv_weights_bf16x3(wg)
+    assert "bf16x3" in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3)
+    y = H.conv3d(xg, wg, wp, _g(scale), _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3)
+    err = _rel(_ncdhw(y), yref)
+    assert err <= 1e-4, err
+
+
 def test_conv3d_direct_odd_channels_and_cost_head():
     rng = np.random.default_rng(3)
     for (Cin, Cout) in ((4, 8), (16, 1), (5, 3), (48, 1), (64, 1)):
@@ -189,8 +206,16 @@ def test_layout_roundtrip_and_regulator_accepts_both_formats():
 
 
 # ------------------------------------------------------------------------------ whole path
+@pytest.fixture(params=["f32", "bf16x3"])
+def conv_mode(request):
+    old = H.get_conv_mode()
+    H.set_conv_mode(request.param)
+    yield request.param
+    H.set_conv_mode(old)
+
+
 @pytest.mark.parametrize("name", list(SMALL_CASES))
-def test_small_cases_vs_reference_goldens(golden_dir, name):
+def test_small_cases_vs_reference_goldens(golden_dir, name, conv_mode):
     case = SMALL_CASES[name]
     cfg = case["cfg"]
     z = _load(golden_dir, name)
@@ -206,16 +231,19 @@ def test_small_cases_vs_reference_goldens(golden_dir, name):
         inv, pr = hp.dist_regressor(costs)
         assert tuple(vol.shape) == (case["batch"], cfg.vol_chs, cfg.num_cands, *cfg.cv_hw)
         err = _rel(inv.cpu().numpy(), z[f"inv_dist_g{gain:g}"])
+        print(f"{name} [{conv_mode}] gain {gain}: inv_dist max-rel {err:.3e}")
         assert err <= 1e-3, (gain, err)          # the north-star bar
-        assert err <= 2e-4, (gain, err)          # what the fp32 path actually delivers
+        if conv_mode == "f32":
+            assert err <= 2e-4, (gain, err)      # what the exact-fp32 path actually delivers
         if "vol" in z and gain == case["gains"][0]:
-            assert _rel(vol.contiguous().cpu().numpy(), z["vol"]) <= 2e-5
-            assert _rel(costs.contiguous().cpu().numpy(), z["costs"]) <= 1e-4
-            assert _rel(pr.cpu().numpy(), z["norm_costs"]) <= 1e-3
+            tol = 1.0 if conv_mode == "f32" else 10.0
+            assert _rel(vol.contiguous().cpu().numpy(), z["vol"]) <= 2e-5 * tol
+            assert _rel(costs.contiguous().cpu().numpy(), z["costs"]) <= 1e-4 * tol
+            assert _rel(pr.cpu().numpy(), z["norm_costs"]) <= 1e-3 * tol
 
 
 @pytest.mark.parametrize("name", list(FULL_CASES))
-def test_full_size_vs_reference_goldens(golden_dir, name):
+def test_full_size_vs_reference_goldens(golden_dir, name, conv_mode):
     """BASELINE.json configs at full size (G16V, G16VV, E8, 4cam-32): inv_dist of the
     reference forward, committed as fixtures, against the HIP path on regenerated inputs."""
     case = FULL_CASES[name]
@@ -237,7 +265,7 @@ def test_full_size_vs_reference_goldens(golden_dir, name):
                              cfg.dist_cands, cfg.bf, cfg.interp_scale_factor, cfg.pre_interp).numpy()
         err = _rel(inv.cpu().numpy(), ref)
         l1 = float(np.abs(inv.cpu().numpy() - ref).mean() / np.abs(ref).mean())
-        print(f"{name} gain {gain}: max-rel {err:.3e} mean-L1-rel {l1:.3e} (golden inputs: {same_inputs})")
+        print(f"{name} [{conv_mode}] gain {gain}: max-rel {err:.3e} mean-L1-rel {l1:.3e} (golden inputs: {same_inputs})")
         assert err <= 1e-3, (gain, err)
         del hp
     torch.cuda.empty_cache()

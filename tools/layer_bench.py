@@ -53,9 +53,11 @@ def main():
     ap.add_argument("--config", default="G16V")
     ap.add_argument("--batch", type=int, nargs="+", default=[1, 8])
     ap.add_argument("--direct", action="store_true")
+    ap.add_argument("--mode", default="f32")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     dev = "cuda:0"
+    H.set_conv_mode(a.mode)
     rng = np.random.default_rng(0)
     for B in a.batch:
         print(f"== {a.config} B={B}")
@@ -64,12 +66,15 @@ def main():
             x = torch.from_numpy(rng.standard_normal((B, d, h, w, cin), dtype=np.float32)).to(dev)
             wt = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32)).to(dev)
             wp = H.pack_conv_weights(wt)
+            wpb = H.pack_conv_weights_bf16x3(wt) if a.mode == "bf16x3" else None
             sc = torch.ones(cout, device=dev)
             sh = torch.zeros(cout, device=dev)
             do, ho, wo = (d - 1) // s + 1, (h - 1) // s + 1, (w - 1) // s + 1
             r = torch.zeros((B, do, ho, wo, cout), device=dev) if res else None
             y = torch.empty((B, do, ho, wo, cout), device=dev)
             impl = H.CONV_DIRECT if (a.direct or wp is None) else H.CONV_MFMA
+            if wpb is not None:
+                impl, wp = H.CONV_BF16X3, wpb
             us = timeit(lambda: H.conv3d(x, wt, wp, sc, sh, res=r, stride=s, impl=impl, out=y))
             gf = 2 * 27 * cin * cout * B * do * ho * wo / 1e9
             mult = 6 if "x6" in name else 1
