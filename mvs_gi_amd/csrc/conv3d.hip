@@ -186,174 +186,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs a) {
     }
 }
 
-// ----------------------------------------------------------------------------------------
-// split-bf16 ("bf16x3") implicit GEMM on v_mfma_f32_16x16x32_bf16
-//   every fp32 operand is split as x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16
-//   significant bits) and a product is evaluated as hi*hi + hi*lo + lo*hi with fp32
-//   accumulation: 3 MFMAs at 16x the fp32-MFMA rate = 5.3x the exact-fp32 kernel, relative
-//   error ~2^-16 per product (the dropped lo*lo term and the 16-bit operands).
-//   K = 32 of one MFMA = two taps x 16 channels: lanes with (lane >> 5) == 0 read tap 2p,
-//   the others tap 2p+1 (27 taps -> 14 pairs, the last one half empty: zero weights).
-//   Activations stay fp32 in HBM; the split happens once per staged element on the way
-//   into LDS (hi[16] | lo[16] | pad, 80 B per voxel, same footprint as the fp32 kernel).
-// ----------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int kVSB = 80;      // LDS bytes per staged voxel in the bf16x3 kernel
-constexpr int kPairs = 14;
-
-// [Cout][Cin][27] -> [Cin/16][14 pairs][Cout/16][hi|lo][64 lanes][8 bf16]
-//   lane = (kg << 4) | i holds W[cout = ct*16+i][cin = cc*16 + (kg&1)*8 + j][tap = 2p + (kg>>1)]
-__global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout, int Cin) {
-    const int CT = Cout / 16;
-    const long long total = (long long)(Cin / 16) * kPairs * CT * 64;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int lane = (int)(idx & 63);
-    long long r = idx >> 6;
-    const int ct = (int)(r % CT);
-    r /= CT;
-    const int p = (int)(r % kPairs);
-    const int cc = (int)(r / kPairs);
-    const int kg = lane >> 4;
-    const int co = ct * 16 + (lane & 15);
-    const int ci = cc * 16 + (kg & 1) * 8;
-    const int tap = 2 * p + (kg >> 1);
-    bf16x8 hi, lo;
-    for (int j = 0; j < 8; ++j) {
-        const float v = tap < 27 ? w[((long long)co * Cin + ci + j) * 27 + tap] : 0.f;
-        const __bf16 h = (__bf16)v;
-        hi[j] = h;
-        lo[j] = (__bf16)(v - (float)h);
-    }
-    const long long o = ((((long long)cc * kPairs + p) * CT + ct) * 2) * 64 + lane;
-    wp[o] = hi;
-    wp[o + 64] = lo;
-}
-
-template <int ITD, int ITH, int ITW>
-__device__ __forceinline__ void stage_slice_split(unsigned char* lds, const float* __restrict__ xb_base, int Cin,
-                                                  int c0, int id0, int ih0, int iw0, int Din, int Hin, int Win,
-                                                  int tid) {
-    constexpr int IV = ITD * ITH * ITW;
-    for (int e = tid; e < IV * 4; e += 256) {
-        const int v = e >> 2, q = e & 3;
-        const int iw = v % ITW, ih = (v / ITW) % ITH, id = v / (ITW * ITH);
-        const int gd = id0 + id, gh = ih0 + ih, gw = iw0 + iw;
-        f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (gd >= 0 && gd < Din && gh >= 0 && gh < Hin && gw >= 0 && gw < Win)
-            val = *reinterpret_cast<const f32x4*>(xb_base + (((long long)gd * Hin + gh) * Win + gw) * Cin + c0 + q * 4);
-        bf16x4 hi, lo;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const __bf16 h = (__bf16)val[k];
-            hi[k] = h;
-            lo[k] = (__bf16)(val[k] - (float)h);
-        }
-        *reinterpret_cast<bf16x4*>(lds + v * kVSB + q * 8) = hi;
-        *reinterpret_cast<bf16x4*>(lds + v * kVSB + 32 + q * 8) = lo;
-    }
-}
-
-template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S>
-__global__ __launch_bounds__(256) void conv3d_bf16x3_kernel(ConvArgs a) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(WM * MW * 16 == TD * TH * TW, "brick must be covered by the voxel tiles");
-    constexpr int ITD = (TD - 1) * S + 3, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave % WM, wn = wave / WM;
-    const int col = lane & 15, kg = lane >> 4;
-    const bool second = kg >= 2;      // this lane's k-range belongs to the pair's second tap
-
-    int t = blockIdx.x;
-    const int tw_i = t % a.tiles_w;
-    t /= a.tiles_w;
-    const int th_i = t % a.tiles_h;
-    t /= a.tiles_h;
-    const int td_i = t % a.tiles_d;
-    const int b = t / a.tiles_d;
-    const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
-    const int id0 = od0 * S - 1, ih0 = oh0 * S - 1, iw0 = ow0 * S - 1;
-
-    const int CT = a.Cout / 16;
-    const int ct0 = (blockIdx.y * WN + wn) * NW;
-
-    int base[MW];
-#pragma unroll
-    for (int i = 0; i < MW; ++i) {
-        const int v = (wm * MW + i) * 16 + col;
-        const int w_ = v % TW, h_ = (v / TW) % TH, d_ = v / (TW * TH);
-        base[i] = (((d_ * S) * ITH + h_ * S) * ITW + w_ * S) * kVSB + (kg & 1) * 16;
-    }
-
-    f32x4 acc[MW][NW];
-#pragma unroll
-    for (int i = 0; i < MW; ++i)
-#pragma unroll
-        for (int j = 0; j < NW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nchunks = a.Cin / 16;
-    const float* xb_base = a.x + (long long)b * a.Din * a.Hin * a.Win * a.Cin;
-    const bf16x8* wpb = reinterpret_cast<const bf16x8*>(a.wp);
-    for (int cc = 0; cc < nchunks; ++cc) {
-        __syncthreads();
-        stage_slice_split<ITD, ITH, ITW>(ldsb, xb_base, a.Cin, cc * 16, id0, ih0, iw0, a.Din, a.Hin, a.Win, tid);
-        __syncthreads();
-        const bf16x8* wp = wpb + (long long)cc * kPairs * CT * 128 + lane;
-#pragma unroll
-        for (int p = 0; p < kPairs; ++p) {
-            const int t0 = 2 * p, t1 = (2 * p + 1 < 27) ? 2 * p + 1 : 2 * p;   // pad tap: weights are 0
-            const int off0 = (((t0 / 9) * ITH + (t0 / 3) % 3) * ITW + t0 % 3) * kVSB;
-            const int off1 = (((t1 / 9) * ITH + (t1 / 3) % 3) * ITW + t1 % 3) * kVSB;
-            const int off = second ? off1 : off0;
-            bf16x8 wh[NW], wl[NW];
-#pragma unroll
-            for (int j = 0; j < NW; ++j) {
-                const int ct = ct0 + j < CT ? ct0 + j : CT - 1;     // clamped; surplus tiles are never stored
-                wh[j] = wp[(long long)(p * CT + ct) * 128];
-                wl[j] = wp[(long long)(p * CT + ct) * 128 + 64];
-            }
-            bf16x8 xh[MW], xl[MW];
-#pragma unroll
-            for (int i = 0; i < MW; ++i) {
-                xh[i] = *reinterpret_cast<const bf16x8*>(ldsb + base[i] + off);
-                xl[i] = *reinterpret_cast<const bf16x8*>(ldsb + base[i] + off + 32);
-            }
-#pragma unroll
-            for (int i = 0; i < MW; ++i)
-#pragma unroll
-                for (int j = 0; j < NW; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], xh[i], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xl[i], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xh[i], acc[i][j], 0, 0, 0);
-                }
-        }
-    }
-
-#pragma unroll
-    for (int i = 0; i < MW; ++i) {
-        const int v = (wm * MW + i) * 16 + col;
-        const int w_ = v % TW, h_ = (v / TW) % TH, d_ = v / (TW * TH);
-        const int od = od0 + d_, oh = oh0 + h_, ow = ow0 + w_;
-        if (od >= a.Do || oh >= a.Ho || ow >= a.Wo) continue;
-        const long long vox = (((long long)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const int ct = ct0 + j;
-            if (ct >= CT) continue;
-            const int co = ct * 16 + kg * 4;
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + co);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + co);
-            f32x4 r = acc[i][j] * sc + sh;
-            if (a.res) r += *reinterpret_cast<const f32x4*>(a.res + vox * a.Cout + co);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : r[e] * a.neg_slope;
-            *reinterpret_cast<f32x4*>(a.y + vox * a.Cout + co) = r;
-        }
-    }
-}
+#include "conv3d_bf16x3.hpp"
 
 // ----------------------------------------------------------------------------------------
 // cost head (Cout == 1, stride 1; unet_regulator.py:61-68): one thread per output voxel of a
@@ -459,14 +292,12 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(ConvArgs a) {
     }
 }
 
-template <int MODE, int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S>
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S>
 int launch_mfma(ConvArgs a, hipStream_t st) {
     constexpr int ITD = (TD - 1) * S + 3, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
-    constexpr size_t lds_bytes = (size_t)ITD * ITH * ITW * kVS * sizeof(float);   // == kVSB bytes per voxel
-    static_assert(kVS * sizeof(float) == kVSB, "both kernels use 80 B per staged voxel");
+    constexpr size_t lds_bytes = (size_t)ITD * ITH * ITW * kVS * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS tile too large");
-    auto kern = MODE == 0 ? conv3d_mfma_kernel<NW, MW, WM, WN, TD, TH, TW, S>
-                          : conv3d_bf16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S>;
+    auto kern = conv3d_mfma_kernel<NW, MW, WM, WN, TD, TH, TW, S>;
     static bool attr_done = false;   // benign race: idempotent
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -513,8 +344,9 @@ int launch_direct(const ConvArgs& a, hipStream_t st) {
 enum Variant {
     V_DIRECT1, V_DIRECT4, V_HEAD,
     V_S1_N16_B256, V_S1_N32_B256, V_S1_N32_B64, V_S1_N64_B128, V_S1_N64_B64, V_S2_N32_B64, V_S2_N64_B64,
-    V_B3_FIRST,   // the same seven tilings on the split-bf16 kernel
-    V_COUNT = V_B3_FIRST + 7
+    // split-bf16 kernel: 16-wide bricks (conflict-free LDS reads); N = couts per workgroup
+    B3_N16, B3_N32, B3_N48, B3_N64, B3_N96, B3_N32_S, B3_N64_S, B3_S2_N32, B3_S2_N64,
+    V_COUNT
 };
 const char* const kVariantNames[V_COUNT] = {
     "conv3d_direct_kernel<1>", "conv3d_direct_kernel<4>", "conv3d_head_kernel",
@@ -522,9 +354,10 @@ const char* const kVariantNames[V_COUNT] = {
     "conv3d_mfma_kernel<2, 1, 4, 1, 2, 4, 8, 1>", "conv3d_mfma_kernel<2, 4, 2, 2, 2, 8, 8, 1>",
     "conv3d_mfma_kernel<2, 2, 2, 2, 2, 4, 8, 1>", "conv3d_mfma_kernel<2, 1, 4, 1, 2, 4, 8, 2>",
     "conv3d_mfma_kernel<2, 2, 2, 2, 2, 4, 8, 2>",
-    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 8, 8, 1>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 8, 8, 1>",
-    "conv3d_bf16x3_kernel<2, 1, 4, 1, 2, 4, 8, 1>", "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 8, 8, 1>",
-    "conv3d_bf16x3_kernel<2, 2, 2, 2, 2, 4, 8, 1>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 2, 4, 8, 2>",
+    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1>",
+    "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1>", "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1>",
+    "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1>",
+    "conv3d_bf16x3_kernel<2, 2, 2, 2, 1, 4, 16, 1>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 2, 4, 8, 2>",
     "conv3d_bf16x3_kernel<2, 2, 2, 2, 2, 4, 8, 2>",
 };
 
@@ -550,13 +383,23 @@ int select_variant(const ConvArgs& a, int impl) {
     }
     const int CT = a.Cout / 16;
     const long long vox = (long long)a.B * a.Do * a.Ho * a.Wo;
-    const int shift = impl == MVSGI_CONV_BF16X3 ? V_B3_FIRST - V_S1_N16_B256 : 0;
-    if (a.stride == 1) {
-        if (CT == 1) return shift + V_S1_N16_B256;
-        if (CT <= 3) return shift + (vox >= 256ll * 512 ? V_S1_N32_B256 : V_S1_N32_B64);
-        return shift + (vox * CT >= 128ll * 4 * 1024 ? V_S1_N64_B128 : V_S1_N64_B64);
+    if (impl == MVSGI_CONV_BF16X3) {
+        if (a.stride == 2) return CT <= 3 ? B3_S2_N32 : B3_S2_N64;
+        // workgroups a 256-voxel (N <= 48) / 128-voxel (N >= 64) brick decomposition would give
+        const long long big = (long long)a.B * mvsgi::cdiv(a.Do, 4) * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
+        const long long mid = (long long)a.B * mvsgi::cdiv(a.Do, 2) * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
+        if (CT == 1) return B3_N16;
+        if (CT == 2) return big >= 384 ? B3_N32 : B3_N32_S;
+        if (CT == 3) return B3_N48;
+        if (CT % 6 == 0 && mid * (CT / 6) >= 384) return B3_N96;
+        return mid * mvsgi::cdiv(CT, 4) >= 384 ? B3_N64 : B3_N64_S;
     }
-    return shift + (CT <= 3 ? V_S2_N32_B64 : V_S2_N64_B64);
+    if (a.stride == 1) {
+        if (CT == 1) return V_S1_N16_B256;
+        if (CT <= 3) return vox >= 256ll * 512 ? V_S1_N32_B256 : V_S1_N32_B64;
+        return vox * CT >= 128ll * 4 * 1024 ? V_S1_N64_B128 : V_S1_N64_B64;
+    }
+    return CT <= 3 ? V_S2_N32_B64 : V_S2_N64_B64;
 }
 
 int launch_variant(int v, const ConvArgs& a, hipStream_t st) {
@@ -564,20 +407,22 @@ int launch_variant(int v, const ConvArgs& a, hipStream_t st) {
         case V_DIRECT1:
         case V_DIRECT4: return launch_direct(a, st);
         case V_HEAD: return launch_head(a, st);
-        case V_S1_N16_B256: return launch_mfma<0, 1, 4, 4, 1, 4, 8, 8, 1>(a, st);
-        case V_S1_N32_B256: return launch_mfma<0, 2, 4, 4, 1, 4, 8, 8, 1>(a, st);
-        case V_S1_N32_B64: return launch_mfma<0, 2, 1, 4, 1, 2, 4, 8, 1>(a, st);
-        case V_S1_N64_B128: return launch_mfma<0, 2, 4, 2, 2, 2, 8, 8, 1>(a, st);
-        case V_S1_N64_B64: return launch_mfma<0, 2, 2, 2, 2, 2, 4, 8, 1>(a, st);
-        case V_S2_N32_B64: return launch_mfma<0, 2, 1, 4, 1, 2, 4, 8, 2>(a, st);
-        case V_S2_N64_B64: return launch_mfma<0, 2, 2, 2, 2, 2, 4, 8, 2>(a, st);
-        case V_B3_FIRST + 0: return launch_mfma<1, 1, 4, 4, 1, 4, 8, 8, 1>(a, st);
-        case V_B3_FIRST + 1: return launch_mfma<1, 2, 4, 4, 1, 4, 8, 8, 1>(a, st);
-        case V_B3_FIRST + 2: return launch_mfma<1, 2, 1, 4, 1, 2, 4, 8, 1>(a, st);
-        case V_B3_FIRST + 3: return launch_mfma<1, 2, 4, 2, 2, 2, 8, 8, 1>(a, st);
-        case V_B3_FIRST + 4: return launch_mfma<1, 2, 2, 2, 2, 2, 4, 8, 1>(a, st);
-        case V_B3_FIRST + 5: return launch_mfma<1, 2, 1, 4, 1, 2, 4, 8, 2>(a, st);
-        case V_B3_FIRST + 6: return launch_mfma<1, 2, 2, 2, 2, 2, 4, 8, 2>(a, st);
+        case V_S1_N16_B256: return launch_mfma<1, 4, 4, 1, 4, 8, 8, 1>(a, st);
+        case V_S1_N32_B256: return launch_mfma<2, 4, 4, 1, 4, 8, 8, 1>(a, st);
+        case V_S1_N32_B64: return launch_mfma<2, 1, 4, 1, 2, 4, 8, 1>(a, st);
+        case V_S1_N64_B128: return launch_mfma<2, 4, 2, 2, 2, 8, 8, 1>(a, st);
+        case V_S1_N64_B64: return launch_mfma<2, 2, 2, 2, 2, 4, 8, 1>(a, st);
+        case V_S2_N32_B64: return launch_mfma<2, 1, 4, 1, 2, 4, 8, 2>(a, st);
+        case V_S2_N64_B64: return launch_mfma<2, 2, 2, 2, 2, 4, 8, 2>(a, st);
+        case B3_N16: return launch_bf16x3<1, 4, 4, 1, 4, 4, 16, 1>(a, st);
+        case B3_N32: return launch_bf16x3<2, 4, 4, 1, 4, 4, 16, 1>(a, st);
+        case B3_N48: return launch_bf16x3<3, 4, 4, 1, 4, 4, 16, 1>(a, st);
+        case B3_N64: return launch_bf16x3<2, 4, 2, 2, 2, 4, 16, 1>(a, st);
+        case B3_N96: return launch_bf16x3<3, 4, 2, 2, 2, 4, 16, 1>(a, st);
+        case B3_N32_S: return launch_bf16x3<2, 1, 4, 1, 1, 4, 16, 1>(a, st);
+        case B3_N64_S: return launch_bf16x3<2, 2, 2, 2, 1, 4, 16, 1>(a, st);
+        case B3_S2_N32: return launch_bf16x3<2, 1, 4, 1, 2, 4, 8, 2>(a, st);
+        case B3_S2_N64: return launch_bf16x3<2, 2, 2, 2, 2, 4, 8, 2>(a, st);
     }
     return mvsgi::fail("mvsgi_conv3d_f32: bad variant %d", v);
 }
