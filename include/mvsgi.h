@@ -72,6 +72,17 @@ int mvsgi_sweep_cat_f32(const float* feats, const float* grids, float* vol,
                         int B, int N, int C, int Hi, int Wi,
                         int D, int Ho, int Wo, mvsgi_stream_t stream);
 
+/* The same two sweeps on channels-last feature maps, feats [B][N][Hi][Wi][C] (C % 4 == 0; std: N <= 4):
+ * one 64-byte texel per tap instead of C strided planes.  The Python layer transposes the
+ * feature extractor's NCHW output once (mvsgi_ncv_to_nvc_f32) unless it already is channels-last. */
+int mvsgi_sweep_std_nhwc_f32(const float* feats, const float* grids, const void* grid_masks,
+                             int grid_mask_is_f32, const float* masks, float* vol,
+                             int B, int N, int C, int Hi, int Wi, int Hm, int Wm,
+                             int D, int Ho, int Wo, mvsgi_stream_t stream);
+int mvsgi_sweep_cat_nhwc_f32(const float* feats, const float* grids, float* vol,
+                             int B, int N, int C, int Hi, int Wi,
+                             int D, int Ho, int Wo, mvsgi_stream_t stream);
+
 /* ---- K2: 3x3x3 convolution block -----------------------------------------------------
  * Replaces BaseConvBlk3d.forward (common/common_modules.py:107-115):
  *   y = act( conv3d(x, w, pad=1, stride) * scale[co] + shift[co] (+ res) )

@@ -31,16 +31,15 @@ template <int VEC>
 __global__ __launch_bounds__(256) void resize_trilinear_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                int B, int C, int Di, int Hi, int Wi, int Do, int Ho,
                                                                int Wo, float sd, float sh, float sw) {
+    // grid = (ceil(Wo * C/VEC / 256), Ho, B * Do): only one 32-bit division per lane
     const int cg = C / VEC;
-    const long long total = (long long)B * Do * Ho * Wo * cg;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int c = (int)(idx % cg) * VEC;
-    const long long vox = idx / cg;
-    const int ow = (int)(vox % Wo);
-    const int oh = (int)((vox / Wo) % Ho);
-    const int od = (int)((vox / ((long long)Wo * Ho)) % Do);
-    const int b = (int)(vox / ((long long)Wo * Ho * Do));
+    const int xi = blockIdx.x * 256 + threadIdx.x;
+    if (xi >= Wo * cg) return;
+    const int ow = xi / cg;
+    const int c = (xi - ow * cg) * VEC;
+    const int oh = blockIdx.y;
+    const int b = blockIdx.z / Do, od = blockIdx.z - b * Do;
+    const long long vox = (((long long)b * Do + od) * Ho + oh) * Wo + ow;
     const Axis ad = axis_setup(od, Di, sd), ah = axis_setup(oh, Hi, sh), aw = axis_setup(ow, Wi, sw);
     const float* xb = x + (long long)b * Di * Hi * Wi * C + c;
     float r[VEC];
@@ -93,14 +92,16 @@ extern "C" int mvsgi_resize_trilinear_f32(const float* x, float* y, int B, int C
                   "mvsgi_resize_trilinear_f32: non-positive dimension");
     const float sd = (float)Di / (float)Do, sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
     hipStream_t st = mvsgi::as_stream(stream);
+    MVSGI_REQUIRE(Ho < 65536 && (long long)B * Do < 65536 && (long long)Wo * C < (1ll << 31),
+                  "mvsgi_resize_trilinear_f32: dimensions exceed the launch geometry");
     if (C % 4 == 0) {
-        const long long total = (long long)B * Do * Ho * Wo * (C / 4);
-        hipLaunchKernelGGL((resize_trilinear_kernel<4>), dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0, st, x,
-                           y, B, C, Di, Hi, Wi, Do, Ho, Wo, sd, sh, sw);
+        const dim3 grid((unsigned)mvsgi::cdiv((long long)Wo * (C / 4), 256), (unsigned)Ho, (unsigned)(B * Do));
+        hipLaunchKernelGGL((resize_trilinear_kernel<4>), grid, dim3(256), 0, st, x, y, B, C, Di, Hi, Wi, Do, Ho, Wo, sd,
+                           sh, sw);
     } else {
-        const long long total = (long long)B * Do * Ho * Wo * C;
-        hipLaunchKernelGGL((resize_trilinear_kernel<1>), dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0, st, x,
-                           y, B, C, Di, Hi, Wi, Do, Ho, Wo, sd, sh, sw);
+        const dim3 grid((unsigned)mvsgi::cdiv((long long)Wo * C, 256), (unsigned)Ho, (unsigned)(B * Do));
+        hipLaunchKernelGGL((resize_trilinear_kernel<1>), grid, dim3(256), 0, st, x, y, B, C, Di, Hi, Wi, Do, Ho, Wo, sd,
+                           sh, sw);
     }
     return mvsgi::check_launch("mvsgi_resize_trilinear_f32");
 }

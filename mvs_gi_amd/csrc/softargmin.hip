@@ -40,13 +40,12 @@ __global__ __launch_bounds__(256) void softargmin_kernel(const float* __restrict
                                                          const float* __restrict__ inv_idx,
                                                          float* __restrict__ inv_dist, float* __restrict__ norm_costs,
                                                          int B, int D, int H, int W, int scale) {
+    // grid = (ceil(OW / 256), OH, B)
     const int OH = H * scale, OW = W * scale;
-    const long long total = (long long)B * OH * OW;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int ox = (int)(idx % OW);
-    const int oy = (int)((idx / OW) % OH);
-    const int b = (int)(idx / ((long long)OW * OH));
+    const int ox = blockIdx.x * 256 + threadIdx.x;
+    if (ox >= OW) return;
+    const int oy = blockIdx.y, b = blockIdx.z;
+    const long long idx = ((long long)b * OH + oy) * OW + ox;
     const Axis2 ay = axis2(oy, H, scale), ax = axis2(ox, W, scale);
     const long long HW = (long long)H * W;
     const float* cb = costs + (long long)b * D * HW;
@@ -81,8 +80,8 @@ extern "C" int mvsgi_softargmin_f32(const float* costs, const float* inv_idx, fl
     MVSGI_REQUIRE(costs && inv_idx && inv_dist, "mvsgi_softargmin_f32: null pointer");
     MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_softargmin_f32: non-positive dimension");
     MVSGI_REQUIRE(scale == 1 || scale == 2, "mvsgi_softargmin_f32: scale %d not in {1, 2}", scale);
-    const long long total = (long long)B * H * scale * W * scale;
-    hipLaunchKernelGGL(softargmin_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0,
+    MVSGI_REQUIRE(H * scale < 65536 && B < 65536, "mvsgi_softargmin_f32: dimensions exceed the launch geometry");
+    hipLaunchKernelGGL(softargmin_kernel, dim3((unsigned)mvsgi::cdiv(W * scale, 256), (unsigned)(H * scale), (unsigned)B), dim3(256), 0,
                        mvsgi::as_stream(stream), costs, inv_idx, inv_dist, norm_costs, B, D, H, W, scale);
     return mvsgi::check_launch("mvsgi_softargmin_f32");
 }

@@ -60,6 +60,22 @@ __device__ __forceinline__ float bilin_fetch(const float* __restrict__ plane, co
     return ((i00 * t.w00 + i01 * t.w01) + i10 * t.w10) + i11 * t.w11;
 }
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// Correctly rounded x / d for a small positive integer-valued d, given inv = RN(1 / d):
+// q = RN(x * inv); r = x - d*q (exact in an fma); q' = RN(q + r * inv)  (Markstein).  Identical to
+// IEEE division for normal-range results; the (never observed) tiny / huge / non-finite cases
+// take the hardware division so the result stays bit-identical to the reference's torch.div.
+__device__ __forceinline__ float div_small(float x, float d, float inv) {
+    const float ax = fabsf(x);
+    const float q = x * inv;
+    const float r = __builtin_fmaf(-d, q, x);
+    float res = __builtin_fmaf(r, inv, q);
+    if (ax == 0.0f) res = x;                                         // +-0 / d = +-0
+    else if (!(ax >= 1e-30f && ax <= 1e30f)) res = x / d;            // rare: exact hardware path
+    return res;
+}
+
 struct SweepDims {
     int B, N, C, Hi, Wi, Hm, Wm, D, Ho, Wo;
 };
@@ -169,6 +185,126 @@ __global__ __launch_bounds__(256) void sweep_cat_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// channels-last variants: feats [B][N][Hi][Wi][C].  Four lanes share one output voxel, each owning
+// channel quads {q, q+4, ...}: a tap is one 16-byte load per lane and the four lanes of a voxel
+// read one contiguous 64-byte texel (C == 16), 4x fewer gather instructions than the NCHW kernel
+// and 4x more waves in flight.  The per-camera set-up (bilinear taps of the feature map, the mask
+// sample, validity) is computed once -- lane q of a quad takes camera q -- and shared through
+// quad shuffles.  Arithmetic is unchanged (bit-identical output).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4_t ld4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
+
+__device__ __forceinline__ f32x4_t bilin_fetch4(const float* __restrict__ img, int C, const Bilin& t) {
+#pragma clang fp contract(off)
+    const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4_t i00 = t.o00 >= 0 ? ld4(img + t.o00 * C) : z;      // o < Hi*Wi, o*C fits 32 bits (checked on host)
+    const f32x4_t i01 = t.o01 >= 0 ? ld4(img + t.o01 * C) : z;
+    const f32x4_t i10 = t.o10 >= 0 ? ld4(img + t.o10 * C) : z;
+    const f32x4_t i11 = t.o11 >= 0 ? ld4(img + t.o11 * C) : z;
+    return ((i00 * t.w00 + i01 * t.w01) + i10 * t.w10) + i11 * t.w11;
+}
+
+// grid = (ceil(Wo / 64), Ho, B * D); block = 64 voxels x 4 lanes.  No per-lane integer division:
+// (b, d, ho) come from the block index, wo from the thread index.
+template <int NCAM>
+__global__ __launch_bounds__(256) void sweep_std_nhwc_kernel(const float* __restrict__ feats,
+                                                             const float* __restrict__ grids,
+                                                             const unsigned char* __restrict__ gm_u8,
+                                                             const float* __restrict__ gm_f32,
+                                                             const float* __restrict__ masks,
+                                                             float* __restrict__ vol, SweepDims s) {
+#pragma clang fp contract(off)
+    static_assert(NCAM <= 4, "one camera per lane of a quad");
+    const int q = threadIdx.x & 3;
+    int wo = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool live = wo < s.Wo;
+    if (!live) wo = s.Wo - 1;            // keep whole quads alive for the shuffles
+    const int ho = blockIdx.y;
+    const int b = blockIdx.z / s.D, d = blockIdx.z - b * s.D;
+    const int HWm = s.Hm * s.Wm, HWi = s.Hi * s.Wi;
+
+    // lane q sets up camera q
+    Bilin mine = {};
+    float myvalid = 0.f;
+    if (q < NCAM) {
+        const long long grow = (((long long)(b * NCAM + q) * s.D + d) * s.Ho + ho) * s.Wo;   // wave-uniform
+        const float2 gxy = *reinterpret_cast<const float2*>(grids + (grow + wo) * 2);
+        mine = bilin_setup(gxy.x, gxy.y, s.Wi, s.Hi);
+        const Bilin mt = bilin_setup(gxy.x, gxy.y, s.Wm, s.Hm);
+        const float sm = bilin_fetch(masks + (long long)(b * NCAM + q) * HWm, mt);
+        const bool gmv = gm_f32 ? (gm_f32[grow + wo] != 0.0f) : (gm_u8[grow + wo] != 0);
+        myvalid = ((sm > 0.0f) && gmv) ? 1.0f : 0.0f;
+    }
+    const int lane = threadIdx.x & 63, qbase = lane & ~3;
+    Bilin ft[NCAM];
+    float vf[NCAM];
+    float n = 0.0f;
+#pragma unroll
+    for (int cam = 0; cam < NCAM; ++cam) {
+        const int src = qbase + cam;
+        ft[cam].o00 = __shfl(mine.o00, src);
+        ft[cam].o01 = __shfl(mine.o01, src);
+        ft[cam].o10 = __shfl(mine.o10, src);
+        ft[cam].o11 = __shfl(mine.o11, src);
+        ft[cam].w00 = __shfl(mine.w00, src);
+        ft[cam].w01 = __shfl(mine.w01, src);
+        ft[cam].w10 = __shfl(mine.w10, src);
+        ft[cam].w11 = __shfl(mine.w11, src);
+        vf[cam] = __shfl(myvalid, src);
+        n = n + vf[cam];
+    }
+    const bool ok = n > 1.0f;
+    const float cnt = ok ? n : 1.0f;
+    const float inv = 1.0f / cnt;
+    float* out = vol + ((((long long)b * s.D + d) * s.Ho + ho) * s.Wo + wo) * s.C;
+    const float* fb = feats + (long long)b * NCAM * HWi * s.C;
+    for (int c = q * 4; c < s.C; c += 16) {
+        f32x4_t sv[NCAM];
+#pragma unroll
+        for (int cam = 0; cam < NCAM; ++cam) sv[cam] = bilin_fetch4(fb + (long long)cam * HWi * s.C + c, s.C, ft[cam]);
+        f32x4_t r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int cam = 0; cam < NCAM; ++cam) sum = sum + sv[cam][k] * vf[cam];
+            const float avg = div_small(sum, cnt, inv);
+            float var = 0.0f;
+#pragma unroll
+            for (int cam = 0; cam < NCAM; ++cam) {
+                const float t = vf[cam] != 0.0f ? sv[cam][k] : avg;
+                const float df = t - avg;
+                var = var + df * df;
+            }
+            var = div_small(var, cnt, inv);
+            r[k] = ok ? var : 0.0f;
+        }
+        if (live) *reinterpret_cast<f32x4_t*>(out + c) = r;
+    }
+}
+
+// grid = (ceil(Wo / 64), Ho * N, B * D)
+__global__ __launch_bounds__(256) void sweep_cat_nhwc_kernel(const float* __restrict__ feats,
+                                                             const float* __restrict__ grids,
+                                                             float* __restrict__ vol, SweepDims s) {
+#pragma clang fp contract(off)
+    const int q = threadIdx.x & 3;
+    const int wo = blockIdx.x * 64 + (threadIdx.x >> 2);
+    if (wo >= s.Wo) return;
+    const int ho = blockIdx.y / s.N, cam = blockIdx.y - ho * s.N;
+    const int b = blockIdx.z / s.D, d = blockIdx.z - b * s.D;
+    const long long grow = (((long long)(b * s.N + cam) * s.D + d) * s.Ho + ho) * s.Wo;
+    const float2 gxy = *reinterpret_cast<const float2*>(grids + (grow + wo) * 2);
+    const Bilin ft = bilin_setup(gxy.x, gxy.y, s.Wi, s.Hi);
+    const int HWi = s.Hi * s.Wi;
+    const long long vox = (((long long)b * s.D + d) * s.Ho + ho) * s.Wo + wo;
+    float* out = vol + vox * ((long long)s.N * s.C) + (long long)cam * s.C;
+    const float* img = feats + (long long)(b * s.N + cam) * HWi * s.C;
+    for (int c = q * 4; c < s.C; c += 16)
+        *reinterpret_cast<f32x4_t*>(out + c) = bilin_fetch4(img + c, s.C, ft);
+}
+
 int check_dims(const SweepDims& s, const char* who) {
     MVSGI_REQUIRE(s.B > 0 && s.N > 0 && s.C > 0 && s.Hi > 0 && s.Wi > 0 && s.D > 0 && s.Ho > 0 && s.Wo > 0,
                   "%s: non-positive dimension", who);
@@ -227,4 +363,43 @@ extern "C" int mvsgi_sweep_cat_f32(const float* feats, const float* grids, float
     else
         hipLaunchKernelGGL((sweep_cat_kernel<1>), grid, block, 0, st, feats, grids, vol, s);
     return mvsgi::check_launch("mvsgi_sweep_cat_f32");
+}
+
+// Channels-last feature maps: feats [B][N][Hi][Wi][C], C % 4 == 0, N <= 4 (std).  Same outputs.
+extern "C" int mvsgi_sweep_std_nhwc_f32(const float* feats, const float* grids, const void* grid_masks,
+                                        int grid_mask_is_f32, const float* masks, float* vol, int B, int N,
+                                        int C, int Hi, int Wi, int Hm, int Wm, int D, int Ho, int Wo,
+                                        mvsgi_stream_t stream) {
+    SweepDims s{B, N, C, Hi, Wi, Hm, Wm, D, Ho, Wo};
+    if (check_dims(s, "mvsgi_sweep_std_nhwc_f32")) return 1;
+    MVSGI_REQUIRE(Hm > 0 && Wm > 0, "mvsgi_sweep_std_nhwc_f32: non-positive mask size");
+    MVSGI_REQUIRE(feats && grids && grid_masks && masks && vol, "mvsgi_sweep_std_nhwc_f32: null pointer");
+    MVSGI_REQUIRE(N >= 1 && N <= 4, "mvsgi_sweep_std_nhwc_f32: num_cams %d not in [1, 4]", N);
+    MVSGI_REQUIRE(C % 4 == 0, "mvsgi_sweep_std_nhwc_f32: C=%d must be a multiple of 4", C);
+    MVSGI_REQUIRE((long long)Hi * Wi * C < (1ll << 31) && Ho < 65536 && (long long)B * D < 65536,
+                  "mvsgi_sweep_std_nhwc_f32: dimensions exceed the launch geometry");
+    const dim3 grid((unsigned)mvsgi::cdiv(Wo, 64), (unsigned)Ho, (unsigned)(B * D)), block(256);
+    const unsigned char* g8 = grid_mask_is_f32 ? nullptr : static_cast<const unsigned char*>(grid_masks);
+    const float* g32 = grid_mask_is_f32 ? static_cast<const float*>(grid_masks) : nullptr;
+    hipStream_t st = mvsgi::as_stream(stream);
+    switch (N) {
+        case 1: hipLaunchKernelGGL((sweep_std_nhwc_kernel<1>), grid, block, 0, st, feats, grids, g8, g32, masks, vol, s); break;
+        case 2: hipLaunchKernelGGL((sweep_std_nhwc_kernel<2>), grid, block, 0, st, feats, grids, g8, g32, masks, vol, s); break;
+        case 3: hipLaunchKernelGGL((sweep_std_nhwc_kernel<3>), grid, block, 0, st, feats, grids, g8, g32, masks, vol, s); break;
+        case 4: hipLaunchKernelGGL((sweep_std_nhwc_kernel<4>), grid, block, 0, st, feats, grids, g8, g32, masks, vol, s); break;
+    }
+    return mvsgi::check_launch("mvsgi_sweep_std_nhwc_f32");
+}
+
+extern "C" int mvsgi_sweep_cat_nhwc_f32(const float* feats, const float* grids, float* vol, int B, int N, int C,
+                                        int Hi, int Wi, int D, int Ho, int Wo, mvsgi_stream_t stream) {
+    SweepDims s{B, N, C, Hi, Wi, 1, 1, D, Ho, Wo};
+    if (check_dims(s, "mvsgi_sweep_cat_nhwc_f32")) return 1;
+    MVSGI_REQUIRE(feats && grids && vol, "mvsgi_sweep_cat_nhwc_f32: null pointer");
+    MVSGI_REQUIRE(C % 4 == 0, "mvsgi_sweep_cat_nhwc_f32: C=%d must be a multiple of 4", C);
+    MVSGI_REQUIRE((long long)Hi * Wi * C < (1ll << 31) && (long long)Ho * N < 65536 && (long long)B * D < 65536,
+                  "mvsgi_sweep_cat_nhwc_f32: dimensions exceed the launch geometry");
+    hipLaunchKernelGGL(sweep_cat_nhwc_kernel, dim3((unsigned)mvsgi::cdiv(Wo, 64), (unsigned)(Ho * N), (unsigned)(B * D)),
+                       dim3(256), 0, mvsgi::as_stream(stream), feats, grids, vol, s);
+    return mvsgi::check_launch("mvsgi_sweep_cat_nhwc_f32");
 }

@@ -55,9 +55,29 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 # --------------------------------------------------------------------------------------
-def sweep_std(feats, grids, grid_masks, masks) -> torch.Tensor:
-    """-> vol_raw [B, D, Ho, Wo, C] (masked variance over cameras)."""
+def _feats_nhwc(feats):
+    """[B, N, C, Hi, Wi] -> channels-last storage [B, N, Hi, Wi, C] (no copy if it already is)."""
+    if feats.dim() != 5:
+        raise AssertionError(f"feats must be [B, N, C, Hi, Wi], got {tuple(feats.shape)}")
+    v = feats.permute(0, 1, 3, 4, 2)
+    if v.is_contiguous() and v.data_ptr() % 16 == 0 and v.is_cuda and v.dtype == torch.float32:
+        return v
     lib = _lib.load()
+    f = _dev(feats, "feats")
+    B, N, C, Hi, Wi = f.shape
+    y = torch.empty((B, N, Hi, Wi, C), device=f.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_ncv_to_nvc_f32(f.data_ptr(), y.data_ptr(), B * N, C, Hi * Wi, _stream_ptr(f)),
+               "mvsgi_ncv_to_nvc_f32")
+    return y
+
+
+def sweep_std(feats, grids, grid_masks, masks, layout: str = "auto") -> torch.Tensor:
+    """-> vol_raw [B, D, Ho, Wo, C] (masked variance over cameras).  layout: 'auto' uses the
+    channels-last kernel when C % 4 == 0 and N <= 4 (transposing NCHW feats once), 'nchw'
+    forces the plane-gather kernel."""
+    lib = _lib.load()
+    if layout == "auto" and feats.dim() == 5 and feats.shape[2] % 4 == 0 and feats.shape[1] <= 4:
+        return _sweep_std_nhwc(feats, grids, grid_masks, masks)
     feats = _dev(feats, "feats")
     grids = _dev(grids, "grids")
     masks = _dev(masks, "masks")
@@ -86,9 +106,50 @@ def sweep_std(feats, grids, grid_masks, masks) -> torch.Tensor:
     return vol
 
 
-def sweep_cat(feats, grids) -> torch.Tensor:
+def _gm_arg(grid_masks):
+    if grid_masks.dtype == torch.bool:
+        return _dev(grid_masks, "grid_masks", torch.bool), 0
+    if grid_masks.dtype == torch.uint8:
+        return _dev(grid_masks, "grid_masks", torch.uint8), 0
+    return _dev(grid_masks.to(torch.float32) if grid_masks.dtype != torch.float32 else grid_masks, "grid_masks"), 1
+
+
+def _sweep_std_nhwc(feats, grids, grid_masks, masks) -> torch.Tensor:
+    lib = _lib.load()
+    B, N, C, Hi, Wi = feats.shape
+    f = _feats_nhwc(feats)
+    grids = _dev(grids, "grids")
+    masks = _dev(masks, "masks")
+    gm, gm_f32 = _gm_arg(grid_masks)
+    Bg, Ng, D, Ho, Wo, two = grids.shape
+    if (Bg, Ng, two) != (B, N, 2):
+        raise AssertionError(f"grids {tuple(grids.shape)} do not match feats {tuple(feats.shape)}")
+    if tuple(gm.shape[:5]) != (B, N, D, Ho, Wo) or gm.numel() != B * N * D * Ho * Wo:
+        raise AssertionError(f"grid_masks {tuple(gm.shape)} do not match grids {tuple(grids.shape)}")
+    if masks.shape[0] != B or masks.shape[1] != N or masks.numel() != B * N * masks.shape[-2] * masks.shape[-1]:
+        raise AssertionError(f"masks {tuple(masks.shape)} do not match feats {tuple(feats.shape)}")
+    Hm, Wm = masks.shape[-2:]
+    vol = torch.empty((B, D, Ho, Wo, C), device=f.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_sweep_std_nhwc_f32(f.data_ptr(), grids.data_ptr(), gm.data_ptr(), gm_f32, masks.data_ptr(),
+                                            vol.data_ptr(), B, N, C, Hi, Wi, Hm, Wm, D, Ho, Wo, _stream_ptr(f)),
+               "mvsgi_sweep_std_nhwc_f32")
+    return vol
+
+
+def sweep_cat(feats, grids, layout: str = "auto") -> torch.Tensor:
     """-> vol_raw [B, D, Ho, Wo, N*C] (channel = cam*C + c)."""
     lib = _lib.load()
+    if layout == "auto" and feats.dim() == 5 and feats.shape[2] % 4 == 0:
+        B, N, C, Hi, Wi = feats.shape
+        f = _feats_nhwc(feats)
+        grids = _dev(grids, "grids")
+        Bg, Ng, D, Ho, Wo, two = grids.shape
+        if (Bg, Ng, two) != (B, N, 2):
+            raise AssertionError(f"grids {tuple(grids.shape)} do not match feats {tuple(feats.shape)}")
+        vol = torch.empty((B, D, Ho, Wo, N * C), device=f.device, dtype=torch.float32)
+        _lib.check(lib.mvsgi_sweep_cat_nhwc_f32(f.data_ptr(), grids.data_ptr(), vol.data_ptr(), B, N, C, Hi, Wi, D,
+                                                Ho, Wo, _stream_ptr(f)), "mvsgi_sweep_cat_nhwc_f32")
+        return vol
     feats = _dev(feats, "feats")
     grids = _dev(grids, "grids")
     B, N, C, Hi, Wi = feats.shape

@@ -46,9 +46,16 @@ def test_sweep_edges_bit_exact(golden_dir):
     f, g, m = _g(z["feats"]), _g(z["grids"]), _g(z["masks"])
     gm = _g(z["grid_masks_bool"])
     for gmask in (gm, gm.float(), gm.to(torch.uint8)):
-        v = _ncdhw(H.sweep_std(f, g, gmask, m))
+        v = _ncdhw(H.sweep_std(f, g, gmask, m))          # C = 5: plane-gather (NCHW) kernel
         assert np.array_equal(v, z["vol_raw_std_bool"])
     assert np.array_equal(_ncdhw(H.sweep_cat(f, g)), z["vol_raw_cat"])
+    # channels-last kernels on the same edge cases: pad C 5 -> 8 with zero planes
+    f8 = torch.cat([f, torch.zeros_like(f[:, :, :3])], dim=2).contiguous()
+    for gmask in (gm, gm.float()):
+        v8 = _ncdhw(H.sweep_std(f8, g, gmask, m))
+        assert np.array_equal(v8[:, :5], z["vol_raw_std_bool"]) and not v8[:, 5:].any()
+    c8 = _ncdhw(H.sweep_cat(f8, g)).reshape(2, 3, 8, *z["vol_raw_cat"].shape[2:])
+    assert np.array_equal(c8[:, :, :5].reshape(z["vol_raw_cat"].shape), z["vol_raw_cat"])
 
 
 @pytest.mark.parametrize("name", ["std_d8", "std_d16_rand", "cat_d8", "std_d10_odd"])
@@ -59,11 +66,14 @@ def test_sweep_seeded_bit_exact(golden_dir, name):
     inp = synth.make_inputs(cfg, seed=case["seed"], batch=case["batch"], grid_kind=case["grid_kind"],
                             grid_mask_dtype=case["grid_mask_dtype"])
     assert synth.digest(inp) == str(z["inputs_sha256"])
-    if cfg.builder == "std":
-        v = H.sweep_std(_g(inp["feats"]), _g(inp["grids"]), _g(inp["grid_masks"]), _g(inp["masks"]))
-    else:
-        v = H.sweep_cat(_g(inp["feats"]), _g(inp["grids"]))
-    assert np.array_equal(_ncdhw(v), z["vol_raw"])
+    feats = _g(inp["feats"])
+    feats_cl = feats.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)   # already channels-last storage
+    for layout, ft in (("auto", feats), ("auto", feats_cl), ("nchw", feats)):
+        if cfg.builder == "std":
+            v = H.sweep_std(ft, _g(inp["grids"]), _g(inp["grid_masks"]), _g(inp["masks"]), layout=layout)
+        else:
+            v = H.sweep_cat(ft, _g(inp["grids"]), layout=layout)
+        assert np.array_equal(_ncdhw(v), z["vol_raw"]), layout
 
 
 # ------------------------------------------------------------------------------ K2 conv

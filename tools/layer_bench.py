@@ -88,11 +88,15 @@ def main():
         us = timeit(lambda: hp(feats), iters=10)
         print(f"  whole path: {us:.1f} us / batch -> {B / us * 1e6:.1f} frames/s")
         g, gm, m = hp.grids, hp.grid_masks, hp.masks
-        if cfg.builder == "std":
-            us = timeit(lambda: H.sweep_std(feats, g, gm, m))
-        else:
-            us = timeit(lambda: H.sweep_cat(feats, g))
-        print(f"  sweep: {us:.1f} us")
+        for layout in ("auto", "nchw"):
+            if cfg.builder == "std":
+                us = timeit(lambda: H.sweep_std(feats, g, gm, m, layout=layout))
+            else:
+                us = timeit(lambda: H.sweep_cat(feats, g, layout=layout))
+            print(f"  sweep[{layout}]: {us:.1f} us")
+        fcl = H._feats_nhwc(feats).permute(0, 1, 4, 2, 3)
+        us = timeit(lambda: H.sweep_std(fcl, g, gm, m) if cfg.builder == "std" else H.sweep_cat(fcl, g))
+        print(f"  sweep[channels-last input, no transpose]: {us:.1f} us")
         c = torch.zeros((B, cfg.num_cands, *cfg.cv_hw), device=dev)
         us = timeit(lambda: H.softargmin(c, hp.dist_regressor.inv_dist_idx, 2, True))
         print(f"  softargmin(+norm_costs): {us:.1f} us")
