@@ -37,6 +37,7 @@ struct ConvArgs {
     int B, Cin, Din, Hin, Win, Cout, Do, Ho, Wo, stride;
     float neg_slope;   // act(v) = v > 0 ? v : v * neg_slope; 1.0 = identity
     int tiles_d, tiles_h, tiles_w;
+    int total_units;   // persistent bf16x3 kernel: bricks x cout blocks
 };
 
 constexpr int kVS = 20;           // LDS floats per staged voxel: 16 channels + 4 pad

@@ -13,13 +13,19 @@
 //     ds_read_b128 services together (8 lanes of one kg, 8 of its tap-partner) address 15
 //     different consecutive voxels + 1 shared one at an 80-byte stride: bank-conflict free for the
 //     in-row pairs (delta 1) and the row-wrap pairs (delta ITW - 2 = 16), see DESIGN.md;
-//   * activations stay fp32 in HBM; the halo brick of one 16-channel slice is fetched into
-//     registers one slice AHEAD (loads in flight under the MFMA loop), split on the way into LDS
-//     as [hi0-7 | hi8-15 | lo0-7 | lo8-15 | pad] = 80 B per voxel;
+//   * WAVE SPECIALISATION: a workgroup is 4 consumer waves (MFMA) + 4 producer waves.  Vector
+//     memory loads return in issue order, so a wave that mixes slow activation loads (HBM /
+//     Infinity Cache) with the fast weight-fragment loads (L1/L2) stalls every fragment behind
+//     the slowest activation load in front of it.  Here the consumers' queues hold weight
+//     fragments only; the producers fetch the NEXT unit's halo brick (one 16-channel slice, fp32
+//     in HBM), split it and write it to the other half of a double-buffered LDS image
+//     [hi0-7 | hi8-15 | lo0-7 | lo8-15 | pad] = 80 B per voxel, while the consumers multiply the
+//     current one.  One __syncthreads() per unit hands the buffers over;
 //   * weights arrive pre-split and lane-ordered straight from L2 (one coalesced 16-byte load per
-//     lane per fragment); every wave of every workgroup reads the same few hundred KB;
-//   * the flat grid is re-mapped so that each XCD (= each private L2) owns a contiguous run of
-//     bricks: neighbouring bricks' halos and the cout-blocks of one brick hit the same L2.
+//     lane per fragment), requested 1-2 slots ahead of their MFMAs into rotating registers;
+//   * workgroups are persistent (one or two per CU) and walk (brick, cout-block) units with
+//     stride gridDim.x; the unit index space is re-mapped so that each XCD (= each private L2)
+//     owns a contiguous run of bricks: neighbouring halos and the cout-blocks of a brick share L2.
 #pragma once
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -27,7 +33,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int kVSB = 80;      // LDS bytes per staged voxel
 constexpr int kPairs = 14;
 
-// [Cout][Cin][27] -> [Cin/16][14 pairs][Cout/16][hi|lo][64 lanes][8 bf16]
+// [Cout][Cin][27] -> [Cin/16][Cout/16][14 pairs][hi|lo][64 lanes][8 bf16]
 //   lane = (kg << 4) | i holds W[cout = ct*16+i][cin = cc*16 + (kg>>1)*8 + j][tap = 2p + (kg&1)]
 __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout, int Cin) {
     const int CT = Cout / 16;
@@ -51,7 +57,7 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, bf16x8* 
         hi[j] = h;
         lo[j] = (__bf16)(v - (float)h);
     }
-    const long long o = ((((long long)cc * kPairs + p) * CT + ct) * 2) * 64 + lane;
+    const long long o = ((((long long)cc * CT + ct) * kPairs + p) * 2) * 64 + lane;
     wp[o] = hi;
     wp[o + 64] = lo;
 }
@@ -64,214 +70,297 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 }
 
 template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S>
-__global__ __launch_bounds__(256) void conv3d_bf16x3_kernel(ConvArgs a) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
+    static_assert(WM * WN == 4, "4 consumer waves per workgroup");
     static_assert(WM * MW * 16 == TD * TH * TW, "brick must be covered by the voxel tiles");
     constexpr int ITD = (TD - 1) * S + 3, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
     constexpr int IV = ITD * ITH * ITW;
-    constexpr int NIT = (IV * 4 + 255) / 256;
+    constexpr int NIT = (IV * 4 + 255) / 256;      // staging items per producer thread and unit
+    constexpr int BUF = IV * kVSB;                 // bytes of one LDS image
+    // weight pipeline of the consumers: WB register buffers, fragments requested LA slots ahead.
+    // A slice has NSLOT slots = 14 tap pairs (+ one rotation-only slot when WB == 3, so that
+    // NSLOT % WB == 0 and every buffer index is a compile-time constant).
+    constexpr int WB = NW <= 2 ? 3 : 2;
+    constexpr int LA = WB - 1;
+    constexpr int NSLOT = WB == 3 ? 15 : 14;
+    static_assert(NSLOT % WB == 0, "pipeline geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave % WM, wn = wave / WM;
-    const int col = lane & 15, kg = lane >> 4;
-    const bool second = kg & 1;       // this lane's k-range belongs to the pair's second tap
-
-    // flat grid -> (brick, cout block), cout block fastest, XCD-contiguous
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform
+    const bool producer = wave >= 4;
     const int CT = a.Cout / 16;
     const int ny = (CT + WN * NW - 1) / (WN * NW);
-    int t = xcd_remap(blockIdx.x, gridDim.x);
-    const int cb = t % ny;
-    t /= ny;
-    const int tw_i = t % a.tiles_w;
-    t /= a.tiles_w;
-    const int th_i = t % a.tiles_h;
-    t /= a.tiles_h;
-    const int td_i = t % a.tiles_d;
-    const int b = t / a.tiles_d;
-    const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
-    const int id0 = od0 * S - 1, ih0 = oh0 * S - 1, iw0 = ow0 * S - 1;
-    const int ct0 = (cb * WN + wn) * NW;
-
-    // per-lane LDS byte address of each voxel tile's B fragment (hi part, tap offset excluded)
-    int base[MW];
-#pragma unroll
-    for (int i = 0; i < MW; ++i) {
-        const int v = (wm * MW + i) * 16 + col;
-        const int w_ = v % TW, h_ = (v / TW) % TH, d_ = v / (TW * TH);
-        base[i] = (((d_ * S) * ITH + h_ * S) * ITW + w_ * S) * kVSB + (kg >> 1) * 16;
-    }
-
-    // staging plan: item e = tid + it*256 -> (halo voxel e>>2, channel quad e&3); element offset
-    // of the item within one (batch, slice-0) volume.  Padding / surplus items load a valid
-    // dummy address and are zeroed by a select (no per-item branch: a branch per load makes
-    // hipcc wait for each one in turn).
-    int goff[NIT];
-    unsigned okmask = 0;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int e = tid + it * 256;
-        const int v = e >> 2, q = e & 3;
-        const int iw = v % ITW, ih = (v / ITW) % ITH, id = v / (ITW * ITH);
-        const int gd = id0 + id, gh = ih0 + ih, gw = iw0 + iw;
-        const bool ok = (e < IV * 4) && gd >= 0 && gd < a.Din && gh >= 0 && gh < a.Hin && gw >= 0 && gw < a.Win;
-        goff[it] = ok ? ((gd * a.Hin + gh) * a.Win + gw) * a.Cin + q * 4 : 0;
-        okmask |= ok ? (1u << it) : 0u;
-    }
-    const float* xb_base = a.x + (long long)b * a.Din * a.Hin * a.Win * a.Cin;
-    f32x4 pre[NIT];
-    static_assert(NIT <= kPairs - 1, "the slice prefetch is spread over the pair loop");
-#define MVSGI_PRELOAD(IT, CC) pre[IT] = *reinterpret_cast<const f32x4*>(xb_base + goff[IT] + (CC) * 16);
-
-    f32x4 acc[MW][NW];
-#pragma unroll
-    for (int i = 0; i < MW; ++i)
-#pragma unroll
-        for (int j = 0; j < NW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     const int nchunks = a.Cin / 16;
-    const bf16x8* wpb = reinterpret_cast<const bf16x8*>(a.wp) + lane;
-    int ctc[NW];                                   // clamped cout tile (surplus tiles are never stored)
-#pragma unroll
-    for (int j = 0; j < NW; ++j) ctc[j] = ct0 + j < CT ? ct0 + j : CT - 1;
+    const int total = a.total_units;               // bricks x cout blocks
+    const int G = gridDim.x;
+    // units of this workgroup: ids blockIdx.x + k*G (G % 8 == 0 or G == total, so id % 8 is this
+    // block's XCD), each nchunks slices long
+    const int nmine = (total - (int)blockIdx.x + G - 1) / G;
+    const int U = nmine * nchunks;
 
-    // software pipeline: the weight fragments of pair p+1 are requested before pair p is multiplied
-    // (double-buffered registers); the activation fragments of pair p+1 are read from LDS half a
-    // pair ahead, into the registers the first / second half of pair p's MFMAs have just consumed
-    // (small tiles: fully double-buffered).  All indices are static after unrolling.
-    constexpr int XB = MW <= 2 ? 2 : 1;
-    constexpr int MH = XB == 2 ? MW : MW / 2;      // voxel tiles per half
-    bf16x8 wh[2][NW], wl[2][NW], xh[XB][MW], xl[XB][MW];
-#define MVSGI_LOADW(BUF, CC, P)                                                                   \
-    _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                              \
-        const bf16x8* q_ = wpb + ((long long)((CC) * kPairs + (P)) * CT + ctc[j]) * 128;          \
-        wh[BUF][j] = q_[0];                                                                       \
-        wl[BUF][j] = q_[64];                                                                      \
+#define MVSGI_DECODE(ID, CB, B, OD, OH, OW)                       \
+    {                                                             \
+        int t_ = xcd_remap((ID), total);                          \
+        CB = t_ % ny;                                             \
+        t_ /= ny;                                                 \
+        OW = (t_ % a.tiles_w) * TW;                               \
+        t_ /= a.tiles_w;                                          \
+        OH = (t_ % a.tiles_h) * TH;                               \
+        t_ /= a.tiles_h;                                          \
+        OD = (t_ % a.tiles_d) * TD;                               \
+        B = t_ / a.tiles_d;                                       \
     }
-#define MVSGI_READX(BUF, P, I0, I1)                                                               \
-    {                                                                                             \
-        const int p_ = (P);                                                                       \
-        const int t0_ = 2 * p_, t1_ = (2 * p_ + 1 < 27) ? 2 * p_ + 1 : 2 * p_;                    \
-        const int o0_ = (((t0_ / 9) * ITH + (t0_ / 3) % 3) * ITW + t0_ % 3) * kVSB;               \
-        const int o1_ = (((t1_ / 9) * ITH + (t1_ / 3) % 3) * ITW + t1_ % 3) * kVSB;               \
-        const int off_ = second ? o1_ : o0_;                                                      \
-        _Pragma("unroll") for (int i = (I0); i < (I1); ++i) {                                     \
-            xh[BUF][i] = *reinterpret_cast<const bf16x8*>(ldsb + base[i] + off_);                 \
-            xl[BUF][i] = *reinterpret_cast<const bf16x8*>(ldsb + base[i] + off_ + 32);            \
-        }                                                                                         \
-    }
-#define MVSGI_MFMAS(WB, XBUF, I0, I1)                                                             \
-    _Pragma("unroll") for (int i = (I0); i < (I1); ++i)                                           \
-        _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                          \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[WB][j], xh[XBUF][i], acc[i][j], 0, 0, 0); \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[WB][j], xl[XBUF][i], acc[i][j], 0, 0, 0); \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[WB][j], xh[XBUF][i], acc[i][j], 0, 0, 0); \
-        }
 
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) { MVSGI_PRELOAD(it, 0) }
-    MVSGI_LOADW(0, 0, 0)
-    for (int cc = 0; cc < nchunks; ++cc) {
-        __syncthreads();                       // every wave is done reading the previous slice
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {     // split fp32 -> (hi, lo) bf16 on the way into LDS
-            const int e = tid + it * 256;
-            if (e < IV * 4) {
-                const int v = e >> 2, q = e & 3;
-                const bool ok = (okmask >> it) & 1u;
-                bf16x4 hi, lo;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float xv = ok ? pre[it][k] : 0.f;
-                    const __bf16 h = (__bf16)xv;
-                    hi[k] = h;
-                    lo[k] = (__bf16)(xv - (float)h);
-                }
-                *reinterpret_cast<bf16x4*>(ldsb + v * kVSB + q * 8) = hi;
-                *reinterpret_cast<bf16x4*>(ldsb + v * kVSB + 32 + q * 8) = lo;
-            }
+    if (producer) {
+        // =========================== producers: HBM -> split bf16 -> LDS ===========================
+        const int ptid = tid - 256;
+        int goff[NIT];
+        unsigned okmask = 0;
+        const float* xb = a.x;
+        f32x4 pre[NIT];
+        // staging plan of a brick: item e = ptid + it*256 -> (halo voxel e>>2, channel quad e&3);
+        // padding / surplus items read a valid dummy address and are zeroed by a select (a branch
+        // per load would make hipcc wait for each one in turn)
+#define MVSGI_PLAN(UNIT)                                                                                \
+        {                                                                                               \
+            int cb_, b_, od_, oh_, ow_;                                                                 \
+            MVSGI_DECODE(UNIT, cb_, b_, od_, oh_, ow_)                                                  \
+            (void)cb_;                                                                                  \
+            const int id0_ = od_ * S - 1, ih0_ = oh_ * S - 1, iw0_ = ow_ * S - 1;                       \
+            okmask = 0;                                                                                 \
+            _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                        \
+                const int e = ptid + it * 256;                                                          \
+                const int v = e >> 2, q = e & 3;                                                        \
+                const int iw = v % ITW, ih = (v / ITW) % ITH, id = v / (ITW * ITH);                     \
+                const int gd = id0_ + id, gh = ih0_ + ih, gw = iw0_ + iw;                               \
+                const bool ok = (e < IV * 4) && gd >= 0 && gd < a.Din && gh >= 0 && gh < a.Hin && gw >= 0 && gw < a.Win; \
+                goff[it] = ok ? ((gd * a.Hin + gh) * a.Win + gw) * a.Cin + q * 4 : 0;                   \
+                okmask |= ok ? (1u << it) : 0u;                                                         \
+            }                                                                                           \
+            xb = a.x + (long long)b_ * a.Din * a.Hin * a.Win * a.Cin;                                   \
         }
-        __syncthreads();
-        const bool more = cc + 1 < nchunks;
-        MVSGI_READX(0, 0, 0, MW)
-#pragma unroll
-        for (int p = 0; p < kPairs; ++p) {
-            const int cur = p & 1, nxt = cur ^ 1;
-            const int xcur = XB == 2 ? cur : 0, xnxt = XB == 2 ? nxt : 0;
-            if (p + 1 < kPairs) {
-                MVSGI_LOADW(nxt, cc, p + 1)
-            } else if (more) {
-                MVSGI_LOADW(nxt, cc + 1, 0)
+#define MVSGI_STAGE(CC, DST)                                                                            \
+        {                                                                                               \
+            _Pragma("unroll") for (int it = 0; it < NIT; ++it)                                          \
+                pre[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xb) +           \
+                                                          (unsigned)((goff[it] + (CC) * 16) * 4));      \
+            _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                        \
+                const int e = ptid + it * 256;                                                          \
+                if (e < IV * 4) {                                                                       \
+                    const int v = e >> 2, q = e & 3;                                                    \
+                    const bool ok = (okmask >> it) & 1u;                                                \
+                    bf16x4 hi, lo;                                                                      \
+                    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                     \
+                        const float xv = ok ? pre[it][k] : 0.f;                                         \
+                        const __bf16 h = (__bf16)xv;                                                    \
+                        hi[k] = h;                                                                      \
+                        lo[k] = (__bf16)(xv - (float)h);                                                \
+                    }                                                                                   \
+                    *reinterpret_cast<bf16x4*>((DST) + v * kVSB + q * 8) = hi;                          \
+                    *reinterpret_cast<bf16x4*>((DST) + v * kVSB + 32 + q * 8) = lo;                     \
+                }                                                                                       \
+            }                                                                                           \
+        }
+        MVSGI_PLAN((int)blockIdx.x)
+        MVSGI_STAGE(0, ldsb)
+        __syncthreads();                                   // image 0 holds unit 0
+        int k = 0, cc = 0;                                 // (brick ordinal, slice) of the unit being multiplied
+        for (int u = 0; u < U; ++u) {
+            int ncc = cc + 1, nk = k;
+            if (ncc == nchunks) { ncc = 0; nk = k + 1; }
+            if (u + 1 < U) {
+                if (ncc == 0) { MVSGI_PLAN((int)blockIdx.x + nk * G) }
+                unsigned char* dst = ldsb + ((u + 1) & 1) * BUF;
+                MVSGI_STAGE(ncc, dst)
             }
-            // one item of the next slice's halo brick per pair: global loads complete in order, so
-            // a burst here would sit in front of every weight fragment of the following pairs
-            if (more && p >= 1 && p - 1 < NIT) { MVSGI_PRELOAD(p - 1, cc + 1) }
-            if (XB == 2) {
-                if (p + 1 < kPairs) MVSGI_READX(xnxt, p + 1, 0, MW)
-                __builtin_amdgcn_sched_barrier(0);
-                MVSGI_MFMAS(cur, xcur, 0, MW)
+            cc = ncc;
+            k = nk;
+            __syncthreads();                               // unit u multiplied, image of unit u+1 complete
+        }
+#undef MVSGI_PLAN
+#undef MVSGI_STAGE
+    } else {
+        // =========================== consumers: LDS + L2 weights -> MFMA ===========================
+        const int wm = wave % WM, wn = wave / WM;
+        const int col = lane & 15, kg = lane >> 4;
+        const bool second = kg & 1;       // this lane's k-range belongs to the pair's second tap
+        const char* wpb = reinterpret_cast<const char*>(a.wp);    // uniform base; per-lane part is lane*16
+        const unsigned lane16 = lane * 16;
+        // per-lane LDS byte offset of each voxel tile's B fragment (hi part, tap offset excluded)
+        int base[MW];
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+            const int v = (wm * MW + i) * 16 + col;
+            const int w_ = v % TW, h_ = (v / TW) % TH, d_ = v / (TW * TH);
+            base[i] = (((d_ * S) * ITH + h_ * S) * ITW + w_ * S) * kVSB + (kg >> 1) * 16;
+        }
+        int ctc[NW], ctn[NW];             // clamped cout tiles of the current / the next unit
+#define MVSGI_CTILES(DST, CB)                                                         \
+        _Pragma("unroll") for (int j = 0; j < NW; ++j) {                              \
+            const int c_ = ((CB) * WN + wn) * NW + j;                                 \
+            DST[j] = c_ < CT ? c_ : CT - 1;                                           \
+        }
+        bf16x8 wh[WB][NW], wl[WB][NW];
+        constexpr int XB = MW <= 2 ? 2 : 1;
+        constexpr int MH = XB == 2 ? MW : MW / 2;      // voxel tiles per half
+        bf16x8 xh[XB][MW], xl[XB][MW];
+#define MVSGI_LOADW(BUFI, CC, P, CTS)                                                                 \
+        _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                              \
+            const char* q_ = wpb + (((long long)(CC) * CT + CTS[j]) * kPairs) * 2048;  /* wave-uniform */ \
+            wh[BUFI][j] = *reinterpret_cast<const bf16x8*>(q_ + (l16 + (unsigned)(P) * 2048u));          \
+            wl[BUFI][j] = *reinterpret_cast<const bf16x8*>(q_ + (l16 + (unsigned)(P) * 2048u + 1024u));  \
+        }
+#define MVSGI_READX(BUFI, P, I0, I1)                                                                  \
+        {                                                                                             \
+            const int p_ = (P);                                                                       \
+            const int t0_ = 2 * p_, t1_ = (2 * p_ + 1 < 27) ? 2 * p_ + 1 : 2 * p_;                    \
+            const int o0_ = (((t0_ / 9) * ITH + (t0_ / 3) % 3) * ITW + t0_ % 3) * kVSB;               \
+            const int o1_ = (((t1_ / 9) * ITH + (t1_ / 3) % 3) * ITW + t1_ % 3) * kVSB;               \
+            const int off_ = second ? o1_ : o0_;                                                      \
+            _Pragma("unroll") for (int i = (I0); i < (I1); ++i) {                                     \
+                xh[BUFI][i] = *reinterpret_cast<const bf16x8*>(img + base[i] + off_);                 \
+                xl[BUFI][i] = *reinterpret_cast<const bf16x8*>(img + base[i] + off_ + 32);            \
+            }                                                                                         \
+        }
+#define MVSGI_MFMAS(WBUF, XBUF, I0, I1)                                                               \
+        _Pragma("unroll") for (int i = (I0); i < (I1); ++i)                                           \
+            _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                          \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[WBUF][j], xh[XBUF][i], acc[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[WBUF][j], xl[XBUF][i], acc[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[WBUF][j], xh[XBUF][i], acc[i][j], 0, 0, 0); \
+            }
+        f32x4 acc[MW][NW];
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int j = 0; j < NW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        int cb_, b_, od0, oh0, ow0;
+        MVSGI_DECODE((int)blockIdx.x, cb_, b_, od0, oh0, ow0)
+        MVSGI_CTILES(ctc, cb_)
+        {
+            unsigned l16 = lane16;
+#pragma unroll
+            for (int s0 = 0; s0 < LA; ++s0) { MVSGI_LOADW(s0, 0, s0, ctc) }
+        }
+        __syncthreads();                                   // image 0 holds unit 0
+        int k = 0, cc = 0;
+        for (int u = 0; u < U; ++u) {
+            const unsigned char* img = ldsb + (u & 1) * BUF;
+            const bool last = cc + 1 == nchunks;
+            const bool more = u + 1 < U;
+            const int ncc = last ? 0 : cc + 1;
+            int ncb = cb_, nb = b_, nod0 = od0, noh0 = oh0, now0 = ow0;
+            if (last && more) {
+                MVSGI_DECODE((int)blockIdx.x + (k + 1) * G, ncb, nb, nod0, noh0, now0)
+                MVSGI_CTILES(ctn, ncb)
             } else {
-                __builtin_amdgcn_sched_barrier(0);
-                MVSGI_MFMAS(cur, 0, 0, MH)
-                __builtin_amdgcn_sched_barrier(0);
-                if (p + 1 < kPairs) MVSGI_READX(0, p + 1, 0, MH)
-                __builtin_amdgcn_sched_barrier(0);
-                MVSGI_MFMAS(cur, 0, MH, MW)
-                __builtin_amdgcn_sched_barrier(0);
-                if (p + 1 < kPairs) MVSGI_READX(0, p + 1, MH, MW)
+#pragma unroll
+                for (int j = 0; j < NW; ++j) ctn[j] = ctc[j];
             }
-            __builtin_amdgcn_sched_barrier(0);
+            MVSGI_READX(0, 0, 0, MW)
+#pragma unroll
+            for (int s_ = 0; s_ < NSLOT; ++s_) {
+                const int wcur = s_ % WB;
+                unsigned l16 = lane16;
+                asm volatile("" : "+v"(l16));      // keep `lane*16 + const` from being hoisted 28x out of the loop
+                const int xcur = XB == 2 ? (s_ & 1) : 0, xnxt = XB == 2 ? (xcur ^ 1) : 0;
+                // weight fragments LA slots ahead (this slice, or the first slots of the next unit)
+                if (s_ + LA < NSLOT) {
+                    if (s_ + LA < kPairs) { MVSGI_LOADW((s_ + LA) % WB, cc, s_ + LA, ctc) }
+                } else if (more) {
+                    MVSGI_LOADW((s_ + LA - NSLOT) % WB, ncc, s_ + LA - NSLOT, ctn)
+                }
+                if (s_ < kPairs) {
+                    if (XB == 2) {
+                        if (s_ + 1 < kPairs) MVSGI_READX(xnxt, s_ + 1, 0, MW)
+                        __builtin_amdgcn_sched_barrier(0);
+                        MVSGI_MFMAS(wcur, xcur, 0, MW)
+                    } else {
+                        __builtin_amdgcn_sched_barrier(0);
+                        MVSGI_MFMAS(wcur, 0, 0, MH)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (s_ + 1 < kPairs) MVSGI_READX(0, s_ + 1, 0, MH)
+                        __builtin_amdgcn_sched_barrier(0);
+                        MVSGI_MFMAS(wcur, 0, MH, MW)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (s_ + 1 < kPairs) MVSGI_READX(0, s_ + 1, MH, MW)
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (last) {
+                // epilogue of the finished brick: lane (col, kg) of tile (i, j) holds couts
+                // ct*16 + 4*kg + 0..3 of voxel i*16 + col
+                const int ct0 = (cb_ * WN + wn) * NW;
+#pragma unroll
+                for (int i = 0; i < MW; ++i) {
+                    const int v = (wm * MW + i) * 16 + col;
+                    const int w_ = v % TW, h_ = (v / TW) % TH, d_ = v / (TW * TH);
+                    const int od = od0 + d_, oh = oh0 + h_, ow = ow0 + w_;
+                    const bool inside = od < a.Do && oh < a.Ho && ow < a.Wo;
+                    const long long vox = (((long long)b_ * a.Do + od) * a.Ho + oh) * a.Wo + ow;
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) {
+                        const int ct = ct0 + j;
+                        if (inside && ct < CT) {
+                            const int co = ct * 16 + kg * 4;
+                            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + co);
+                            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + co);
+                            f32x4 r = acc[i][j] * sc + sh;
+                            if (a.res) r += *reinterpret_cast<const f32x4*>(a.res + vox * a.Cout + co);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : r[e] * a.neg_slope;
+                            *reinterpret_cast<f32x4*>(a.y + vox * a.Cout + co) = r;
+                        }
+                        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                k += 1;
+                cb_ = ncb; b_ = nb; od0 = nod0; oh0 = noh0; ow0 = now0;
+#pragma unroll
+                for (int j = 0; j < NW; ++j) ctc[j] = ctn[j];
+            }
+            cc = ncc;
+            __syncthreads();                               // image of unit u+1 complete, image u free
         }
-    }
-#undef MVSGI_MFMAS
-#undef MVSGI_PRELOAD
+#undef MVSGI_CTILES
 #undef MVSGI_LOADW
 #undef MVSGI_READX
-
-    // epilogue: lane (col, kg) of tile (i, j) holds couts ct*16 + 4*kg + 0..3 of voxel i*16 + col
-#pragma unroll
-    for (int i = 0; i < MW; ++i) {
-        const int v = (wm * MW + i) * 16 + col;
-        const int w_ = v % TW, h_ = (v / TW) % TH, d_ = v / (TW * TH);
-        const int od = od0 + d_, oh = oh0 + h_, ow = ow0 + w_;
-        if (od >= a.Do || oh >= a.Ho || ow >= a.Wo) continue;
-        const long long vox = (((long long)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const int ct = ct0 + j;
-            if (ct >= CT) continue;
-            const int co = ct * 16 + kg * 4;
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + co);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + co);
-            f32x4 r = acc[i][j] * sc + sh;
-            if (a.res) r += *reinterpret_cast<const f32x4*>(a.res + vox * a.Cout + co);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : r[e] * a.neg_slope;
-            *reinterpret_cast<f32x4*>(a.y + vox * a.Cout + co) = r;
-        }
+#undef MVSGI_MFMAS
     }
+#undef MVSGI_DECODE
 }
 
 template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S>
 int launch_bf16x3(ConvArgs a, hipStream_t st) {
     constexpr int ITD = (TD - 1) * S + 3, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
-    constexpr size_t lds_bytes = (size_t)ITD * ITH * ITW * kVSB;
-    static_assert(lds_bytes <= 160 * 1024, "LDS tile too large");
+    constexpr size_t lds_bytes = (size_t)2 * ITD * ITH * ITW * kVSB;      // double-buffered image
+    static_assert(lds_bytes <= 160 * 1024, "LDS images too large");
     auto kern = conv3d_bf16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S>;
-    static bool attr_done = false;   // benign race: idempotent
-    if (!attr_done) {
+    static int wgs_per_cu = 0;       // benign race: idempotent
+    if (!wgs_per_cu) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return mvsgi::fail("conv3d: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
+        int occ = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 512, lds_bytes);
+        if (e != hipSuccess || occ < 1) occ = 1;
+        wgs_per_cu = occ > 2 ? 2 : occ;
     }
     a.tiles_d = (int)mvsgi::cdiv(a.Do, TD);
     a.tiles_h = (int)mvsgi::cdiv(a.Ho, TH);
     a.tiles_w = (int)mvsgi::cdiv(a.Wo, TW);
     const int CT = a.Cout / 16;
     const long long nb = (long long)a.B * a.tiles_d * a.tiles_h * a.tiles_w * mvsgi::cdiv(CT, WN * NW);
-    MVSGI_REQUIRE(nb < (1ll << 31), "conv3d: too many workgroups");
-    MVSGI_REQUIRE((long long)a.Din * a.Hin * a.Win * a.Cin < (1ll << 31), "conv3d: volume too large for 32-bit offsets");
-    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds_bytes, st, a);
+    MVSGI_REQUIRE(nb < (1ll << 31), "conv3d: too many units");
+    MVSGI_REQUIRE((long long)a.Din * a.Hin * a.Win * a.Cin < (1ll << 29), "conv3d: volume too large for 32-bit byte offsets");
+    a.total_units = (int)nb;
+    // persistent grid (a multiple of 8 unless it covers every unit once): each workgroup walks the
+    // units blockIdx.x + k*gridDim.x, which stay on its XCD's contiguous run of the index space
+    const long long resident = 256ll * wgs_per_cu;
+    const unsigned grid = (unsigned)(nb <= resident ? nb : resident);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds_bytes, st, a);
     return mvsgi::check_launch("mvsgi_conv3d_f32(bf16x3)");
 }
