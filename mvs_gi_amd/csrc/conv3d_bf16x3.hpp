@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
             DST[j] = c_ < CT ? c_ : CT - 1;                                           \
         }
         bf16x8 wh[WB][NW], wl[WB][NW];
-        constexpr int XB = MW <= 2 ? 2 : 1;
+        constexpr int XB = MW <= 4 ? 2 : 1;            // activation fragments: double-buffered when they fit
         constexpr int MH = XB == 2 ? MW : MW / 2;      // voxel tiles per half
         bf16x8 xh[XB][MW], xl[XB][MW];
 #define MVSGI_LOADW(BUFI, CC, P, CTS)                                                                 \
@@ -259,6 +259,16 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < NW; ++j) ctn[j] = ctc[j];
             }
+            // per-channel scale / shift of this wave's cout tiles: requested before the last slice is
+            // multiplied so the epilogue does not wait for them one tile at a time
+            f32x4 esc[NW], esh[NW];
+            if (last) {
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    esc[j] = *reinterpret_cast<const f32x4*>(a.scale + ctc[j] * 16 + kg * 4);
+                    esh[j] = *reinterpret_cast<const f32x4*>(a.shift + ctc[j] * 16 + kg * 4);
+                }
+            }
             MVSGI_READX(0, 0, 0, MW)
 #pragma unroll
             for (int s_ = 0; s_ < NSLOT; ++s_) {
@@ -306,9 +316,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
                         const int ct = ct0 + j;
                         if (inside && ct < CT) {
                             const int co = ct * 16 + kg * 4;
-                            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + co);
-                            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + co);
-                            f32x4 r = acc[i][j] * sc + sh;
+                            f32x4 r = acc[i][j] * esc[j] + esh[j];
                             if (a.res) r += *reinterpret_cast<const f32x4*>(a.res + vox * a.Cout + co);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : r[e] * a.neg_slope;
