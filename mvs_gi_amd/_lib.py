@@ -11,7 +11,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmvsgi_hip.so")
+LIB_PATH = os.environ.get("MVSGI_LIB", os.path.join(_HERE, "libmvsgi_hip.so"))   # MVSGI_LIB: diagnostic builds
 
 ABI_VERSION = 1
 

@@ -284,9 +284,19 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
                 }
                 if (s_ < kPairs) {
                     if (XB == 2) {
+                        // one scheduling region per slot: the next slot's fragment requests (2*NW weight
+                        // loads, 2*MW LDS reads) are interleaved one per RATIO MFMAs, so their issue
+                        // cycles hide in the MFMA gaps instead of draining the matrix pipe between slots
                         if (s_ + 1 < kPairs) MVSGI_READX(xnxt, s_ + 1, 0, MW)
-                        __builtin_amdgcn_sched_barrier(0);
                         MVSGI_MFMAS(wcur, xcur, 0, MW)
+                        constexpr int NMEM = 2 * NW + 2 * MW, NMFMA = 3 * MW * NW;
+                        constexpr int RATIO = NMFMA / NMEM > 0 ? NMFMA / NMEM : 1;
+#pragma unroll
+                        for (int q_ = 0; q_ < NMEM; ++q_) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, RATIO, 0);      // MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);          // VMEM read | DS read
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);          // the rest
                     } else {
                         __builtin_amdgcn_sched_barrier(0);
                         MVSGI_MFMAS(wcur, 0, 0, MH)
