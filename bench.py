@@ -35,9 +35,12 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="G16V")
-    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
     ap.add_argument("--mode", default="bf16x3", choices=["bf16x3", "f32"],
                     help="conv arithmetic: split-bf16 MFMA (3 bf16 MFMAs per product, fp32 accumulate) or exact fp32 MFMA")
+    ap.add_argument("--graph", action="store_true",
+                    help="also time hipGraph replays of the same step (reported as graph_replay_*; the headline "
+                         "value and the per-kernel events always come from the eager launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl=RCCL)")
@@ -256,6 +259,15 @@ def main(argv=None):
         agg = probe.summary()
 
     assert torch.isfinite(out["inv"]).all()
+    graph_res = None
+    if args.graph:
+        hp.capture(feats)
+
+        def gstep():
+            hp.replay()
+        gel = timed_steps(gstep, sync, args.steps, args.warmup, world, backend_ready, dev)
+        graph_res = {"graph_replay_frames_per_s": round(B * world * args.steps / gel, 2),
+                     "graph_replay_ms_per_step": round(gel / args.steps * 1e3, 4)}
     frames = B * world * args.steps
     value = frames / el
     # dominant kernel = largest total time among the conv variants
@@ -285,6 +297,8 @@ def main(argv=None):
         "kernels": {k: {"launches": v[0], "avg_us": round(v[2] / v[0] * 1e3, 2),
                         "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2)} for k, v in sorted(agg.items())},
     }
+    if graph_res is not None:
+        res.update(graph_res)
     if cpu_res is not None:
         res["cpu_baseline"] = cpu_res
     if backend_ready:

@@ -317,3 +317,23 @@ def test_full_size_properties_batch_and_determinism():
     assert torch.isfinite(both).all()
     lo, hi = hp.dist_regressor.inv_dist_idx_min, hp.dist_regressor.inv_dist_idx_max
     assert float(both.min()) >= lo - 1e-3 and float(both.max()) <= hi + 1e-3   # convex combination
+
+
+def test_hipgraph_replay_equals_eager():
+    """The captured hipGraph of the whole path replays to bit-identical results, also for new
+    input contents written into the static buffer."""
+    from mvs_gi_amd.configs import CONFIGS, DIST_8L
+    cfg = CONFIGS["G16V"].scaled(feat_hw=(32, 128), mask_hw=(64, 256), cv_hw=(16, 64), dist_cands=DIST_8L)
+    inp = synth.make_inputs(cfg, seed=7, batch=1)
+    hp = HotPath(cfg, synth.make_weights(cfg, seed=7), inp, device=DEV)
+    rng = np.random.default_rng(1)
+    f1 = _g(rng.standard_normal((2, *inp["feats"].shape[1:]), dtype=np.float32))
+    f2 = _g(rng.standard_normal((2, *inp["feats"].shape[1:]), dtype=np.float32))
+    e1 = hp(f1)[0].clone()
+    e2 = hp(f2)[0].clone()
+    hp.capture(f1)
+    g1 = hp.replay(f1)[0].clone()
+    g2 = hp.replay(f2)[0].clone()
+    g1b = hp.replay(f1)[0].clone()
+    assert torch.equal(e1, g1) and torch.equal(e2, g2) and torch.equal(g1, g1b)
+    assert not torch.equal(g1, g2)
