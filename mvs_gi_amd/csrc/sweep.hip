@@ -72,7 +72,10 @@ __device__ __forceinline__ float div_small(float x, float d, float inv) {
     const float r = __builtin_fmaf(-d, q, x);
     float res = __builtin_fmaf(r, inv, q);
     if (ax == 0.0f) res = x;                                         // +-0 / d = +-0
-    else if (!(ax >= 1e-30f && ax <= 1e30f)) res = x / d;            // rare: exact hardware path
+    const bool rare = ax != 0.0f && !(ax >= 1e-30f && ax <= 1e30f);
+    if (__builtin_amdgcn_ballot_w64(rare) != 0) {                    // wave-uniform: normally skipped entirely
+        if (rare) res = x / d;                                       // exact hardware division
+    }
     return res;
 }
 
@@ -205,6 +208,28 @@ __device__ __forceinline__ f32x4_t bilin_fetch4(const float* __restrict__ img, i
     return ((i00 * t.w00 + i01 * t.w01) + i10 * t.w10) + i11 * t.w11;
 }
 
+// Buffer-descriptor variants of the two fetches: the tap offset is a 32-bit byte offset into a
+// per-image descriptor and an out-of-image tap (offset -1 -> huge unsigned) is answered with
+// zeros by the hardware range check, which IS the reference's zero padding: no 64-bit address
+// arithmetic and no selects per tap.
+__device__ __forceinline__ f32x4_t bilin_fetch4_buf(__amdgpu_buffer_rsrc_t img, int c, int C, const Bilin& t) {
+#pragma clang fp contract(off)
+    const f32x4_t i00 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(img, (t.o00 * C + c) * 4, 0, 0));
+    const f32x4_t i01 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(img, (t.o01 * C + c) * 4, 0, 0));
+    const f32x4_t i10 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(img, (t.o10 * C + c) * 4, 0, 0));
+    const f32x4_t i11 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(img, (t.o11 * C + c) * 4, 0, 0));
+    return ((i00 * t.w00 + i01 * t.w01) + i10 * t.w10) + i11 * t.w11;
+}
+
+__device__ __forceinline__ float bilin_fetch_buf(__amdgpu_buffer_rsrc_t plane, const Bilin& t) {
+#pragma clang fp contract(off)
+    const float i00 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(plane, t.o00 * 4, 0, 0));
+    const float i01 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(plane, t.o01 * 4, 0, 0));
+    const float i10 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(plane, t.o10 * 4, 0, 0));
+    const float i11 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(plane, t.o11 * 4, 0, 0));
+    return ((i00 * t.w00 + i01 * t.w01) + i10 * t.w10) + i11 * t.w11;
+}
+
 // grid = (ceil(Wo / 64), Ho, B * D); block = 64 voxels x 4 lanes.  No per-lane integer division:
 // (b, d, ho) come from the block index, wo from the thread index.
 template <int NCAM>
@@ -237,6 +262,11 @@ __global__ __launch_bounds__(256) void sweep_std_nhwc_kernel(const float* __rest
         myvalid = ((sm > 0.0f) && gmv) ? 1.0f : 0.0f;
     }
     const int lane = threadIdx.x & 63, qbase = lane & ~3;
+    __amdgpu_buffer_rsrc_t img[NCAM];                  // one descriptor per camera image (wave-uniform)
+#pragma unroll
+    for (int cam = 0; cam < NCAM; ++cam)
+        img[cam] = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(feats + (long long)(b * NCAM + cam) * HWi * s.C), 0, HWi * s.C * 4, 0x00020000);
     Bilin ft[NCAM];
     float vf[NCAM];
     float n = 0.0f;
@@ -258,11 +288,10 @@ __global__ __launch_bounds__(256) void sweep_std_nhwc_kernel(const float* __rest
     const float cnt = ok ? n : 1.0f;
     const float inv = 1.0f / cnt;
     float* out = vol + ((((long long)b * s.D + d) * s.Ho + ho) * s.Wo + wo) * s.C;
-    const float* fb = feats + (long long)b * NCAM * HWi * s.C;
     for (int c = q * 4; c < s.C; c += 16) {
         f32x4_t sv[NCAM];
 #pragma unroll
-        for (int cam = 0; cam < NCAM; ++cam) sv[cam] = bilin_fetch4(fb + (long long)cam * HWi * s.C + c, s.C, ft[cam]);
+        for (int cam = 0; cam < NCAM; ++cam) sv[cam] = bilin_fetch4_buf(img[cam], c, s.C, ft[cam]);
         f32x4_t r;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -300,9 +329,10 @@ __global__ __launch_bounds__(256) void sweep_cat_nhwc_kernel(const float* __rest
     const int HWi = s.Hi * s.Wi;
     const long long vox = (((long long)b * s.D + d) * s.Ho + ho) * s.Wo + wo;
     float* out = vol + vox * ((long long)s.N * s.C) + (long long)cam * s.C;
-    const float* img = feats + (long long)(b * s.N + cam) * HWi * s.C;
+    const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(feats + (long long)(b * s.N + cam) * HWi * s.C), 0, HWi * s.C * 4, 0x00020000);
     for (int c = q * 4; c < s.C; c += 16)
-        *reinterpret_cast<f32x4_t*>(out + c) = bilin_fetch4(img + c, s.C, ft);
+        *reinterpret_cast<f32x4_t*>(out + c) = bilin_fetch4_buf(img, c, s.C, ft);
 }
 
 int check_dims(const SweepDims& s, const char* who) {
