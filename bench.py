@@ -82,7 +82,8 @@ def timed_steps(step_fn, sync_fn, steps: int, warmup: int, world: int, backend_r
         dist.barrier()
     el = time.perf_counter() - t0
     if backend_ready:
-        t = torch.tensor([el], dtype=torch.float64, device=device if device is not None else "cpu")
+        on_cpu = device is None or dist.get_backend() == "gloo"
+        t = torch.tensor([el], dtype=torch.float64, device="cpu" if on_cpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     return el
@@ -225,11 +226,17 @@ def main(argv=None):
             raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
                              f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    if os.environ.get("MVSGI_BENCH_SHARE_GPU"):      # test hook: N ranks on one device (use --backend gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend_ready = False
     if world > 1:
-        dist.init_process_group(backend=args.backend or "nccl", rank=rank, world_size=world, device_id=dev)
+        backend = args.backend or "nccl"
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
         backend_ready = True
 
     cfg = CONFIGS[args.config]

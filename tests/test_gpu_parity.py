@@ -337,3 +337,24 @@ def test_hipgraph_replay_equals_eager():
     g1b = hp.replay(f1)[0].clone()
     assert torch.equal(e1, g1) and torch.equal(e2, g2) and torch.equal(g1, g1b)
     assert not torch.equal(g1, g2)
+
+
+def test_bench_two_ranks_frame_sharded_on_one_gpu():
+    """bench.py's N>1 path end to end (rendezvous, per-rank frames, barrier, max-over-ranks, one JSON
+    line from rank 0): two ranks share this box's single GPU, control plane over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MVSGI_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29655", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--backend", "gloo"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
+    assert d["value"] > 0 and abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.02
+    assert "cpu_baseline" not in d and d["roofline"]["bound"] == "mfma"
