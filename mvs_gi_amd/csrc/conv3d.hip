@@ -21,6 +21,10 @@
 //    counts; used for the Cout == 1 cost head (unet_regulator.py:61-68) and as the on-device
 //    cross-check of the MFMA path.
 #include "common.hpp"
+#ifdef MVSGI_STAMPS
+#include <cstdio>
+#include <cstdlib>
+#endif
 
 namespace {
 
@@ -38,6 +42,7 @@ struct ConvArgs {
     float neg_slope;   // act(v) = v > 0 ? v : v * neg_slope; 1.0 = identity
     int tiles_d, tiles_h, tiles_w;
     int total_units;   // persistent bf16x3 kernel: bricks x cout blocks
+    unsigned long long* dbg;   // MVSGI_STAMPS diagnostic build only
 };
 
 constexpr int kVS = 20;           // LDS floats per staged voxel: 16 channels + 4 pad

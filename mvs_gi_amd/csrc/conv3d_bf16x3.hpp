@@ -27,6 +27,9 @@
 //     stride gridDim.x; the unit index space is re-mapped so that each XCD (= each private L2)
 //     owns a contiguous run of bricks: neighbouring halos and the cout-blocks of a brick share L2.
 #pragma once
+#ifndef MVSGI_ABL
+#define MVSGI_ABL 0   // diagnostic builds: 1 no weight loads, 2 no LDS fragment reads, 4 no split, 8 no staging, 16 no MFMA
+#endif
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -98,6 +101,18 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
     // block's XCD), each nchunks slices long
     const int nmine = (total - (int)blockIdx.x + G - 1) / G;
     const int U = nmine * nchunks;
+#ifdef MVSGI_STAMPS   // diagnostic build only (tools/stamp_probe.py): s_memtime stamps of block 8
+    int nst = 0;
+#define STAMP()                                                                                     \
+    if (a.dbg && blockIdx.x == 8 && nst < 120) {                                                    \
+        unsigned long long t_;                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        if (lane == 0) a.dbg[wave * 128 + nst] = t_;                                                \
+        nst++;                                                                                      \
+    }
+#else
+#define STAMP()
+#endif
 
 #define MVSGI_DECODE(ID, CB, B, OD, OH, OW)                       \
     {                                                             \
@@ -153,30 +168,35 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
                     bf16x4 hi, lo;                                                                      \
                     _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                     \
                         const float xv = ok ? pre[it][k] : 0.f;                                         \
-                        const __bf16 h = (__bf16)xv;                                                    \
+                        const __bf16 h = (MVSGI_ABL & 4) ? __builtin_bit_cast(__bf16, (unsigned short)(__builtin_bit_cast(unsigned, xv) >> 16)) : (__bf16)xv; \
                         hi[k] = h;                                                                      \
-                        lo[k] = (__bf16)(xv - (float)h);                                                \
+                        lo[k] = (MVSGI_ABL & 4) ? h : (__bf16)(xv - (float)h);                          \
                     }                                                                                   \
                     *reinterpret_cast<bf16x4*>((DST) + v * kVSB + q * 8) = hi;                          \
                     *reinterpret_cast<bf16x4*>((DST) + v * kVSB + 32 + q * 8) = lo;                     \
                 }                                                                                       \
             }                                                                                           \
         }
+        STAMP()
         MVSGI_PLAN((int)blockIdx.x)
         MVSGI_STAGE(0, ldsb)
+        STAMP()
         __syncthreads();                                   // image 0 holds unit 0
+        STAMP()
         int k = 0, cc = 0;                                 // (brick ordinal, slice) of the unit being multiplied
         for (int u = 0; u < U; ++u) {
             int ncc = cc + 1, nk = k;
             if (ncc == nchunks) { ncc = 0; nk = k + 1; }
-            if (u + 1 < U) {
+            if (u + 1 < U && !(MVSGI_ABL & 8)) {
                 if (ncc == 0) { MVSGI_PLAN((int)blockIdx.x + nk * G) }
                 unsigned char* dst = ldsb + ((u + 1) & 1) * BUF;
                 MVSGI_STAGE(ncc, dst)
             }
             cc = ncc;
             k = nk;
+            STAMP()
             __syncthreads();                               // unit u multiplied, image of unit u+1 complete
+            STAMP()
         }
 #undef MVSGI_PLAN
 #undef MVSGI_STAGE
@@ -223,13 +243,19 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
                 xl[BUFI][i] = *reinterpret_cast<const bf16x8*>(img + base[i] + off_ + 32);            \
             }                                                                                         \
         }
+// term-major order: the three products of one accumulator are MW*NW MFMAs apart, never
+// back to back (a dependent v_mfma_f32_16x16x32_bf16 issued right behind its producer waits
+// for it: measured 19.1 instead of 16 cycles per MFMA with the accumulator-major order)
 #define MVSGI_MFMAS(WBUF, XBUF, I0, I1)                                                               \
         _Pragma("unroll") for (int i = (I0); i < (I1); ++i)                                           \
-            _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                          \
+            _Pragma("unroll") for (int j = 0; j < NW; ++j)                                            \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[WBUF][j], xh[XBUF][i], acc[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int i = (I0); i < (I1); ++i)                                           \
+            _Pragma("unroll") for (int j = 0; j < NW; ++j)                                            \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[WBUF][j], xl[XBUF][i], acc[i][j], 0, 0, 0); \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[WBUF][j], xh[XBUF][i], acc[i][j], 0, 0, 0); \
-            }
+        _Pragma("unroll") for (int i = (I0); i < (I1); ++i)                                           \
+            _Pragma("unroll") for (int j = 0; j < NW; ++j)                                            \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[WBUF][j], xh[XBUF][i], acc[i][j], 0, 0, 0);
         f32x4 acc[MW][NW];
 #pragma unroll
         for (int i = 0; i < MW; ++i)
@@ -244,7 +270,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
             for (int s0 = 0; s0 < LA; ++s0) { MVSGI_LOADW(s0, 0, s0, ctc) }
         }
+        STAMP()
         __syncthreads();                                   // image 0 holds unit 0
+        STAMP()
         int k = 0, cc = 0;
         for (int u = 0; u < U; ++u) {
             const unsigned char* img = ldsb + (u & 1) * BUF;
@@ -277,18 +305,20 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
                 asm volatile("" : "+v"(l16));      // keep `lane*16 + const` from being hoisted 28x out of the loop
                 const int xcur = XB == 2 ? (s_ & 1) : 0, xnxt = XB == 2 ? (xcur ^ 1) : 0;
                 // weight fragments LA slots ahead (this slice, or the first slots of the next unit)
-                if (s_ + LA < NSLOT) {
-                    if (s_ + LA < kPairs) { MVSGI_LOADW((s_ + LA) % WB, cc, s_ + LA, ctc) }
-                } else if (more) {
-                    MVSGI_LOADW((s_ + LA - NSLOT) % WB, ncc, s_ + LA - NSLOT, ctn)
+                if (!(MVSGI_ABL & 1)) {
+                    if (s_ + LA < NSLOT) {
+                        if (s_ + LA < kPairs) { MVSGI_LOADW((s_ + LA) % WB, cc, s_ + LA, ctc) }
+                    } else if (more) {
+                        MVSGI_LOADW((s_ + LA - NSLOT) % WB, ncc, s_ + LA - NSLOT, ctn)
+                    }
                 }
                 if (s_ < kPairs) {
                     if (XB == 2) {
                         // one scheduling region per slot: the next slot's fragment requests (2*NW weight
                         // loads, 2*MW LDS reads) are interleaved one per RATIO MFMAs, so their issue
                         // cycles hide in the MFMA gaps instead of draining the matrix pipe between slots
-                        if (s_ + 1 < kPairs) MVSGI_READX(xnxt, s_ + 1, 0, MW)
-                        MVSGI_MFMAS(wcur, xcur, 0, MW)
+                        if (s_ + 1 < kPairs && !(MVSGI_ABL & 2)) MVSGI_READX(xnxt, s_ + 1, 0, MW)
+                        if (!(MVSGI_ABL & 16)) { MVSGI_MFMAS(wcur, xcur, 0, MW) }
                         constexpr int NMEM = 2 * NW + 2 * MW, NMFMA = 3 * MW * NW;
                         constexpr int RATIO = NMFMA / NMEM > 0 ? NMFMA / NMEM : 1;
 #pragma unroll
@@ -310,6 +340,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            STAMP()
             if (last) {
                 // epilogue of the finished brick: lane (col, kg) of tile (i, j) holds couts
                 // ct*16 + 4*kg + 0..3 of voxel i*16 + col
@@ -341,7 +372,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
                 for (int j = 0; j < NW; ++j) ctc[j] = ctn[j];
             }
             cc = ncc;
+            STAMP()
             __syncthreads();                               // image of unit u+1 complete, image u free
+            STAMP()
         }
 #undef MVSGI_CTILES
 #undef MVSGI_LOADW
@@ -349,6 +382,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
 #undef MVSGI_MFMAS
     }
 #undef MVSGI_DECODE
+#undef STAMP
 }
 
 template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S>
@@ -375,6 +409,24 @@ int launch_bf16x3(ConvArgs a, hipStream_t st) {
     MVSGI_REQUIRE(nb < (1ll << 31), "conv3d: too many units");
     MVSGI_REQUIRE((long long)a.Din * a.Hin * a.Win * a.Cin < (1ll << 29), "conv3d: volume too large for 32-bit byte offsets");
     a.total_units = (int)nb;
+#ifdef MVSGI_STAMPS
+    {   // stamps of the PREVIOUS launch are printed when MVSGI_STAMP=2
+        static unsigned long long* dbgbuf = nullptr;
+        const char* e_ = getenv("MVSGI_STAMP");
+        if (e_ && !dbgbuf) { (void)hipMalloc(&dbgbuf, 8 * 128 * 8); (void)hipMemset(dbgbuf, 0, 8 * 128 * 8); }
+        a.dbg = dbgbuf;
+        if (e_ && atoi(e_) == 2 && dbgbuf) {
+            static unsigned long long h[8 * 128];
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(h, dbgbuf, sizeof(h), hipMemcpyDeviceToHost);
+            for (int w = 0; w < 8; ++w) {
+                fprintf(stderr, "wave %d:", w);
+                for (int i = 0; i < 44; ++i) fprintf(stderr, " %lld", (long long)(h[w * 128 + i] - h[0]));
+                fprintf(stderr, "\n");
+            }
+        }
+    }
+#endif
     // persistent grid (a multiple of 8 unless it covers every unit once): each workgroup walks the
     // units blockIdx.x + k*gridDim.x, which stay on its XCD's contiguous run of the index space
     const long long resident = 256ll * wgs_per_cu;
