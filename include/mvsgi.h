@@ -110,6 +110,22 @@ int mvsgi_conv3d_f32(const float* x, const float* w_oidhw, const float* w_packed
 const char* mvsgi_conv3d_variant_f32(int B, int Cin, int Din, int Hin, int Win, int Cout,
                                      int stride, int impl);
 
+/* ---- K2-2D: convolution block of the feature extractor ----------
+ * Replaces BaseConvBlk2d.forward (common/common_modules.py:56-70) on channels-last images:
+ *   y = act( conv2d(x, w, pad k/2, stride) * scale[co] + shift[co] (+ res) )
+ *   x [B][Hin][Win][Cin] (or the caller's NCHW images when in_nchw != 0, direct path only),
+ *   y / res [B][Ho][Wo][Cout], w_oihw [Cout][Cin][k][k], k odd <= 7, stride 1|2.
+ * impl: MVSGI_CONV_BF16X3 = split-bf16 MFMA kernel (k == 3, Cin, Cout multiples of 16, w_packed from
+ * mvsgi_conv2d_pack_weights_bf16x3); anything else, or AUTO/DIRECT = exact fp32 direct kernel. */
+size_t mvsgi_conv2d_packed_weight_bytes_bf16x3(int Cout, int Cin);
+int mvsgi_conv2d_pack_weights_bf16x3(const float* w_oihw, void* w_packed, int Cout, int Cin,
+                                     mvsgi_stream_t stream);
+int mvsgi_conv2d_f32(const float* x, const float* w_oihw, const void* w_packed,
+                     const float* scale, const float* shift, const float* res, float* y,
+                     int B, int Cin, int Hin, int Win, int Cout, int ksize, int stride,
+                     float neg_slope, int impl, int in_nchw, mvsgi_stream_t stream);
+const char* mvsgi_conv2d_variant_f32(int Cin, int Cout, int ksize, int stride, int impl, int in_nchw);
+
 /* ---- K3: trilinear resize ------------------------------------------------------------
  * Replaces F.interpolate(mode='trilinear', align_corners=False, size=...) inside
  * ResizeConv3d.forward (common/common_modules.py:333-350), for x2 and for the odd-size

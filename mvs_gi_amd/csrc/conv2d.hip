@@ -1,0 +1,169 @@
+// 2-D convolution block for the feature extractor:
+//   y = act( conv2d(x, w, pad k/2, stride) * scale + shift (+ res) )
+// replaces BaseConvBlk2d.forward (dsta_mvs/model/common/common_modules.py:56-70) with eval-mode
+// BatchNorm2d as the per-channel (scale, shift); images are channels-last [B][H][W][C]
+// (the first layer may read the caller's NCHW images directly).
+//
+//  * 3x3, Cin/Cout multiples of 16: the split-bf16 MFMA kernel of conv3d_bf16x3.hpp instantiated
+//    with KD = 1 (a brick is one image plane thick, 9 taps -> 5 tap pairs);
+//  * anything else (the 5x5 stride-2 RGB stem, exact-fp32 mode): conv2d_direct_kernel.
+#include "common.hpp"
+#include "conv_common.hpp"
+#ifdef MVSGI_STAMPS
+#include <cstdio>
+#include <cstdlib>
+#endif
+
+namespace {
+
+#include "conv3d_bf16x3.hpp"
+
+struct Conv2dArgs {
+    const float* x;
+    const float* w;      // [Cout][Cin][k][k]
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* y;
+    int B, Cin, Hin, Win, Cout, Ho, Wo, k, stride, in_nchw;
+    float neg_slope;
+};
+
+// thread = (pixel, CO consecutive couts); weights are wave-uniform reads
+template <int CO>
+__global__ __launch_bounds__(256) void conv2d_direct_kernel(Conv2dArgs a) {
+    const int groups = (a.Cout + CO - 1) / CO;
+    const long long total = (long long)a.B * a.Ho * a.Wo * groups;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cg = (int)(idx % groups);
+    const long long pix = idx / groups;
+    const int ow = (int)(pix % a.Wo);
+    const int oh = (int)((pix / a.Wo) % a.Ho);
+    const int b = (int)(pix / ((long long)a.Wo * a.Ho));
+    const int co0 = cg * CO, pad = a.k / 2;
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+    for (int ky = 0; ky < a.k; ++ky) {
+        const int ih = oh * a.stride - pad + ky;
+        if (ih < 0 || ih >= a.Hin) continue;
+        for (int kx = 0; kx < a.k; ++kx) {
+            const int iw = ow * a.stride - pad + kx;
+            if (iw < 0 || iw >= a.Win) continue;
+            for (int ci = 0; ci < a.Cin; ++ci) {
+                const float xv = a.in_nchw ? a.x[(((long long)b * a.Cin + ci) * a.Hin + ih) * a.Win + iw]
+                                           : a.x[(((long long)b * a.Hin + ih) * a.Win + iw) * a.Cin + ci];
+#pragma unroll
+                for (int o = 0; o < CO; ++o) {
+                    const int co = co0 + o;
+                    if (co < a.Cout) acc[o] = fmaf(xv, a.w[(((long long)co * a.Cin + ci) * a.k + ky) * a.k + kx], acc[o]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+        const int co = co0 + o;
+        if (co >= a.Cout) break;
+        float r = acc[o] * a.scale[co] + a.shift[co];
+        if (a.res) r += a.res[pix * a.Cout + co];
+        r = r > 0.f ? r : r * a.neg_slope;
+        a.y[pix * a.Cout + co] = r;
+    }
+}
+
+enum Variant2d { D2_DIRECT, D2_N16, D2_N32, D2_N64, D2_S2_N32, D2_S2_N64, D2_COUNT };
+const char* const kNames2d[D2_COUNT] = {
+    "conv2d_direct_kernel<4>",
+    "conv3d_bf16x3_kernel<1, 4, 4, 1, 1, 16, 16, 1, 1>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 1, 16, 16, 1, 1>",
+    "conv3d_bf16x3_kernel<2, 4, 2, 2, 1, 8, 16, 1, 1>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 2, 1>",
+    "conv3d_bf16x3_kernel<2, 2, 2, 2, 1, 4, 16, 2, 1>",
+};
+
+int select2d(int Cin, int Cout, int k, int stride, int impl, const void* w, const void* wp, int in_nchw) {
+    const bool mfma_ok = k == 3 && Cin % 16 == 0 && Cout % 16 == 0 && !in_nchw && (stride == 1 || stride == 2);
+    if (impl == MVSGI_CONV_BF16X3 && mfma_ok) {
+        if (!wp) { mvsgi::fail("mvsgi_conv2d_f32: bf16x3 path needs w_packed"); return D2_COUNT; }
+        const int CT = Cout / 16;
+        if (stride == 2) return CT <= 2 ? D2_S2_N32 : D2_S2_N64;
+        return CT == 1 ? D2_N16 : CT <= 3 ? D2_N32 : D2_N64;
+    }
+    if (impl != MVSGI_CONV_AUTO && impl != MVSGI_CONV_DIRECT && impl != MVSGI_CONV_BF16X3) {
+        mvsgi::fail("mvsgi_conv2d_f32: unknown impl %d", impl);
+        return D2_COUNT;
+    }
+    if (!w) { mvsgi::fail("mvsgi_conv2d_f32: direct path needs w_oihw"); return D2_COUNT; }
+    return D2_DIRECT;
+}
+
+}  // namespace
+
+extern "C" size_t mvsgi_conv2d_packed_weight_bytes_bf16x3(int Cout, int Cin) {
+    return (size_t)(Cin / 16) * pairs_of(1) * (size_t)(Cout / 16) * 2 * 64 * 16;
+}
+
+extern "C" int mvsgi_conv2d_pack_weights_bf16x3(const float* w_oihw, void* w_packed, int Cout, int Cin,
+                                                mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(w_oihw && w_packed, "mvsgi_conv2d_pack_weights_bf16x3: null pointer");
+    MVSGI_REQUIRE(Cout > 0 && Cin > 0 && Cout % 16 == 0 && Cin % 16 == 0,
+                  "mvsgi_conv2d_pack_weights_bf16x3: Cout=%d Cin=%d must be positive multiples of 16", Cout, Cin);
+    const long long total = (long long)(Cin / 16) * pairs_of(1) * (Cout / 16) * 64;
+    hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0,
+                       mvsgi::as_stream(stream), w_oihw, reinterpret_cast<bf16x8*>(w_packed), Cout, Cin, 9);
+    return mvsgi::check_launch("mvsgi_conv2d_pack_weights_bf16x3");
+}
+
+extern "C" const char* mvsgi_conv2d_variant_f32(int Cin, int Cout, int ksize, int stride, int impl, int in_nchw) {
+    static const float dummy = 0.f;
+    const int v = select2d(Cin, Cout, ksize, stride, impl, &dummy, &dummy, in_nchw);
+    return v == D2_COUNT ? nullptr : kNames2d[v];
+}
+
+extern "C" int mvsgi_conv2d_f32(const float* x, const float* w_oihw, const void* w_packed, const float* scale,
+                                const float* shift, const float* res, float* y, int B, int Cin, int Hin, int Win,
+                                int Cout, int ksize, int stride, float neg_slope, int impl, int in_nchw,
+                                mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(x && y && scale && shift, "mvsgi_conv2d_f32: null pointer");
+    MVSGI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0, "mvsgi_conv2d_f32: bad dims");
+    MVSGI_REQUIRE(ksize >= 1 && (ksize & 1) && ksize <= 7, "mvsgi_conv2d_f32: kernel size %d not odd in [1, 7]", ksize);
+    MVSGI_REQUIRE(stride == 1 || stride == 2, "mvsgi_conv2d_f32: stride %d not in {1, 2}", stride);
+    const int pad = ksize / 2;
+    const int Ho = (Hin + 2 * pad - ksize) / stride + 1, Wo = (Win + 2 * pad - ksize) / stride + 1;
+    const int v = select2d(Cin, Cout, ksize, stride, impl, w_oihw, w_packed, in_nchw);
+    if (v == D2_COUNT) return 1;
+    hipStream_t st = mvsgi::as_stream(stream);
+    if (v == D2_DIRECT) {
+        Conv2dArgs a{x, w_oihw, scale, shift, res, y, B, Cin, Hin, Win, Cout, Ho, Wo, ksize, stride, in_nchw, neg_slope};
+        const long long total = (long long)B * Ho * Wo * mvsgi::cdiv(Cout, 4);
+        hipLaunchKernelGGL((conv2d_direct_kernel<4>), dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0, st, a);
+        return mvsgi::check_launch("mvsgi_conv2d_f32(direct)");
+    }
+    // images as a volume whose D planes do not interact: [B][H][W][C] == [1][B][H][W][C]
+    ConvArgs a{};
+    a.x = x;
+    a.wp = reinterpret_cast<const f32x4*>(w_packed);
+    a.scale = scale;
+    a.shift = shift;
+    a.res = res;
+    a.y = y;
+    a.B = 1;
+    a.Cin = Cin;
+    a.Din = B;
+    a.Hin = Hin;
+    a.Win = Win;
+    a.Cout = Cout;
+    a.stride = stride;
+    a.neg_slope = neg_slope;
+    a.Do = B;
+    a.Ho = Ho;
+    a.Wo = Wo;
+    switch (v) {
+        case D2_N16: return launch_bf16x3<1, 4, 4, 1, 1, 16, 16, 1, 1>(a, st);
+        case D2_N32: return launch_bf16x3<2, 4, 4, 1, 1, 16, 16, 1, 1>(a, st);
+        case D2_N64: return launch_bf16x3<2, 4, 2, 2, 1, 8, 16, 1, 1>(a, st);
+        case D2_S2_N32: return launch_bf16x3<2, 1, 4, 1, 1, 4, 16, 2, 1>(a, st);
+        case D2_S2_N64: return launch_bf16x3<2, 2, 2, 2, 1, 4, 16, 2, 1>(a, st);
+    }
+    return mvsgi::fail("mvsgi_conv2d_f32: bad variant %d", v);
+}

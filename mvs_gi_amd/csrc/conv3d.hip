@@ -21,31 +21,13 @@
 //    counts; used for the Cout == 1 cost head (unet_regulator.py:61-68) and as the on-device
 //    cross-check of the MFMA path.
 #include "common.hpp"
+#include "conv_common.hpp"
 #ifdef MVSGI_STAMPS
 #include <cstdio>
 #include <cstdlib>
 #endif
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct ConvArgs {
-    const float* x;
-    const float* w_oidhw;
-    const f32x4* wp;
-    const float* scale;
-    const float* shift;
-    const float* res;
-    float* y;
-    int B, Cin, Din, Hin, Win, Cout, Do, Ho, Wo, stride;
-    float neg_slope;   // act(v) = v > 0 ? v : v * neg_slope; 1.0 = identity
-    int tiles_d, tiles_h, tiles_w;
-    int total_units;   // persistent bf16x3 kernel: bricks x cout blocks
-    unsigned long long* dbg;   // MVSGI_STAMPS diagnostic build only
-};
-
-constexpr int kVS = 20;           // LDS floats per staged voxel: 16 channels + 4 pad
 
 // ----------------------------------------------------------------------------------------
 // weight packing: [Cout][Cin][27] -> [Cin/16][27][Cout/16][64 lanes][4]
@@ -466,7 +448,7 @@ extern "C" size_t mvsgi_conv3d_packed_weight_floats(int Cout, int Cin) {
 }
 
 extern "C" size_t mvsgi_conv3d_packed_weight_bytes_bf16x3(int Cout, int Cin) {
-    return (size_t)(Cin / 16) * kPairs * (size_t)(Cout / 16) * 2 * 64 * 16;
+    return (size_t)(Cin / 16) * pairs_of(3) * (size_t)(Cout / 16) * 2 * 64 * 16;
 }
 
 extern "C" int mvsgi_conv3d_pack_weights_bf16x3(const float* w_oidhw, void* w_packed, int Cout, int Cin,
@@ -474,9 +456,9 @@ extern "C" int mvsgi_conv3d_pack_weights_bf16x3(const float* w_oidhw, void* w_pa
     MVSGI_REQUIRE(w_oidhw && w_packed, "mvsgi_conv3d_pack_weights_bf16x3: null pointer");
     MVSGI_REQUIRE(Cout > 0 && Cin > 0 && Cout % 16 == 0 && Cin % 16 == 0,
                   "mvsgi_conv3d_pack_weights_bf16x3: Cout=%d Cin=%d must be positive multiples of 16", Cout, Cin);
-    const long long total = (long long)(Cin / 16) * kPairs * (Cout / 16) * 64;
+    const long long total = (long long)(Cin / 16) * pairs_of(3) * (Cout / 16) * 64;
     hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0,
-                       mvsgi::as_stream(stream), w_oidhw, reinterpret_cast<bf16x8*>(w_packed), Cout, Cin);
+                       mvsgi::as_stream(stream), w_oidhw, reinterpret_cast<bf16x8*>(w_packed), Cout, Cin, 27);
     return mvsgi::check_launch("mvsgi_conv3d_pack_weights_bf16x3");
 }
 

@@ -34,11 +34,13 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int kVSB = 80;      // LDS bytes per staged voxel
-constexpr int kPairs = 14;
+constexpr int pairs_of(int kd) { return (kd * 9 + 1) / 2; }      // KD = 3: 14 pairs of 27 taps; KD = 1 (2-D 3x3): 5 of 9
 
-// [Cout][Cin][27] -> [Cin/16][Cout/16][14 pairs][hi|lo][64 lanes][8 bf16]
+// [Cout][Cin][taps] -> [Cin/16][Cout/16][pairs][hi|lo][64 lanes][8 bf16]   (taps = 27 or 9)
 //   lane = (kg << 4) | i holds W[cout = ct*16+i][cin = cc*16 + (kg>>1)*8 + j][tap = 2p + (kg&1)]
-__global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout, int Cin) {
+__global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout, int Cin,
+                                           int taps) {
+    const int kPairs = (taps + 1) / 2;
     const int CT = Cout / 16;
     const long long total = (long long)(Cin / 16) * kPairs * CT * 64;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -55,7 +57,7 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, bf16x8* 
     const int tap = 2 * p + (kg & 1);
     bf16x8 hi, lo;
     for (int j = 0; j < 8; ++j) {
-        const float v = tap < 27 ? w[((long long)co * Cin + ci + j) * 27 + tap] : 0.f;
+        const float v = tap < taps ? w[((long long)co * Cin + ci + j) * taps + tap] : 0.f;
         const __bf16 h = (__bf16)v;
         hi[j] = h;
         lo[j] = (__bf16)(v - (float)h);
@@ -72,21 +74,26 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S>
+// KD = 3: 3x3x3 convolution of a volume; KD = 1: 3x3 convolution of images (a volume with D planes
+// that do not see each other: the feature extractor's conv2d on [B*N] channels-last images)
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3>
 __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
     static_assert(WM * WN == 4, "4 consumer waves per workgroup");
     static_assert(WM * MW * 16 == TD * TH * TW, "brick must be covered by the voxel tiles");
-    constexpr int ITD = (TD - 1) * S + 3, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
+    static_assert(KD == 3 || (KD == 1 && TD == 1), "2-D bricks are one plane thick");
+    constexpr int SD = KD == 1 ? 1 : S;               // images are never strided over
+    constexpr int kTaps = KD * 9, kPairs = pairs_of(KD);
+    constexpr int ITD = (TD - 1) * SD + KD, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
     constexpr int IV = ITD * ITH * ITW;
     constexpr int NIT = (IV * 4 + 255) / 256;      // staging items per producer thread and unit
     constexpr int BUF = IV * kVSB;                 // bytes of one LDS image
     // weight pipeline of the consumers: WB register buffers, fragments requested LA slots ahead.
-    // A slice has NSLOT slots = 14 tap pairs (+ one rotation-only slot when WB == 3, so that
-    // NSLOT % WB == 0 and every buffer index is a compile-time constant).
+    // A slice has NSLOT slots = the tap pairs rounded up to a multiple of WB (rotation-only slots), so
+    // that every register-buffer index is a compile-time constant.
     constexpr int WB = NW <= 2 ? 3 : 2;
     constexpr int LA = WB - 1;
-    constexpr int NSLOT = WB == 3 ? 15 : 14;
-    static_assert(NSLOT % WB == 0, "pipeline geometry");
+    constexpr int NSLOT = ((kPairs + WB - 1) / WB) * WB;
+    static_assert(NSLOT % WB == 0 && NSLOT >= kPairs, "pipeline geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
             int cb_, b_, od_, oh_, ow_;                                                                 \
             MVSGI_DECODE(UNIT, cb_, b_, od_, oh_, ow_)                                                  \
             (void)cb_;                                                                                  \
-            const int id0_ = od_ * S - 1, ih0_ = oh_ * S - 1, iw0_ = ow_ * S - 1;                       \
+            const int id0_ = od_ * SD - KD / 2, ih0_ = oh_ * S - 1, iw0_ = ow_ * S - 1;                 \
             okmask = 0;                                                                                 \
             _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                        \
                 const int e = ptid + it * 256;                                                          \
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
         for (int i = 0; i < MW; ++i) {
             const int v = (wm * MW + i) * 16 + col;
             const int w_ = v % TW, h_ = (v / TW) % TH, d_ = v / (TW * TH);
-            base[i] = (((d_ * S) * ITH + h_ * S) * ITW + w_ * S) * kVSB + (kg >> 1) * 16;
+            base[i] = (((d_ * SD) * ITH + h_ * S) * ITW + w_ * S) * kVSB + (kg >> 1) * 16;
         }
         int ctc[NW], ctn[NW];             // clamped cout tiles of the current / the next unit
 #define MVSGI_CTILES(DST, CB)                                                         \
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
 #define MVSGI_READX(BUFI, P, I0, I1)                                                                  \
         {                                                                                             \
             const int p_ = (P);                                                                       \
-            const int t0_ = 2 * p_, t1_ = (2 * p_ + 1 < 27) ? 2 * p_ + 1 : 2 * p_;                    \
+            const int t0_ = 2 * p_, t1_ = (2 * p_ + 1 < kTaps) ? 2 * p_ + 1 : 2 * p_;                 \
             const int o0_ = (((t0_ / 9) * ITH + (t0_ / 3) % 3) * ITW + t0_ % 3) * kVSB;               \
             const int o1_ = (((t1_ / 9) * ITH + (t1_ / 3) % 3) * ITW + t1_ % 3) * kVSB;               \
             const int off_ = second ? o1_ : o0_;                                                      \
@@ -385,12 +392,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
 #undef STAMP
 }
 
-template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S>
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3>
 int launch_bf16x3(ConvArgs a, hipStream_t st) {
-    constexpr int ITD = (TD - 1) * S + 3, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
+    constexpr int ITD = (TD - 1) * (KD == 1 ? 1 : S) + KD, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
     constexpr size_t lds_bytes = (size_t)2 * ITD * ITH * ITW * kVSB;      // double-buffered image
     static_assert(lds_bytes <= 160 * 1024, "LDS images too large");
-    auto kern = conv3d_bf16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S>;
+    auto kern = conv3d_bf16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD>;
     static int wgs_per_cu = 0;       // benign race: idempotent
     if (!wgs_per_cu) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

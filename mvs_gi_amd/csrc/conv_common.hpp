@@ -1,0 +1,25 @@
+// Definitions shared by the 3-D (conv3d.hip) and 2-D (conv2d.hip) convolution translation units.
+#pragma once
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+    const float* x;
+    const float* w_oidhw;
+    const f32x4* wp;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* y;
+    int B, Cin, Din, Hin, Win, Cout, Do, Ho, Wo, stride;
+    float neg_slope;   // act(v) = v > 0 ? v : v * neg_slope; 1.0 = identity
+    int tiles_d, tiles_h, tiles_w;
+    int total_units;   // persistent bf16x3 kernel: bricks x cout blocks
+    unsigned long long* dbg;   // MVSGI_STAMPS diagnostic build only
+};
+
+constexpr int kVS = 20;           // LDS floats per staged voxel: 16 channels + 4 pad
+
+
+}  // namespace

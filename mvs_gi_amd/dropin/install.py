@@ -27,6 +27,7 @@ from . import cost_volume_builder as _cvb
 from . import cost_volume_regulator as _reg
 from . import distance_regressor as _dr
 from . import torch_only as _to
+from . import feature_extractor as _fe
 
 _ALIAS_FLAG = "__mvsgi_alias__"
 _state = {"mode": None, "saved": []}
@@ -64,12 +65,19 @@ def _install_aliases():
     _export(reg, _reg, ["UNetCostVolumeRegulatorBase", "UNetCostVolumeRegulator", "UNetDownBlk"])
     dr = _pkg("dsta_mvs.model.distance_regressor")
     _export(dr, _dr, ["DistanceRegressorWithFixedCandidates"])
+    fe = _pkg("dsta_mvs.model.feature_extractor")
+    _export(fe, _fe, ["SimpleFeatExtraction"])
     mm = _pkg("dsta_mvs.model.mvs_model")
     _export(mm, _to, ["SphericalSweepStereoBase"])
     mods.update({"dsta_mvs": root, "dsta_mvs.model": model, "dsta_mvs.model.common": common,
                  "dsta_mvs.model.cost_volume_builder": cvb, "dsta_mvs.model.cost_volume_regulator": reg,
-                 "dsta_mvs.model.distance_regressor": dr, "dsta_mvs.model.mvs_model": mm})
+                 "dsta_mvs.model.distance_regressor": dr, "dsta_mvs.model.mvs_model": mm,
+                 "dsta_mvs.model.feature_extractor": fe})
+    fe.simple_feature_extractor = leaf("dsta_mvs.model.feature_extractor.simple_feature_extractor", _fe)
+
     common.common_modules = leaf("dsta_mvs.model.common.common_modules", _cm)
+    for n in ("BaseConvBlk2d", "ResConvBlk2d"):      # the 2-D blocks live in common_modules upstream
+        setattr(common.common_modules, n, getattr(_fe, n))
     cvb.spherical_sweep_avg = leaf("dsta_mvs.model.cost_volume_builder.spherical_sweep_avg", _cvb)
     cvb.spherical_sweep = leaf("dsta_mvs.model.cost_volume_builder.spherical_sweep", _cvb)
     reg.unet_regulator = leaf("dsta_mvs.model.cost_volume_regulator.unet_regulator", _reg)
@@ -77,7 +85,7 @@ def _install_aliases():
     mm.torch_only = leaf("dsta_mvs.model.mvs_model.torch_only", _to)
     root.model = model
     model.common, model.cost_volume_builder, model.cost_volume_regulator = common, cvb, reg
-    model.distance_regressor, model.mvs_model = dr, mm
+    model.distance_regressor, model.mvs_model, model.feature_extractor = dr, mm, fe
     for k, v in mods.items():
         sys.modules[k] = v
     _state["saved"] = list(mods)
@@ -104,6 +112,10 @@ def _patch_reference():
     rebind(c.BaseConvBlk3d, forward=_cm.BaseConvBlk3d.forward)
     rebind(c.ResConvBlk3d, forward=_cm.ResConvBlk3d.forward)
     rebind(c.ResizeConv3d, forward=_cm.ResizeConv3d.forward)
+    rebind(c.BaseConvBlk2d, forward=_fe.BaseConvBlk2d.forward)
+    rebind(c.ResConvBlk2d, forward=_fe.ResConvBlk2d.forward)
+    f = importlib.import_module("dsta_mvs.model.feature_extractor.simple_feature_extractor")
+    rebind(f.SimpleFeatExtraction, forward=_fe.extractor_forward)
     _state["saved"] = saved
 
 

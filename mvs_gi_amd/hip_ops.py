@@ -219,6 +219,49 @@ def conv3d_variant(B, Cin, Din, Hin, Win, Cout, stride=1, impl=CONV_AUTO) -> str
     return name.decode()
 
 
+def pack_conv2d_weights_bf16x3(w_oihw: torch.Tensor) -> Optional[torch.Tensor]:
+    """[Cout, Cin, 3, 3] -> split-bf16 MFMA layout, or None when unsupported."""
+    lib = _lib.load()
+    w = _dev(w_oihw, "conv weight")
+    Cout, Cin = w.shape[:2]
+    if tuple(w.shape[2:]) != (3, 3) or Cin % 16 or Cout % 16:
+        return None
+    wp = torch.empty(lib.mvsgi_conv2d_packed_weight_bytes_bf16x3(Cout, Cin), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.mvsgi_conv2d_pack_weights_bf16x3(w.data_ptr(), wp.data_ptr(), Cout, Cin, _stream_ptr(w)),
+               "mvsgi_conv2d_pack_weights_bf16x3")
+    return wp
+
+
+def conv2d(x, w_oihw, w_packed, scale, shift, res=None, stride=1, neg_slope=0.01, impl=CONV_AUTO, in_nchw=False):
+    """x [B, H, W, Cin] (or [B, Cin, H, W] with in_nchw) -> y [B, Ho, Wo, Cout] = act(conv(x)*scale + shift (+res))."""
+    lib = _lib.load()
+    x = _dev(x, "x")
+    if in_nchw:
+        B, Cin, Hin, Win = x.shape
+    else:
+        B, Hin, Win, Cin = x.shape
+    Cout, k = scale.numel(), int(w_oihw.shape[-1])
+    pad = k // 2
+    Ho, Wo = (Hin + 2 * pad - k) // stride + 1, (Win + 2 * pad - k) // stride + 1
+    if res is not None:
+        res = _dev(res, "res")
+        if tuple(res.shape) != (B, Ho, Wo, Cout):
+            raise AssertionError(f"residual {tuple(res.shape)} does not match output {(B, Ho, Wo, Cout)}")
+    y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_conv2d_f32(x.data_ptr(), _ptr(w_oihw), _ptr(w_packed), scale.data_ptr(), shift.data_ptr(),
+                                    _ptr(res), y.data_ptr(), B, Cin, Hin, Win, Cout, k, stride, float(neg_slope), impl,
+                                    int(bool(in_nchw)), _stream_ptr(x)), "mvsgi_conv2d_f32")
+    return y
+
+
+def conv2d_variant(Cin, Cout, k=3, stride=1, impl=CONV_AUTO, in_nchw=False) -> str:
+    lib = _lib.load()
+    name = lib.mvsgi_conv2d_variant_f32(Cin, Cout, k, stride, impl, int(bool(in_nchw)))
+    if name is None:
+        raise RuntimeError("mvsgi_conv2d_variant_f32: " + lib.mvsgi_last_error().decode())
+    return name.decode()
+
+
 def resize_trilinear(x, size) -> torch.Tensor:
     lib = _lib.load()
     x = _dev(x, "x")

@@ -128,6 +128,47 @@ def make_weights(cfg: PathConfig, seed: int = 0, gain: float = 1.0) -> Dict[str,
     return dict(cv_builder=builder, cv_regulator=reg)
 
 
+def _conv_block2d(rng, prefix, cin, cout, k, out):
+    bound = float(np.sqrt(6.0 / (cin * k * k)))
+    out[f"{prefix}.conv_layer.weight"] = rng.uniform(-bound, bound, (cout, cin, k, k)).astype(np.float32)
+    out[f"{prefix}.norm_layer.weight"] = rng.uniform(0.5, 1.5, (cout,)).astype(np.float32)
+    out[f"{prefix}.norm_layer.bias"] = rng.normal(0, 0.1, (cout,)).astype(np.float32)
+    out[f"{prefix}.norm_layer.running_mean"] = rng.normal(0, 0.1, (cout,)).astype(np.float32)
+    out[f"{prefix}.norm_layer.running_var"] = rng.uniform(0.5, 1.5, (cout,)).astype(np.float32)
+    out[f"{prefix}.norm_layer.num_batches_tracked"] = np.asarray(1, np.int64)
+
+
+def make_extractor_weights(seed: int = 0, in_chs: int = 3, chs: int = 16, layers=(5, 10),
+                           out_gain: float = 0.06) -> Dict[str, np.ndarray]:
+    """State dict of SimpleFeatExtraction (reference key names: first, blks.{i}[.blk1|.blk2], final_layer).
+    `out_gain` scales the last BatchNorm so that the features come out O(1) like the N(0,1) features
+    the hot-path cases use (31 He-initialised layers with residual adds otherwise grow them ~18x, which
+    turns the downstream softmax into an arg-max and the end-to-end test into a tie-breaking test)."""
+    rng = np.random.default_rng(20_000 + seed)
+    sd: Dict[str, np.ndarray] = {}
+    _conv_block2d(rng, "first", in_chs, chs, 5, sd)
+    i = 0
+    for step, n in enumerate(layers):
+        for _ in range(n):
+            _conv_block2d(rng, f"blks.{i}.blk1", chs, chs, 3, sd)
+            _conv_block2d(rng, f"blks.{i}.blk2", chs, chs, 3, sd)
+            i += 1
+        if step != len(layers) - 1:
+            _conv_block2d(rng, f"blks.{i}", chs, chs, 3, sd)
+            i += 1
+    _conv_block2d(rng, "final_layer", chs, chs, 3, sd)
+    sd["final_layer.norm_layer.weight"] = (sd["final_layer.norm_layer.weight"] * np.float32(out_gain)).astype(np.float32)
+    sd["final_layer.norm_layer.bias"] = (sd["final_layer.norm_layer.bias"] * np.float32(out_gain)).astype(np.float32)
+    return sd
+
+
+def make_images(cfg: PathConfig, seed: int = 0, batch: int = 1) -> np.ndarray:
+    """imgs [B, N, 3, 4*Hi, 4*Wi] in [0, 1) (the extractor's output is the 1/4-resolution feature map)."""
+    rng = np.random.default_rng(30_000 + seed)
+    Hi, Wi = cfg.feat_hw
+    return rng.random((batch, cfg.num_cams, 3, 4 * Hi, 4 * Wi), dtype=np.float32)
+
+
 def digest(arrays: Dict[str, np.ndarray]) -> str:
     """Order-independent sha256 over named arrays: lets a test on the GPU box prove it
     regenerated exactly the inputs the golden outputs were computed from."""

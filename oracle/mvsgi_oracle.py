@@ -183,6 +183,49 @@ def regulator_forward(vol: Tensor, p: Dict[str, Tensor], u_depth: int = 3, blk_w
 
 
 # ----------------------------------------------------------------------------
+# feature extractor
+# ----------------------------------------------------------------------------
+def conv_block2d(x: Tensor, p: Dict[str, Tensor], prefix: str, stride: int = 1,
+                 res: Optional[Tensor] = None) -> Tensor:
+    """BaseConvBlk2d.forward (common_modules.py:56-70): conv (pad k//2) -> eval BN -> (+res) -> LeakyReLU."""
+    w = p[f"{prefix}.conv_layer.weight"]
+    y = F.conv2d(x, w, p.get(f"{prefix}.conv_layer.bias"), stride=stride, padding=w.shape[-1] // 2)
+    y = F.batch_norm(y, p[f"{prefix}.norm_layer.running_mean"], p[f"{prefix}.norm_layer.running_var"],
+                     p[f"{prefix}.norm_layer.weight"], p[f"{prefix}.norm_layer.bias"], training=False, eps=BN_EPS)
+    if res is not None:
+        y = y + res
+    return F.leaky_relu(y, LRELU_SLOPE)
+
+
+def feature_extractor(imgs: Tensor, p: Dict[str, Tensor], layers: Sequence[int] = (5, 10)) -> Tensor:
+    """SimpleFeatExtraction.forward (feature_extractor/simple_feature_extractor.py:81-84):
+    5x5 stride-2 stem, `layers[i]` residual blocks per stage (ResConvBlk2d.forward,
+    common_modules.py:165-176), a 3x3 stride-2 conv between stages, final 3x3 conv.
+    imgs [M, 3, H, W] -> [M, chs, H/4, W/4]."""
+    x = conv_block2d(imgs, p, "first", stride=2)
+    i = 0
+    for step, n in enumerate(layers):
+        for _ in range(n):
+            r = conv_block2d(x, p, f"blks.{i}.blk1")
+            x = conv_block2d(r, p, f"blks.{i}.blk2", res=x)
+            i += 1
+        if step != len(layers) - 1:
+            x = conv_block2d(x, p, f"blks.{i}", stride=2)
+            i += 1
+    return conv_block2d(x, p, "final_layer")
+
+
+def full_model(imgs: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor, weights, builder: str,
+               dist_cands: Sequence[float], **kw) -> Tensor:
+    """SphericalSweepStereoBase.forward (mvs_model/torch_only.py:20-36): imgs [B, N, 3, H, W]."""
+    with torch.no_grad():
+        B, N = imgs.shape[:2]
+        f = feature_extractor(imgs.reshape(B * N, *imgs.shape[2:]), weights["feature_extractor"])
+        feats = f.reshape(B, N, *f.shape[1:])
+    return hot_path(feats, grids, grid_masks, masks, weights, builder, dist_cands, **kw)
+
+
+# ----------------------------------------------------------------------------
 # regression
 # ----------------------------------------------------------------------------
 def soft_argmin(costs: Tensor, dist_cands: Sequence[float], bf: float = 96.0,

@@ -125,3 +125,13 @@ def test_patch_mode_rebinds_reference_classes():
         print("OK")
     """, extra_path=["/root/reference"])
     assert "OK" in out
+
+
+def test_feature_extractor_state_dict_names():
+    fe = dropin.SimpleFeatExtraction(in_size=(512, 2048), in_chs=3, chs=16, k_sz=3, layers=[5, 10])
+    sd = synth.make_extractor_weights(0)    # keyed with the reference's names (strict-loaded into the reference by make_goldens)
+    fe.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    assert len(fe.state_dict()) == 198
+    assert fe.first.infer_size((512, 2048)) == (256, 1024)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        fe.eval()(torch.zeros(1, 3, 16, 32))

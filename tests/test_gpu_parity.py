@@ -358,3 +358,78 @@ def test_bench_two_ranks_frame_sharded_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
     assert d["value"] > 0 and abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.02
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "mfma"
+
+
+# ------------------------------------------------------------------------------ feature extractor (§8(f) rank 1)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 20, 36, 1, True), (1, 16, 16, 33, 47, 1, False), (2, 16, 16, 24, 40, 2, False),
+                                   (1, 32, 32, 17, 30, 1, True), (1, 16, 64, 16, 32, 2, False), (1, 64, 64, 12, 20, 1, True)])
+def test_conv2d_bf16x3_and_direct_vs_aten(shape):
+    B, Cin, Cout, Hh, W, stride, res = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal((B, Cin, Hh, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.normal(0, 0.2, Cout).astype(np.float32)
+    y = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), None, stride=stride, padding=1)
+    y = y * torch.from_numpy(scale).view(1, -1, 1, 1) + torch.from_numpy(shift).view(1, -1, 1, 1)
+    r = rng.standard_normal(tuple(y.shape)).astype(np.float32) if res else None
+    if res:
+        y = y + torch.from_numpy(r)
+    yref = torch.where(y > 0, y, y * 0.01).numpy()
+    xg = _g(x).permute(0, 2, 3, 1).contiguous()
+    rg = None if r is None else _g(r).permute(0, 2, 3, 1).contiguous()
+    wg = _g(w)
+    yd = H.conv2d(xg, wg, None, _g(scale), _g(shift), res=rg, stride=stride, impl=H.CONV_DIRECT)
+    assert _rel(yd.permute(0, 3, 1, 2).cpu().numpy(), yref) <= 2e-5
+    assert "bf16x3" in H.conv2d_variant(Cin, Cout, 3, stride, H.CONV_BF16X3)
+    yb = H.conv2d(xg, wg, H.pack_conv2d_weights_bf16x3(wg), _g(scale), _g(shift), res=rg, stride=stride, impl=H.CONV_BF16X3)
+    assert _rel(yb.permute(0, 3, 1, 2).cpu().numpy(), yref) <= 1e-4
+
+
+def test_conv2d_stem_5x5_nchw_input():
+    rng = np.random.default_rng(12)
+    x = rng.random((2, 3, 30, 52)).astype(np.float32)
+    w = (rng.standard_normal((16, 3, 5, 5)) / np.sqrt(75)).astype(np.float32)
+    yref = F.leaky_relu(F.conv2d(torch.from_numpy(x), torch.from_numpy(w), None, stride=2, padding=2), 0.01).numpy()
+    y = H.conv2d(_g(x), _g(w), None, torch.ones(16, device=DEV), torch.zeros(16, device=DEV), stride=2, in_nchw=True)
+    assert _rel(y.permute(0, 3, 1, 2).cpu().numpy(), yref) <= 2e-5
+
+
+def test_feature_extractor_and_end_to_end_vs_reference(golden_dir, conv_mode):
+    """SimpleFeatExtraction drop-in and the imgs -> inv_dist composition against the reference's outputs."""
+    from mvs_gi_amd.configs import CONFIGS, DIST_8L
+    z = _load(golden_dir, "extractor_small")
+    cfg = CONFIGS["G16V"].scaled(feat_hw=(16, 64), mask_hw=(64, 256), cv_hw=(8, 32), dist_cands=DIST_8L)
+    seed = 8
+    imgs = synth.make_images(cfg, seed=seed, batch=2)
+    inp = synth.make_inputs(cfg, seed=seed, batch=2)
+    assert synth.digest({"imgs": imgs}) == str(z["imgs_sha256"])
+    fe = dropin.SimpleFeatExtraction(in_size=(64, 256), in_chs=3, chs=16, k_sz=3, layers=[5, 10])
+    fe.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_extractor_weights(seed).items()}, strict=True)
+    hp = HotPath(cfg, synth.make_weights(cfg, seed=seed), inp, device=DEV)
+    model = dropin.SphericalSweepStereoBase(fe.eval().to(DEV), hp.cv_builder, hp.cv_regulator, hp.dist_regressor)
+    with torch.no_grad():
+        feats = model.extract_features(_g(imgs))
+        inv, _ = model(_g(imgs), hp.grids, hp.grid_masks, hp.masks)
+    assert tuple(feats.shape) == tuple(z["feats"].shape)
+    ferr = _rel(feats.contiguous().cpu().numpy(), z["feats"])
+    ierr = _rel(inv.cpu().numpy(), z["inv_dist"])
+    print(f"extractor [{conv_mode}]: feats max-rel {ferr:.3e}, end-to-end inv_dist max-rel {ierr:.3e}")
+    assert ferr <= (2e-5 if conv_mode == "f32" else 2e-4)
+    assert ierr <= 1e-3
+
+
+def test_feature_extractor_full_size_sample(golden_dir, conv_mode):
+    from mvs_gi_amd.configs import CONFIGS
+    z = _load(golden_dir, "extractor_full_sample")
+    imgs = synth.make_images(CONFIGS["G16V"], seed=8, batch=1)
+    assert synth.digest({"imgs": imgs}) == str(z["imgs_sha256"])
+    fe = dropin.SimpleFeatExtraction(in_size=(512, 2048), in_chs=3, chs=16, k_sz=3, layers=[5, 10])
+    fe.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_extractor_weights(8).items()}, strict=True)
+    with torch.no_grad():
+        f = fe.eval().to(DEV)(_g(imgs[0]))
+    assert tuple(f.shape) == (3, 16, 128, 512)
+    err = _rel(f[:, :, ::8, ::8].contiguous().cpu().numpy(), z["feats_8x8"])
+    print(f"extractor full size [{conv_mode}]: max-rel {err:.3e}")
+    assert err <= (2e-5 if conv_mode == "f32" else 2e-4)
+    assert abs(float(f.abs().mean()) - float(z["feats_abs_mean"])) / float(z["feats_abs_mean"]) < 1e-4

@@ -201,8 +201,51 @@ def old_class_equivalence():
     print("  old-class equivalence + pickled module fixture done;", len(buf.getvalue()), "bytes")
 
 
+def extractor_cases():
+    """SimpleFeatExtraction (reference) on seeded images: a small case with the full feature map, the
+    end-to-end imgs -> inv_dist composition through the reference's SphericalSweepStereoBase, and the
+    full 512x2048 size as a strided sample of the feature map."""
+    import importlib.util
+    from dsta_mvs.model.feature_extractor import SimpleFeatExtraction
+    spec = importlib.util.spec_from_file_location("torch_only", os.path.join(REF, "dsta_mvs/model/mvs_model/torch_only.py"))
+    torch_only = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(torch_only)
+    from mvs_gi_amd.configs import CONFIGS, DIST_8L
+    cfg = CONFIGS["G16V"].scaled(feat_hw=(16, 64), mask_hw=(64, 256), cv_hw=(8, 32), dist_cands=DIST_8L)
+    seed = 8
+    fw = synth.make_extractor_weights(seed)
+    fe = SimpleFeatExtraction(in_size=(64, 256), in_chs=3, chs=16, k_sz=3, layers=[5, 10]).eval()
+    fe.load_state_dict({k: torch.from_numpy(v) for k, v in fw.items()}, strict=True)
+    imgs = synth.make_images(cfg, seed=seed, batch=2)
+    inp = synth.make_inputs(cfg, seed=seed, batch=2)
+    w = synth.make_weights(cfg, seed=seed)
+    cvb, reg, dr = build_reference(cfg, w)
+    model = torch_only.SphericalSweepStereoBase(fe, cvb, reg, dr).eval()
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    with torch.no_grad():
+        feats = model.extract_features(torch.from_numpy(imgs))
+        inv, _ = model(torch.from_numpy(imgs), t["grids"], t["grid_masks"], t["masks"])
+    np.savez_compressed(os.path.join(OUT, "extractor_small.npz"), feats=feats.numpy(), inv_dist=inv.numpy(),
+                        imgs_sha256=np.asarray(synth.digest({"imgs": imgs})),
+                        inputs_sha256=np.asarray(synth.digest(inp)))
+    print("  extractor_small: feats", tuple(feats.shape), "std", float(feats.std()), "inv", tuple(inv.shape))
+    # full size, one frame (3 cameras): strided sample
+    cfgf = CONFIGS["G16V"]
+    fef = SimpleFeatExtraction(in_size=(512, 2048), in_chs=3, chs=16, k_sz=3, layers=[5, 10]).eval()
+    fef.load_state_dict({k: torch.from_numpy(v) for k, v in fw.items()}, strict=True)
+    imgsf = synth.make_images(cfgf, seed=seed, batch=1)
+    with torch.no_grad():
+        ff = fef(torch.from_numpy(imgsf[0]))
+    np.savez_compressed(os.path.join(OUT, "extractor_full_sample.npz"), feats_8x8=ff[:, :, ::8, ::8].numpy(),
+                        feats_abs_mean=np.asarray(float(ff.abs().mean())),
+                        imgs_sha256=np.asarray(synth.digest({"imgs": imgsf})))
+    print("  extractor_full_sample: feats", tuple(ff.shape), "abs mean", float(ff.abs().mean()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["small", "full", "edges"]
+    which = sys.argv[1:] or ["small", "full", "edges", "extractor"]
+    if "extractor" in which:
+        extractor_cases()
     if "edges" in which:
         sweep_edges()
         regress_variants()
