@@ -41,6 +41,9 @@ def parse_args(argv=None):
     ap.add_argument("--graph", action="store_true",
                     help="also time hipGraph replays of the same step (reported as graph_replay_*; the headline "
                          "value and the per-kernel events always come from the eager launches)")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="also time imgs -> inv_dist with the HIP feature extractor in front (SURVEY 8(f) rank 1); "
+                         "reported as end_to_end_*; the headline metric stays the plane-sweep hot path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl=RCCL)")
@@ -275,6 +278,29 @@ def main(argv=None):
         gel = timed_steps(gstep, sync, args.steps, args.warmup, world, backend_ready, dev)
         graph_res = {"graph_replay_frames_per_s": round(B * world * args.steps / gel, 2),
                      "graph_replay_ms_per_step": round(gel / args.steps * 1e3, 4)}
+    e2e_res = None
+    if args.end_to_end:
+        from mvs_gi_amd import dropin
+        Hi, Wi = cfg.feat_hw
+        fe = dropin.SimpleFeatExtraction(in_size=(4 * Hi, 4 * Wi), in_chs=3, chs=cfg.feat_chs, k_sz=3, layers=[5, 10])
+        fe.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_extractor_weights(0).items()}, strict=True)
+        fe = fe.eval().to(dev)
+        imgs = torch.from_numpy(rng.random((B * cfg.num_cams, 3, 4 * Hi, 4 * Wi), dtype=np.float32)).to(dev)
+
+        def estep():
+            with torch.no_grad():
+                f = fe(imgs)
+            out["inv"], out["pr"] = hp(f.reshape(B, cfg.num_cams, *f.shape[1:]))
+
+        def fstep():
+            with torch.no_grad():
+                out["f"] = fe(imgs)
+        eel = timed_steps(estep, sync, args.steps, args.warmup, world, backend_ready, dev)
+        fel = timed_steps(fstep, sync, args.steps, args.warmup, world, backend_ready, dev)
+        e2e_res = {"end_to_end_frames_per_s": round(B * world * args.steps / eel, 2),
+                   "end_to_end_ms_per_step": round(eel / args.steps * 1e3, 4),
+                   "feature_extractor_ms_per_step": round(fel / args.steps * 1e3, 4),
+                   "feature_extractor_tflops": round(B * 58.06 / (fel / args.steps) / 1e3, 2)}
     frames = B * world * args.steps
     value = frames / el
     # dominant kernel = largest total time among the conv variants
@@ -306,6 +332,8 @@ def main(argv=None):
     }
     if graph_res is not None:
         res.update(graph_res)
+    if e2e_res is not None:
+        res.update(e2e_res)
     if cpu_res is not None:
         res["cpu_baseline"] = cpu_res
     if backend_ready:

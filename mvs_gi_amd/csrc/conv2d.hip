@@ -73,6 +73,54 @@ __global__ __launch_bounds__(256) void conv2d_direct_kernel(Conv2dArgs a) {
     }
 }
 
+// RGB stem of the extractor (simple_feature_extractor.py:31-38): 5x5, stride 2, 3 -> 16 channels, NCHW
+// images in, channels-last features out.  A workgroup owns a 16x16 patch of output pixels: the
+// 35x35x3 input window and the 75x16 weights (transposed to [tap][cout]) sit in LDS, every thread
+// accumulates the 16 output channels of one pixel (1200 FMAs against 75 + 300 LDS reads).
+__global__ __launch_bounds__(256) void conv2d_stem_kernel(Conv2dArgs a) {
+    constexpr int T = 16, IT = 2 * T + 3, CI = 3, K = 5, CO = 16;
+    __shared__ float xs[CI][IT][IT + 1];
+    __shared__ __attribute__((aligned(16))) float ws[CI * K * K][CO];
+    const int tid = threadIdx.x, tx = tid % T, ty = tid / T;
+    const int ox0 = blockIdx.x * T, oy0 = blockIdx.y * T, b = blockIdx.z;
+    for (int e = tid; e < CI * K * K * CO; e += 256) {
+        const int co = e % CO, tap = e / CO;                    // tap = (ci*5 + ky)*5 + kx
+        ws[tap][co] = a.w[co * (CI * K * K) + tap];
+    }
+    const int ix0 = ox0 * 2 - 2, iy0 = oy0 * 2 - 2;
+    for (int e = tid; e < CI * IT * IT; e += 256) {
+        const int x = e % IT, y = (e / IT) % IT, ci = e / (IT * IT);
+        const int gx = ix0 + x, gy = iy0 + y;
+        xs[ci][y][x] = (gx >= 0 && gx < a.Win && gy >= 0 && gy < a.Hin)
+                           ? a.x[(((long long)b * CI + ci) * a.Hin + gy) * a.Win + gx] : 0.f;
+    }
+    __syncthreads();
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const float xv = xs[ci][2 * ty + ky][2 * tx + kx];
+                const f32x4* wv = reinterpret_cast<const f32x4*>(ws[(ci * K + ky) * K + kx]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += wv[q] * xv;
+            }
+    const int ox = ox0 + tx, oy = oy0 + ty;
+    if (ox >= a.Wo || oy >= a.Ho) return;
+    float* yp = a.y + (((long long)b * a.Ho + oy) * a.Wo + ox) * CO;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 r = acc[q] * *reinterpret_cast<const f32x4*>(a.scale + 4 * q) + *reinterpret_cast<const f32x4*>(a.shift + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : r[e] * a.neg_slope;
+        *reinterpret_cast<f32x4*>(yp + 4 * q) = r;
+    }
+}
+
 enum Variant2d { D2_DIRECT, D2_N16, D2_N32, D2_N64, D2_S2_N32, D2_S2_N64, D2_COUNT };
 const char* const kNames2d[D2_COUNT] = {
     "conv2d_direct_kernel<4>",
@@ -135,6 +183,11 @@ extern "C" int mvsgi_conv2d_f32(const float* x, const float* w_oihw, const void*
     hipStream_t st = mvsgi::as_stream(stream);
     if (v == D2_DIRECT) {
         Conv2dArgs a{x, w_oihw, scale, shift, res, y, B, Cin, Hin, Win, Cout, Ho, Wo, ksize, stride, in_nchw, neg_slope};
+        if (ksize == 5 && stride == 2 && Cin == 3 && Cout == 16 && in_nchw && !res && B < 65536) {
+            hipLaunchKernelGGL(conv2d_stem_kernel, dim3((unsigned)mvsgi::cdiv(Wo, 16), (unsigned)mvsgi::cdiv(Ho, 16), (unsigned)B),
+                               dim3(256), 0, st, a);
+            return mvsgi::check_launch("mvsgi_conv2d_f32(stem)");
+        }
         const long long total = (long long)B * Ho * Wo * mvsgi::cdiv(Cout, 4);
         hipLaunchKernelGGL((conv2d_direct_kernel<4>), dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0, st, a);
         return mvsgi::check_launch("mvsgi_conv2d_f32(direct)");
