@@ -116,7 +116,12 @@ const char* mvsgi_conv3d_variant_f32(int B, int Cin, int Din, int Hin, int Win, 
  *   x [B][Hin][Win][Cin] (or the caller's NCHW images when in_nchw != 0, direct path only),
  *   y / res [B][Ho][Wo][Cout], w_oihw [Cout][Cin][k][k], k odd <= 7, stride 1|2.
  * impl: MVSGI_CONV_BF16X3 = split-bf16 MFMA kernel (k == 3, Cin, Cout multiples of 16, w_packed from
- * mvsgi_conv2d_pack_weights_bf16x3); anything else, or AUTO/DIRECT = exact fp32 direct kernel. */
+ * mvsgi_conv2d_pack_weights_bf16x3); MVSGI_CONV_MFMA = exact fp32 MFMA kernel (k == 3, Cin % 16 == 0,
+ * Cout in {16, 32}, w_packed from mvsgi_conv2d_pack_weights_f32); anything else, or AUTO/DIRECT = exact
+ * fp32 direct kernels (incl. the LDS-tiled 5x5 stride-2 RGB stem). */
+size_t mvsgi_conv2d_packed_weight_floats(int Cout, int Cin);            /* exact-fp32 MFMA path (MVSGI_CONV_MFMA) */
+int mvsgi_conv2d_pack_weights_f32(const float* w_oihw, float* w_packed, int Cout, int Cin,
+                                  mvsgi_stream_t stream);
 size_t mvsgi_conv2d_packed_weight_bytes_bf16x3(int Cout, int Cin);
 int mvsgi_conv2d_pack_weights_bf16x3(const float* w_oihw, void* w_packed, int Cout, int Cin,
                                      mvsgi_stream_t stream);

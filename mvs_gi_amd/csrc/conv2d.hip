@@ -17,6 +17,7 @@
 namespace {
 
 #include "conv3d_bf16x3.hpp"
+#include "conv3d_f32mfma.hpp"
 
 struct Conv2dArgs {
     const float* x;
@@ -121,12 +122,14 @@ __global__ __launch_bounds__(256) void conv2d_stem_kernel(Conv2dArgs a) {
     }
 }
 
-enum Variant2d { D2_DIRECT, D2_N16, D2_N32, D2_N64, D2_S2_N32, D2_S2_N64, D2_COUNT };
+enum Variant2d { D2_DIRECT, D2_N16, D2_N32, D2_N64, D2_S2_N32, D2_S2_N64, D2_F32_N16, D2_F32_N32, D2_F32_S2, D2_COUNT };
 const char* const kNames2d[D2_COUNT] = {
     "conv2d_direct_kernel<4>",
     "conv3d_bf16x3_kernel<1, 4, 4, 1, 1, 16, 16, 1, 1>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 1, 16, 16, 1, 1>",
     "conv3d_bf16x3_kernel<2, 4, 2, 2, 1, 8, 16, 1, 1>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 2, 1>",
     "conv3d_bf16x3_kernel<2, 2, 2, 2, 1, 4, 16, 2, 1>",
+    "conv3d_mfma_kernel<1, 4, 4, 1, 1, 16, 16, 1, 1>", "conv3d_mfma_kernel<2, 4, 4, 1, 1, 16, 16, 1, 1>",
+    "conv3d_mfma_kernel<2, 1, 4, 1, 1, 4, 16, 2, 1>",
 };
 
 int select2d(int Cin, int Cout, int k, int stride, int impl, const void* w, const void* wp, int in_nchw) {
@@ -137,7 +140,12 @@ int select2d(int Cin, int Cout, int k, int stride, int impl, const void* w, cons
         if (stride == 2) return CT <= 2 ? D2_S2_N32 : D2_S2_N64;
         return CT == 1 ? D2_N16 : CT <= 3 ? D2_N32 : D2_N64;
     }
-    if (impl != MVSGI_CONV_AUTO && impl != MVSGI_CONV_DIRECT && impl != MVSGI_CONV_BF16X3) {
+    if (impl == MVSGI_CONV_MFMA && mfma_ok && (Cout == 16 || Cout == 32)) {
+        if (!wp) { mvsgi::fail("mvsgi_conv2d_f32: fp32 MFMA path needs w_packed"); return D2_COUNT; }
+        if (stride == 2) return D2_F32_S2;
+        return Cout == 16 ? D2_F32_N16 : D2_F32_N32;
+    }
+    if (impl != MVSGI_CONV_AUTO && impl != MVSGI_CONV_DIRECT && impl != MVSGI_CONV_BF16X3 && impl != MVSGI_CONV_MFMA) {
         mvsgi::fail("mvsgi_conv2d_f32: unknown impl %d", impl);
         return D2_COUNT;
     }
@@ -160,6 +168,18 @@ extern "C" int mvsgi_conv2d_pack_weights_bf16x3(const float* w_oihw, void* w_pac
     hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0,
                        mvsgi::as_stream(stream), w_oihw, reinterpret_cast<bf16x8*>(w_packed), Cout, Cin, 9);
     return mvsgi::check_launch("mvsgi_conv2d_pack_weights_bf16x3");
+}
+
+extern "C" size_t mvsgi_conv2d_packed_weight_floats(int Cout, int Cin) { return (size_t)9 * (size_t)Cout * (size_t)Cin; }
+
+extern "C" int mvsgi_conv2d_pack_weights_f32(const float* w_oihw, float* w_packed, int Cout, int Cin, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(w_oihw && w_packed, "mvsgi_conv2d_pack_weights_f32: null pointer");
+    MVSGI_REQUIRE(Cout > 0 && Cin > 0 && Cout % 16 == 0 && Cin % 16 == 0,
+                  "mvsgi_conv2d_pack_weights_f32: Cout=%d Cin=%d must be positive multiples of 16", Cout, Cin);
+    const long long total = (long long)(Cin / 16) * 9 * (Cout / 16) * 64;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0,
+                       mvsgi::as_stream(stream), w_oihw, reinterpret_cast<f32x4*>(w_packed), Cout, Cin, 9);
+    return mvsgi::check_launch("mvsgi_conv2d_pack_weights_f32");
 }
 
 extern "C" const char* mvsgi_conv2d_variant_f32(int Cin, int Cout, int ksize, int stride, int impl, int in_nchw) {
@@ -217,6 +237,9 @@ extern "C" int mvsgi_conv2d_f32(const float* x, const float* w_oihw, const void*
         case D2_N64: return launch_bf16x3<2, 4, 2, 2, 1, 8, 16, 1, 1>(a, st);
         case D2_S2_N32: return launch_bf16x3<2, 1, 4, 1, 1, 4, 16, 2, 1>(a, st);
         case D2_S2_N64: return launch_bf16x3<2, 2, 2, 2, 1, 4, 16, 2, 1>(a, st);
+        case D2_F32_N16: return launch_mfma<1, 4, 4, 1, 1, 16, 16, 1, 1>(a, st);
+        case D2_F32_N32: return launch_mfma<2, 4, 4, 1, 1, 16, 16, 1, 1>(a, st);
+        case D2_F32_S2: return launch_mfma<2, 1, 4, 1, 1, 4, 16, 2, 1>(a, st);
     }
     return mvsgi::fail("mvsgi_conv2d_f32: bad variant %d", v);
 }

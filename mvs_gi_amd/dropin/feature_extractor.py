@@ -19,7 +19,7 @@ from .common_modules import NoOp, NORM2D_TYPE, RELU_TYPE, _is_identity
 
 
 class Conv2dLaunch:
-    __slots__ = ("w", "wp_b3", "scale", "shift", "stride", "neg_slope", "k", "cin", "cout", "key")
+    __slots__ = ("w", "wp_b3", "wp_f32", "scale", "shift", "stride", "neg_slope", "k", "cin", "cout", "key")
 
     def run(self, x: Tensor, res: Optional[Tensor] = None, in_nchw: bool = False) -> Tensor:
         impl, wp = H.CONV_AUTO, None
@@ -27,6 +27,10 @@ class Conv2dLaunch:
             if self.wp_b3 is None:
                 self.wp_b3 = H.pack_conv2d_weights_bf16x3(self.w)
             impl, wp = H.CONV_BF16X3, self.wp_b3
+        elif self.k == 3 and self.cin % 16 == 0 and self.cout in (16, 32) and not in_nchw:
+            if self.wp_f32 is None:                    # exact fp32 mode: fp32 MFMA kernel
+                self.wp_f32 = H.pack_conv2d_weights_f32(self.w)
+            impl, wp = H.CONV_MFMA, self.wp_f32
         return H.conv2d(x, self.w, wp, self.scale, self.shift, res=res, stride=self.stride,
                         neg_slope=self.neg_slope, impl=impl, in_nchw=in_nchw)
 
@@ -79,7 +83,7 @@ def lower_conv2d_block(blk) -> Conv2dLaunch:
     else:
         raise NotImplementedError(f"activation {type(act).__name__} has no HIP implementation")
     L = Conv2dLaunch()
-    L.w, L.wp_b3 = w, None
+    L.w, L.wp_b3, L.wp_f32 = w, None, None
     L.scale, L.shift = scale.contiguous(), shift.contiguous()
     L.stride, L.neg_slope, L.k = int(conv.stride[0]), slope, int(k)
     L.cin, L.cout, L.key = int(w.shape[1]), int(cout), key

@@ -232,6 +232,19 @@ def pack_conv2d_weights_bf16x3(w_oihw: torch.Tensor) -> Optional[torch.Tensor]:
     return wp
 
 
+def pack_conv2d_weights_f32(w_oihw: torch.Tensor) -> Optional[torch.Tensor]:
+    """[Cout, Cin, 3, 3] -> exact-fp32 MFMA layout (Cout in {16, 32}), or None when unsupported."""
+    lib = _lib.load()
+    w = _dev(w_oihw, "conv weight")
+    Cout, Cin = w.shape[:2]
+    if tuple(w.shape[2:]) != (3, 3) or Cin % 16 or Cout not in (16, 32):
+        return None
+    wp = torch.empty(lib.mvsgi_conv2d_packed_weight_floats(Cout, Cin), device=w.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_conv2d_pack_weights_f32(w.data_ptr(), wp.data_ptr(), Cout, Cin, _stream_ptr(w)),
+               "mvsgi_conv2d_pack_weights_f32")
+    return wp
+
+
 def conv2d(x, w_oihw, w_packed, scale, shift, res=None, stride=1, neg_slope=0.01, impl=CONV_AUTO, in_nchw=False):
     """x [B, H, W, Cin] (or [B, Cin, H, W] with in_nchw) -> y [B, Ho, Wo, Cout] = act(conv(x)*scale + shift (+res))."""
     lib = _lib.load()

@@ -384,6 +384,11 @@ def test_conv2d_bf16x3_and_direct_vs_aten(shape):
     assert "bf16x3" in H.conv2d_variant(Cin, Cout, 3, stride, H.CONV_BF16X3)
     yb = H.conv2d(xg, wg, H.pack_conv2d_weights_bf16x3(wg), _g(scale), _g(shift), res=rg, stride=stride, impl=H.CONV_BF16X3)
     assert _rel(yb.permute(0, 3, 1, 2).cpu().numpy(), yref) <= 1e-4
+    wpf = H.pack_conv2d_weights_f32(wg)
+    if wpf is not None:
+        assert "conv3d_mfma_kernel" in H.conv2d_variant(Cin, Cout, 3, stride, H.CONV_MFMA)
+        ym = H.conv2d(xg, wg, wpf, _g(scale), _g(shift), res=rg, stride=stride, impl=H.CONV_MFMA)
+        assert _rel(ym.permute(0, 3, 1, 2).cpu().numpy(), yref) <= 2e-5
 
 
 def test_conv2d_stem_5x5_nchw_input():
