@@ -113,7 +113,9 @@ const char* mvsgi_conv3d_variant_f32(int B, int Cin, int Din, int Hin, int Win, 
 /* ---- K2-2D: convolution block of the feature extractor ----------
  * Replaces BaseConvBlk2d.forward (common/common_modules.py:56-70) on channels-last images:
  *   y = act( conv2d(x, w, pad k/2, stride) * scale[co] + shift[co] (+ res) )
- *   x [B][Hin][Win][Cin] (or the caller's NCHW images when in_nchw != 0, direct path only),
+ *   x [B][Hin][Win][Cin]; in_nchw == 1: the caller's fp32 NCHW images (direct path only);
+ *   in_nchw == 2: uint8 [B][Hin][Win][3] camera images, converted as `.float() / 255.0`
+ *   (api/inference_class.py:104-107) inside the 5x5 stride-2 3->16 stem kernel,
  *   y / res [B][Ho][Wo][Cout], w_oihw [Cout][Cin][k][k], k odd <= 7, stride 1|2.
  * impl: MVSGI_CONV_BF16X3 = split-bf16 MFMA kernel (k == 3, Cin, Cout multiples of 16, w_packed from
  * mvsgi_conv2d_pack_weights_bf16x3); MVSGI_CONV_MFMA = exact fp32 MFMA kernel (k == 3, Cin % 16 == 0,
@@ -148,6 +150,12 @@ int mvsgi_resize_trilinear_f32(const float* x, float* y, int B, int C,
 int mvsgi_softargmin_f32(const float* costs, const float* inv_idx, float* inv_dist,
                          float* norm_costs, int B, int D, int H, int W, int scale,
                          mvsgi_stream_t stream);
+
+/* Same with the post-processing of api/inference_class.py:111-114 folded in: inv_dist is divided by
+ * post_div (= bf) after the expectation (post_div == 1 reproduces mvsgi_softargmin_f32). */
+int mvsgi_softargmin_div_f32(const float* costs, const float* inv_idx, float* inv_dist,
+                             float* norm_costs, int B, int D, int H, int W, int scale,
+                             float post_div, mvsgi_stream_t stream);
 
 /* ---- layout helpers for the module boundary ------------------------------------------
  * [B][C][D*H*W] <-> [B][D*H*W][C]; V = D*H*W.  Used when a caller hands the regulator a

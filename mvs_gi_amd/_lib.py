@@ -43,6 +43,7 @@ SIGNATURES = {
     "mvsgi_conv2d_variant_f32": (c_char_p, [c_int] * 6),
     "mvsgi_resize_trilinear_f32": (c_int, [_P, _P] + [c_int] * 8 + [_P]),
     "mvsgi_softargmin_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
+    "mvsgi_softargmin_div_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [c_float, _P]),
     "mvsgi_ncv_to_nvc_f32": (c_int, [_P, _P, c_int, c_int, c_longlong, _P]),
     "mvsgi_nvc_to_ncv_f32": (c_int, [_P, _P, c_int, c_int, c_longlong, _P]),
 }

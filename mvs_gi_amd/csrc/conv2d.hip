@@ -78,6 +78,9 @@ __global__ __launch_bounds__(256) void conv2d_direct_kernel(Conv2dArgs a) {
 // images in, channels-last features out.  A workgroup owns a 16x16 patch of output pixels: the
 // 35x35x3 input window and the 75x16 weights (transposed to [tap][cout]) sit in LDS, every thread
 // accumulates the 16 output channels of one pixel (1200 FMAs against 75 + 300 LDS reads).
+// U8 = true: the images arrive as the camera driver delivers them, uint8 [B][H][W][3], and are
+// converted as the reference does (api/inference_class.py:104-107: .float() / 255.0) on the way into LDS.
+template <bool U8>
 __global__ __launch_bounds__(256) void conv2d_stem_kernel(Conv2dArgs a) {
     constexpr int T = 16, IT = 2 * T + 3, CI = 3, K = 5, CO = 16;
     __shared__ float xs[CI][IT][IT + 1];
@@ -92,8 +95,14 @@ __global__ __launch_bounds__(256) void conv2d_stem_kernel(Conv2dArgs a) {
     for (int e = tid; e < CI * IT * IT; e += 256) {
         const int x = e % IT, y = (e / IT) % IT, ci = e / (IT * IT);
         const int gx = ix0 + x, gy = iy0 + y;
-        xs[ci][y][x] = (gx >= 0 && gx < a.Win && gy >= 0 && gy < a.Hin)
-                           ? a.x[(((long long)b * CI + ci) * a.Hin + gy) * a.Win + gx] : 0.f;
+        float v = 0.f;
+        if (gx >= 0 && gx < a.Win && gy >= 0 && gy < a.Hin) {
+            if (U8)
+                v = (float)reinterpret_cast<const unsigned char*>(a.x)[(((long long)b * a.Hin + gy) * a.Win + gx) * CI + ci] / 255.0f;
+            else
+                v = a.x[(((long long)b * CI + ci) * a.Hin + gy) * a.Win + gx];
+        }
+        xs[ci][y][x] = v;
     }
     __syncthreads();
     f32x4 acc[4];
@@ -204,10 +213,14 @@ extern "C" int mvsgi_conv2d_f32(const float* x, const float* w_oihw, const void*
     if (v == D2_DIRECT) {
         Conv2dArgs a{x, w_oihw, scale, shift, res, y, B, Cin, Hin, Win, Cout, Ho, Wo, ksize, stride, in_nchw, neg_slope};
         if (ksize == 5 && stride == 2 && Cin == 3 && Cout == 16 && in_nchw && !res && B < 65536) {
-            hipLaunchKernelGGL(conv2d_stem_kernel, dim3((unsigned)mvsgi::cdiv(Wo, 16), (unsigned)mvsgi::cdiv(Ho, 16), (unsigned)B),
-                               dim3(256), 0, st, a);
+            const dim3 grid((unsigned)mvsgi::cdiv(Wo, 16), (unsigned)mvsgi::cdiv(Ho, 16), (unsigned)B);
+            if (in_nchw == 2)
+                hipLaunchKernelGGL(conv2d_stem_kernel<true>, grid, dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL(conv2d_stem_kernel<false>, grid, dim3(256), 0, st, a);
             return mvsgi::check_launch("mvsgi_conv2d_f32(stem)");
         }
+        MVSGI_REQUIRE(in_nchw != 2, "mvsgi_conv2d_f32: uint8 HWC input is implemented for the 5x5 stride-2 3->16 stem only");
         const long long total = (long long)B * Ho * Wo * mvsgi::cdiv(Cout, 4);
         hipLaunchKernelGGL((conv2d_direct_kernel<4>), dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0, st, a);
         return mvsgi::check_launch("mvsgi_conv2d_f32(direct)");

@@ -39,7 +39,7 @@ __device__ __forceinline__ Axis2 axis2(int dst, int in, int scale) {
 __global__ __launch_bounds__(256) void softargmin_kernel(const float* __restrict__ costs,
                                                          const float* __restrict__ inv_idx,
                                                          float* __restrict__ inv_dist, float* __restrict__ norm_costs,
-                                                         int B, int D, int H, int W, int scale) {
+                                                         int B, int D, int H, int W, int scale, float post_div) {
     // grid = (ceil(OW / 256), OH, B)
     const int OH = H * scale, OW = W * scale;
     const int ox = blockIdx.x * 256 + threadIdx.x;
@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void softargmin_kernel(const float* __restrict
         s += e;
         t = fmaf(e, inv_idx[d], t);
     }
-    inv_dist[idx] = t / s;
+    const float r = t / s;
+    inv_dist[idx] = post_div == 1.0f ? r : r / post_div;
     if (norm_costs) {
         const long long OHW = (long long)OH * OW;
         float* np = norm_costs + (long long)b * D * OHW + (long long)oy * OW + ox;
@@ -75,13 +76,22 @@ __global__ __launch_bounds__(256) void softargmin_kernel(const float* __restrict
 
 }  // namespace
 
+extern "C" int mvsgi_softargmin_div_f32(const float* costs, const float* inv_idx, float* inv_dist, float* norm_costs,
+                                        int B, int D, int H, int W, int scale, float post_div, mvsgi_stream_t stream);
+
 extern "C" int mvsgi_softargmin_f32(const float* costs, const float* inv_idx, float* inv_dist, float* norm_costs,
                                     int B, int D, int H, int W, int scale, mvsgi_stream_t stream) {
+    return mvsgi_softargmin_div_f32(costs, inv_idx, inv_dist, norm_costs, B, D, H, W, scale, 1.0f, stream);
+}
+
+extern "C" int mvsgi_softargmin_div_f32(const float* costs, const float* inv_idx, float* inv_dist, float* norm_costs,
+                                        int B, int D, int H, int W, int scale, float post_div, mvsgi_stream_t stream) {
     MVSGI_REQUIRE(costs && inv_idx && inv_dist, "mvsgi_softargmin_f32: null pointer");
+    MVSGI_REQUIRE(post_div != 0.0f, "mvsgi_softargmin_div_f32: post_div must be non-zero");
     MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_softargmin_f32: non-positive dimension");
     MVSGI_REQUIRE(scale == 1 || scale == 2, "mvsgi_softargmin_f32: scale %d not in {1, 2}", scale);
     MVSGI_REQUIRE(H * scale < 65536 && B < 65536, "mvsgi_softargmin_f32: dimensions exceed the launch geometry");
     hipLaunchKernelGGL(softargmin_kernel, dim3((unsigned)mvsgi::cdiv(W * scale, 256), (unsigned)(H * scale), (unsigned)B), dim3(256), 0,
-                       mvsgi::as_stream(stream), costs, inv_idx, inv_dist, norm_costs, B, D, H, W, scale);
+                       mvsgi::as_stream(stream), costs, inv_idx, inv_dist, norm_costs, B, D, H, W, scale, post_div);
     return mvsgi::check_launch("mvsgi_softargmin_f32");
 }

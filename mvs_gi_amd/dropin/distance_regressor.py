@@ -24,7 +24,7 @@ def regressor_forward(self, costs: Tensor):
                 f"interp_scale_factor={self.interp_scale_factor}: the HIP soft-argmin fuses x1 and x2 only")
         scale = int(self.interp_scale_factor)
     want = getattr(self, "return_norm_costs", True)
-    return H.softargmin(c, self.inv_dist_idx, scale, want)
+    return H.softargmin(c, self.inv_dist_idx, scale, want, getattr(self, "post_div", 1.0))
 
 
 class DistanceRegressorWithFixedCandidates(nn.Module):

@@ -170,8 +170,9 @@ class ResConvBlk2d(nn.Module):
 
 
 def extractor_forward(self, x: Tensor) -> Tensor:
-    """simple_feature_extractor.py:81-84.  The RGB stem reads the caller's NCHW images directly."""
-    xin = H._dev(x, "imgs")
+    """simple_feature_extractor.py:81-84.  The RGB stem reads the caller's NCHW fp32 images directly, or
+    uint8 [M, H, W, 3] camera images (converted /255 in the kernel, api/inference_class.py:104-107)."""
+    xin = x if x.dtype == torch.uint8 else H._dev(x, "imgs")
     y = lower_conv2d_block(self.first).run(xin, in_nchw=True)
     for blk in self.blks:
         if hasattr(blk, "blk1"):

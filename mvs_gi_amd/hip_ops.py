@@ -248,11 +248,17 @@ def pack_conv2d_weights_f32(w_oihw: torch.Tensor) -> Optional[torch.Tensor]:
 def conv2d(x, w_oihw, w_packed, scale, shift, res=None, stride=1, neg_slope=0.01, impl=CONV_AUTO, in_nchw=False):
     """x [B, H, W, Cin] (or [B, Cin, H, W] with in_nchw) -> y [B, Ho, Wo, Cout] = act(conv(x)*scale + shift (+res))."""
     lib = _lib.load()
-    x = _dev(x, "x")
-    if in_nchw:
-        B, Cin, Hin, Win = x.shape
-    else:
+    layout = int(bool(in_nchw))
+    if x.dtype == torch.uint8:                 # camera images [B, H, W, 3]: converted (/255) inside the stem kernel
+        x = _dev(x, "imgs", torch.uint8)
         B, Hin, Win, Cin = x.shape
+        layout = 2
+    else:
+        x = _dev(x, "x")
+        if in_nchw:
+            B, Cin, Hin, Win = x.shape
+        else:
+            B, Hin, Win, Cin = x.shape
     Cout, k = scale.numel(), int(w_oihw.shape[-1])
     pad = k // 2
     Ho, Wo = (Hin + 2 * pad - k) // stride + 1, (Win + 2 * pad - k) // stride + 1
@@ -263,7 +269,7 @@ def conv2d(x, w_oihw, w_packed, scale, shift, res=None, stride=1, neg_slope=0.01
     y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
     _lib.check(lib.mvsgi_conv2d_f32(x.data_ptr(), _ptr(w_oihw), _ptr(w_packed), scale.data_ptr(), shift.data_ptr(),
                                     _ptr(res), y.data_ptr(), B, Cin, Hin, Win, Cout, k, stride, float(neg_slope), impl,
-                                    int(bool(in_nchw)), _stream_ptr(x)), "mvsgi_conv2d_f32")
+                                    layout, _stream_ptr(x)), "mvsgi_conv2d_f32")
     return y
 
 
@@ -286,8 +292,9 @@ def resize_trilinear(x, size) -> torch.Tensor:
     return y
 
 
-def softargmin(costs_bdhw, inv_idx, scale: int, want_norm_costs: bool):
-    """costs [B, D, H, W], inv_idx [D] -> inv_dist [B, 1, sH, sW], norm_costs [B, D, sH, sW] | None."""
+def softargmin(costs_bdhw, inv_idx, scale: int, want_norm_costs: bool, post_div: float = 1.0):
+    """costs [B, D, H, W], inv_idx [D] -> inv_dist [B, 1, sH, sW] (divided by post_div), norm_costs
+    [B, D, sH, sW] | None."""
     lib = _lib.load()
     c = _dev(costs_bdhw, "costs")
     inv_idx = _dev(inv_idx.reshape(-1), "inv_dist_idx")
@@ -296,8 +303,8 @@ def softargmin(costs_bdhw, inv_idx, scale: int, want_norm_costs: bool):
         raise AssertionError(f"{D} cost planes but {inv_idx.numel()} distance candidates")
     inv = torch.empty((B, 1, H * scale, W * scale), device=c.device, dtype=torch.float32)
     pr = torch.empty((B, D, H * scale, W * scale), device=c.device, dtype=torch.float32) if want_norm_costs else None
-    _lib.check(lib.mvsgi_softargmin_f32(c.data_ptr(), inv_idx.data_ptr(), inv.data_ptr(), _ptr(pr), B, D, H, W, scale,
-                                        _stream_ptr(c)), "mvsgi_softargmin_f32")
+    _lib.check(lib.mvsgi_softargmin_div_f32(c.data_ptr(), inv_idx.data_ptr(), inv.data_ptr(), _ptr(pr), B, D, H, W,
+                                            scale, float(post_div), _stream_ptr(c)), "mvsgi_softargmin_div_f32")
     return inv, pr
 
 

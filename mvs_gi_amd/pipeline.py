@@ -86,3 +86,33 @@ class HotPath:
     def postprocess(self, inv_dist: torch.Tensor) -> np.ndarray:
         """inverse-distance index -> 1/m, on the host (api/inference_class.py:111-114)."""
         return (inv_dist / self.cfg.bf).cpu().numpy()
+
+
+class InferencePipeline:
+    """Build-owned counterpart of InferencePytorch.__call__ (api/inference_class.py:120-127): uint8
+    HWC camera images in, metric inverse distance (inv_dist / bf) as a host array out.  The uint8 ->
+    float / 255 conversion is folded into the extractor's stem kernel and the division by bf into the
+    soft-argmin kernel, so the only host traffic is the image upload and the result download."""
+
+    def __init__(self, cfg: PathConfig, weights, consts, device="cuda"):
+        self.cfg = cfg
+        self.hot = HotPath(cfg, weights, consts, device)
+        Hi, Wi = cfg.feat_hw
+        fe = dropin.SimpleFeatExtraction(in_size=(4 * Hi, 4 * Wi), in_chs=3, chs=cfg.feat_chs, k_sz=3, layers=[5, 10])
+        fe.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in weights["feature_extractor"].items()},
+                           strict=True)
+        self.feature_extractor = fe.eval().to(self.hot.device)
+        self.hot.dist_regressor.post_div = float(cfg.bf)          # inference_class.py:111-114
+        self.hot.dist_regressor.return_norm_costs = False         # discarded by inference callers
+
+    @torch.no_grad()
+    def __call__(self, input_dict) -> np.ndarray:
+        imgs = input_dict["imgs"]
+        if isinstance(imgs, list):
+            imgs = np.stack(imgs, axis=0)                          # [N, H, W, 3] uint8 (one frame)
+        t = torch.from_numpy(np.ascontiguousarray(imgs)).to(self.hot.device)
+        if t.dtype != torch.uint8:
+            raise TypeError("InferencePipeline expects uint8 HWC camera images")
+        f = self.feature_extractor(t)                              # [N, C, Hi, Wi], channels-last storage
+        inv, _ = self.hot(f.unsqueeze(0))
+        return inv.squeeze(0).squeeze(0).cpu().numpy()

@@ -438,3 +438,22 @@ def test_feature_extractor_full_size_sample(golden_dir, conv_mode):
     print(f"extractor full size [{conv_mode}]: max-rel {err:.3e}")
     assert err <= (2e-5 if conv_mode == "f32" else 2e-4)
     assert abs(float(f.abs().mean()) - float(z["feats_abs_mean"])) / float(z["feats_abs_mean"]) < 1e-4
+
+
+def test_inference_pipeline_uint8_in_metric_out(golden_dir, conv_mode):
+    """uint8 HWC camera images -> inv_dist / bf on the host, against the reference's
+    preprocess_imgs / model / postprocess_imgs chain (api/inference_class.py:97-127)."""
+    from mvs_gi_amd.configs import CONFIGS, DIST_8L
+    from mvs_gi_amd.pipeline import InferencePipeline
+    z = _load(golden_dir, "pipeline_u8")
+    cfg = CONFIGS["G16V"].scaled(feat_hw=(16, 64), mask_hw=(64, 256), cv_hw=(8, 32), dist_cands=DIST_8L)
+    seed = 8
+    w = synth.make_weights(cfg, seed=seed)
+    w["feature_extractor"] = synth.make_extractor_weights(seed)
+    inp = synth.make_inputs(cfg, seed=seed, batch=1)
+    pipe = InferencePipeline(cfg, w, inp, device=DEV)
+    out = pipe({"imgs": [im for im in z["imgs_u8"]]})
+    assert out.shape == z["inv_dist_over_bf"].shape == (16, 64)
+    err = _rel(out, z["inv_dist_over_bf"])
+    print(f"pipeline u8 [{conv_mode}]: max-rel {err:.3e}")
+    assert err <= 1e-3

@@ -229,6 +229,15 @@ def extractor_cases():
                         imgs_sha256=np.asarray(synth.digest({"imgs": imgs})),
                         inputs_sha256=np.asarray(synth.digest(inp)))
     print("  extractor_small: feats", tuple(feats.shape), "std", float(feats.std()), "inv", tuple(inv.shape))
+    # uint8 camera images through the reference's pre/post-processing (api/inference_class.py:97-114,
+    # restated here: three tensor ops) around the reference model
+    u8 = np.random.default_rng(81).integers(0, 256, (cfg.num_cams, 64, 256, 3), dtype=np.uint8)
+    with torch.no_grad():
+        t_imgs = torch.from_numpy(np.stack(list(u8), axis=0)).permute(0, 3, 1, 2).unsqueeze(0)
+        t_imgs = t_imgs.float() / 255.0
+        inv1, _ = model(t_imgs, t["grids"][:1], t["grid_masks"][:1], t["masks"][:1])
+        post = (inv1 / dr.bf).squeeze(0).squeeze(0).numpy()
+    np.savez_compressed(os.path.join(OUT, "pipeline_u8.npz"), imgs_u8=u8, inv_dist_over_bf=post)
     # full size, one frame (3 cameras): strided sample
     cfgf = CONFIGS["G16V"]
     fef = SimpleFeatExtraction(in_size=(512, 2048), in_chs=3, chs=16, k_sz=3, layers=[5, 10]).eval()
