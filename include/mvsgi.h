@@ -83,6 +83,19 @@ int mvsgi_sweep_cat_nhwc_f32(const float* feats, const float* grids, float* vol,
                              int B, int N, int C, int Hi, int Wi,
                              int D, int Ho, int Wo, mvsgi_stream_t stream);
 
+/* Rig-constant validity.  The mask half of SphericalSweepStdMasked.sweep -- (bilinear_grid_sample(
+ * masks) > 0) & grid_masks, spherical_sweep_avg.py:92-102 -- depends only on grids / grid_masks /
+ * masks, which the reference builds once per camera rig (api/inference_class.py:40-45).
+ * mvsgi_sweep_validity_u8 evaluates it once into vmask [B][D][Ho][Wo] (bit cam set = camera cam is
+ * valid; N <= 8); mvsgi_sweep_std_nhwc_valid_f32 is mvsgi_sweep_std_nhwc_f32 reading that byte
+ * instead of re-sampling the masks every frame.  Bit-identical output. */
+int mvsgi_sweep_validity_u8(const float* grids, const void* grid_masks, int grid_mask_is_f32,
+                            const float* masks, unsigned char* vmask,
+                            int B, int N, int Hm, int Wm, int D, int Ho, int Wo, mvsgi_stream_t stream);
+int mvsgi_sweep_std_nhwc_valid_f32(const float* feats, const float* grids, const unsigned char* vmask,
+                                   float* vol, int B, int N, int C, int Hi, int Wi,
+                                   int D, int Ho, int Wo, mvsgi_stream_t stream);
+
 /* ---- K2: 3x3x3 convolution block -----------------------------------------------------
  * Replaces BaseConvBlk3d.forward (common/common_modules.py:107-115):
  *   y = act( conv3d(x, w, pad=1, stride) * scale[co] + shift[co] (+ res) )

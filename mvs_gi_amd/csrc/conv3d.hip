@@ -42,55 +42,152 @@ __global__ void pack_head_weights_kernel(const float* __restrict__ w, float* __r
 #include "conv3d_bf16x3.hpp"
 
 // ----------------------------------------------------------------------------------------
-// cost head (Cout == 1, stride 1; unet_regulator.py:61-68): one thread per output voxel of a
-// 4x8x8 brick; the halo brick goes through LDS exactly as in the MFMA kernel, the 27x16 weights
-// of a slice are wave-uniform and arrive as scalar loads (SGPR operands of the FMAs).
+// cost head (Cout == 1, stride 1; unet_regulator.py:61-68), exact fp32 on the matrix cores.
+//
+// Cout == 1 has no output-channel dimension for an implicit GEMM, but the 27 TAPS can play that
+// role:  P[t][u] = sum_c w[t][c] * x[u][c]  is a [27 -> 32] x [Cin] x [voxels] product, and
+//        out[v]  = sum_t P[t][v + offset(t)]  is a sum of 27 shifted copies of it.
+// A workgroup owns an 8 x 32 (h, w) window of one frame and MARCHES along D.  Per input plane p:
+//   1. every wave multiplies its 32-voxel tiles of the 10 x 34 halo window by all taps with
+//      v_mfma_f32_32x32x2_f32 (bit-for-bit fp32 FMAs).  The weights are the A operand (8 VGPRs hold
+//      a 16-channel slice of all 27 taps), the activations go from global memory straight into
+//      the B operand (lane = (voxel, channel half): two 16-byte loads, no LDS staging, every
+//      input voxel fetched once per window);
+//   2. P[27][window] goes to LDS (36 KB), and after one barrier thread (h, w) adds its 3 x 3 x 3
+//      taps into THREE running outputs -- od = p-1 (kd = 2), p (kd = 1), p+1 (kd = 0) -- 27
+//      conflict-free ds_read_b32 per output instead of the 108 ds_read_b128 of a brick-per-
+//      workgroup FMA kernel, which was LDS-bound (and whose 432 scalar-loaded weights per slice
+//      the compiler spilled).
+// The loads of plane p+1 are in flight while plane p is reduced.
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv3d_head_kernel(ConvArgs a) {
-    constexpr int TD = 4, TH = 8, TW = 8;
-    constexpr int ITD = TD + 2, ITH = TH + 2, ITW = TW + 2;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void conv3d_head_kernel(ConvArgs a, int dchunk, int nd) {
+    constexpr int TH = 8, TW = 32, ITH = TH + 2, ITW = TW + 2, PV = ITH * ITW;
+    constexpr int NT = (PV + 31) / 32;               // 32-voxel tiles of the halo window (11)
+    constexpr int TPW = (NT + 3) / 4;                // tiles per wave (3)
+    constexpr int PSTR = 360;                        // row stride of P: rows 4 apart land 32 banks apart
+    static_assert(NT * 32 <= PSTR, "P row too short");
+    extern __shared__ __attribute__((aligned(16))) float pbuf[];     // [27][PSTR]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, h = lane >> 5;
     int t = blockIdx.x;
     const int tw_i = t % a.tiles_w;
     t /= a.tiles_w;
     const int th_i = t % a.tiles_h;
     t /= a.tiles_h;
-    const int td_i = t % a.tiles_d;
-    const int b = t / a.tiles_d;
-    const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
-    const int w_ = tid % TW, h_ = (tid / TW) % TH, d_ = tid / (TW * TH);
-    const int base = ((d_ * ITH + h_) * ITW + w_) * kVS;
-    const float* xb_base = a.x + (long long)b * a.Din * a.Hin * a.Win * a.Cin;
-    const f32x4* __restrict__ wq = a.wp;   // [27][Cin/4] float4
-    const int cq = a.Cin / 4;
-    float acc = 0.f;
-    for (int c0 = 0; c0 < a.Cin; c0 += 16) {
-        __syncthreads();
-        stage_slice<ITD, ITH, ITW>(lds, xb_base, a.Cin, c0, od0 - 1, oh0 - 1, ow0 - 1, a.Din, a.Hin, a.Win, tid);
-        __syncthreads();
+    const int dc = t % nd;
+    const int b = t / nd;
+    const int oh0 = th_i * TH, ow0 = tw_i * TW;
+    const int od_begin = dc * dchunk;
+    const int od_end = od_begin + dchunk < a.Do ? od_begin + dchunk : a.Do;
+    const int p0 = od_begin > 0 ? od_begin - 1 : 0;
+    const int p1 = od_end < a.Din - 1 ? od_end : a.Din - 1;          // inclusive
+    const int nchunks = a.Cin / 16;
+    const int U = (p1 - p0 + 1) * nchunks;
+
+    // this lane's voxel of each of the wave's tiles (the same for every plane)
+    int goff[TPW];
+    bool ok[TPW];
 #pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
-            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-            const int off = ((kd * ITH + kh) * ITW + kw) * kVS;
+    for (int k = 0; k < TPW; ++k) {
+        const int T = wave + 4 * k, v = T * 32 + n;
+        const int ih = v / ITW, iw = v - ih * ITW;
+        const int gh = oh0 - 1 + ih, gw = ow0 - 1 + iw;
+        ok[k] = T < NT && v < PV && gh >= 0 && gh < a.Hin && gw >= 0 && gw < a.Win;
+        goff[k] = ok[k] ? (gh * a.Win + gw) * a.Cin + 8 * h : 0;
+    }
+    const long long plane_stride = (long long)a.Hin * a.Win * a.Cin;
+    const float* xb = a.x + (long long)b * a.Din * plane_stride;
+    // A operand: lane (row = tap n, k-half h) holds w[tap][16*cs + 8*h + j], j = 0..7; rows >= 27 are 0
+    const float* wrow = reinterpret_cast<const float*>(a.wp) + (n < 27 ? n : 0) * a.Cin + 8 * h;
+    f32x4 wa[2], xr[TPW][2];
+#define MVSGI_HEAD_FETCH(P, CS)                                                                     \
+    {                                                                                               \
+        const float* src_ = xb + (long long)(P) * plane_stride + (CS) * 16;                         \
+        _Pragma("unroll") for (int k = 0; k < TPW; ++k) {                                           \
+            xr[k][0] = *reinterpret_cast<const f32x4*>(src_ + goff[k]);                             \
+            xr[k][1] = *reinterpret_cast<const f32x4*>(src_ + goff[k] + 4);                         \
+        }                                                                                           \
+        wa[0] = *reinterpret_cast<const f32x4*>(wrow + (CS) * 16);                                  \
+        wa[1] = *reinterpret_cast<const f32x4*>(wrow + (CS) * 16 + 4);                              \
+    }
+    MVSGI_HEAD_FETCH(p0, 0)
+
+    const int h_ = tid / TW, w_ = tid % TW;
+    const int oh = oh0 + h_, ow = ow0 + w_;
+    const bool inside = oh < a.Ho && ow < a.Wo;
+    const float sc = a.scale[0], sh = a.shift[0];
+    float run[3] = {0.f, 0.f, 0.f};                   // outputs od = p-1, p, p+1 under construction
+    f32x16 acc[TPW];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(&lds[base + off + q * 4]);
-                const f32x4 wv = wq[tap * cq + (c0 >> 2) + q];
-                acc = fmaf(xv[0], wv[0], acc);
-                acc = fmaf(xv[1], wv[1], acc);
-                acc = fmaf(xv[2], wv[2], acc);
-                acc = fmaf(xv[3], wv[3], acc);
+    for (int k = 0; k < TPW; ++k)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+
+    int p = p0, cs = 0;
+    for (int u = 0; u < U; ++u) {
+        int ncs = cs + 1, np = p;
+        if (ncs == nchunks) { ncs = 0; np = p + 1; }
+        const f32x4 w0 = n < 27 ? wa[0] : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 w1 = n < 27 ? wa[1] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) {
+            if (wave + 4 * k < NT) {                 // wave-uniform
+                const f32x4 x0 = ok[k] ? xr[k][0] : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 x1 = ok[k] ? xr[k][1] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j], x0[j], acc[k], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[j], x1[j], acc[k], 0, 0, 0);
             }
         }
+        if (u + 1 < U) MVSGI_HEAD_FETCH(np, ncs)      // in flight during the reduction below
+        if (ncs == 0) {
+            // P of plane p: lane (n, h) holds rows (i / 4) * 8 + 4 * h + i % 4 of voxel T * 32 + n
+#pragma unroll
+            for (int k = 0; k < TPW; ++k) {
+                if (wave + 4 * k < NT) {
+                    const int v = (wave + 4 * k) * 32 + n;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = (i / 4) * 8 + 4 * h + (i % 4);
+                        if (row < 27) pbuf[row * PSTR + v] = acc[k][i];
+                        acc[k][i] = 0.f;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k2 = 0; k2 < 9; ++k2) {
+                const int vv = (h_ + k2 / 3) * ITW + (w_ + k2 % 3);
+                run[0] += pbuf[(18 + k2) * PSTR + vv];      // kd = 2 -> od = p - 1
+                run[1] += pbuf[(9 + k2) * PSTR + vv];       // kd = 1 -> od = p
+                run[2] += pbuf[k2 * PSTR + vv];             // kd = 0 -> od = p + 1
+            }
+            const int od = p - 1;
+            if (od >= od_begin && inside) {
+                const long long vox = (((long long)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
+                float r = run[0] * sc + sh;
+                if (a.res) r += a.res[vox];
+                a.y[vox] = r > 0.f ? r : r * a.neg_slope;
+            }
+            run[0] = run[1];
+            run[1] = run[2];
+            run[2] = 0.f;
+            __syncthreads();                         // P consumed before the next plane overwrites it
+        }
+        p = np;
+        cs = ncs;
     }
-    const int od = od0 + d_, oh = oh0 + h_, ow = ow0 + w_;
-    if (od >= a.Do || oh >= a.Ho || ow >= a.Wo) return;
-    const long long vox = (((long long)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
-    float r = acc * a.scale[0] + a.shift[0];
-    if (a.res) r += a.res[vox];
-    r = r > 0.f ? r : r * a.neg_slope;
-    a.y[vox] = r;
+    if (p1 < od_end && inside) {                     // the last plane of the volume: no plane behind it
+        const long long vox = (((long long)b * a.Do + p1) * a.Ho + oh) * a.Wo + ow;
+        float r = run[0] * sc + sh;
+        if (a.res) r += a.res[vox];
+        a.y[vox] = r > 0.f ? r : r * a.neg_slope;
+    }
+#undef MVSGI_HEAD_FETCH
 }
 
 // ----------------------------------------------------------------------------------------
@@ -146,13 +243,21 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(ConvArgs a) {
 }
 
 int launch_head(ConvArgs a, hipStream_t st) {
-    constexpr size_t lds_bytes = (size_t)6 * 10 * 10 * kVS * sizeof(float);
-    a.tiles_d = (int)mvsgi::cdiv(a.Do, 4);
+    constexpr size_t lds_bytes = (size_t)27 * 360 * sizeof(float);      // P[27][PSTR]
     a.tiles_h = (int)mvsgi::cdiv(a.Ho, 8);
-    a.tiles_w = (int)mvsgi::cdiv(a.Wo, 8);
-    const long long nt = (long long)a.B * a.tiles_d * a.tiles_h * a.tiles_w;
+    a.tiles_w = (int)mvsgi::cdiv(a.Wo, 32);
+    // split D only when the (frame, window) count alone cannot fill the chip (each chunk re-reads
+    // its two boundary planes)
+    const long long windows = (long long)a.B * a.tiles_h * a.tiles_w;
+    long long nd = windows >= 1024 ? 1 : mvsgi::cdiv(1024, windows);
+    if (nd > mvsgi::cdiv(a.Do, 2)) nd = mvsgi::cdiv(a.Do, 2);
+    const int dchunk = (int)mvsgi::cdiv(a.Do, nd);
+    nd = mvsgi::cdiv(a.Do, dchunk);
+    a.tiles_d = (int)nd;
+    const long long nt = windows * nd;
     MVSGI_REQUIRE(nt < (1ll << 31), "conv3d: too many tiles");
-    hipLaunchKernelGGL(conv3d_head_kernel, dim3((unsigned)nt), dim3(256), lds_bytes, st, a);
+    MVSGI_REQUIRE((long long)a.Hin * a.Win * a.Cin < (1ll << 31), "conv3d(head): plane too large for 32-bit offsets");
+    hipLaunchKernelGGL(conv3d_head_kernel, dim3((unsigned)nt), dim3(256), lds_bytes, st, a, dchunk, (int)nd);
     return mvsgi::check_launch("mvsgi_conv3d_f32(head)");
 }
 

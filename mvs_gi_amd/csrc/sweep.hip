@@ -230,8 +230,19 @@ __device__ __forceinline__ float bilin_fetch_buf(__amdgpu_buffer_rsrc_t plane, c
     return ((i00 * t.w00 + i01 * t.w01) + i10 * t.w10) + i11 * t.w11;
 }
 
-// grid = (ceil(Wo / 64), Ho, B * D); block = 64 voxels x 4 lanes.  No per-lane integer division:
-// (b, d, ho) come from the block index, wo from the thread index.
+// Blocks are dealt round-robin over the 8 XCDs (private 4 MiB L2s).  The flat block id is re-mapped
+// (bijectively, cdna_hip_programming.md T1) so that every XCD owns a CONTIGUOUS run of the logical
+// order (b, ho, d, w-tile): the candidates d of one output row hit neighbouring feature rows, so
+// the blocks resident on an XCD at any time share a few feature-map rows of one frame in its L2.
+// With the plain (x, y, z) order every XCD walked every frame's whole feature map (8x the fabric
+// reads; measured FETCH_SIZE, profiles/).
+__device__ __forceinline__ int sweep_xcd_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// grid = ceil(Wo / 64) * D * Ho * B blocks (flat); block = 64 voxels x 4 lanes.  No per-lane integer
+// division: (b, ho, d, w-tile) come from the (scalar) block index, wo from the thread index.
 template <int NCAM>
 __global__ __launch_bounds__(256) void sweep_std_nhwc_kernel(const float* __restrict__ feats,
                                                              const float* __restrict__ grids,
@@ -242,11 +253,17 @@ __global__ __launch_bounds__(256) void sweep_std_nhwc_kernel(const float* __rest
 #pragma clang fp contract(off)
     static_assert(NCAM <= 4, "one camera per lane of a quad");
     const int q = threadIdx.x & 3;
-    int wo = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int WT = (s.Wo + 63) >> 6;
+    int L = sweep_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int wt = L % WT;
+    L /= WT;
+    const int d = L % s.D;
+    L /= s.D;
+    const int ho = L % s.Ho;
+    const int b = L / s.Ho;
+    int wo = wt * 64 + (threadIdx.x >> 2);
     const bool live = wo < s.Wo;
     if (!live) wo = s.Wo - 1;            // keep whole quads alive for the shuffles
-    const int ho = blockIdx.y;
-    const int b = blockIdx.z / s.D, d = blockIdx.z - b * s.D;
     const int HWm = s.Hm * s.Wm, HWi = s.Hi * s.Wi;
 
     // lane q sets up camera q
@@ -313,16 +330,185 @@ __global__ __launch_bounds__(256) void sweep_std_nhwc_kernel(const float* __rest
     }
 }
 
-// grid = (ceil(Wo / 64), Ho * N, B * D)
+// ------------------------------------------------------------------------------------------
+// Rig-constant validity.  `(bilinear_grid_sample(mask) > 0) & grid_mask` (spherical_sweep_avg.py:
+// 92-102) depends only on grids / grid_masks / masks, which are constants of the camera rig
+// (api/inference_class.py:40-45 builds them once): it is evaluated ONCE per rig into one byte per
+// voxel (bit cam = camera cam is valid) with exactly the arithmetic of the fused kernel above, and
+// the per-frame kernel below reads that byte instead of re-sampling the masks (4 scattered
+// image-resolution taps per camera and voxel, and a whole dependent memory round trip).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sweep_validity_kernel(const float* __restrict__ grids,
+                                                             const unsigned char* __restrict__ gm_u8,
+                                                             const float* __restrict__ gm_f32,
+                                                             const float* __restrict__ masks,
+                                                             unsigned char* __restrict__ vmask, SweepDims s) {
+#pragma clang fp contract(off)
+    const long long HW = (long long)s.Ho * s.Wo;
+    const long long total = (long long)s.B * s.D * HW;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const long long pix = idx % HW;
+    const int d = (int)((idx / HW) % s.D);
+    const int b = (int)(idx / (HW * s.D));
+    const long long HWm = (long long)s.Hm * s.Wm;
+    unsigned bits = 0;
+    for (int cam = 0; cam < s.N; ++cam) {
+        const long long g = ((long long)(b * s.N + cam) * s.D + d) * HW + pix;
+        const float2 gxy = *reinterpret_cast<const float2*>(grids + g * 2);
+        const Bilin mt = bilin_setup(gxy.x, gxy.y, s.Wm, s.Hm);
+        const float sm = bilin_fetch(masks + (long long)(b * s.N + cam) * HWm, mt);
+        const bool gmv = gm_f32 ? (gm_f32[g] != 0.0f) : (gm_u8[g] != 0);
+        bits |= ((sm > 0.0f) && gmv) ? (1u << cam) : 0u;
+    }
+    vmask[idx] = (unsigned char)bits;
+}
+
+template <int CAM>
+__device__ __forceinline__ int quad_bcast_i(int v) {     // lane CAM of every quad -> all four lanes (DPP, no LDS)
+    return __builtin_amdgcn_mov_dpp(v, CAM * 0x55, 0xf, 0xf, true);
+}
+template <int CAM>
+__device__ __forceinline__ float quad_bcast_f(float v) {
+    return __builtin_bit_cast(float, quad_bcast_i<CAM>(__builtin_bit_cast(int, v)));
+}
+template <int CAM>
+__device__ __forceinline__ Bilin quad_bcast(const Bilin& m) {
+    Bilin t;
+    t.o00 = quad_bcast_i<CAM>(m.o00);
+    t.o01 = quad_bcast_i<CAM>(m.o01);
+    t.o10 = quad_bcast_i<CAM>(m.o10);
+    t.o11 = quad_bcast_i<CAM>(m.o11);
+    t.w00 = quad_bcast_f<CAM>(m.w00);
+    t.w01 = quad_bcast_f<CAM>(m.w01);
+    t.w10 = quad_bcast_f<CAM>(m.w10);
+    t.w11 = quad_bcast_f<CAM>(m.w11);
+    return t;
+}
+
+// Per-frame kernel with the validity byte.  A block owns 64 consecutive wo of one (b, ho) row and
+// walks `dchunk` candidates, fetching the NEXT candidate's grid point and validity byte before the
+// 12 texel gathers of the current one, so a voxel costs one exposed memory round trip instead of
+// three.  Logical block order (b, ho, d-chunk, w-tile), XCD-contiguous (see sweep_xcd_remap).
+template <int NCAM>
+__global__ __launch_bounds__(256) void sweep_std_nhwc_v_kernel(const float* __restrict__ feats,
+                                                               const float* __restrict__ grids,
+                                                               const unsigned char* __restrict__ vmask,
+                                                               float* __restrict__ vol, SweepDims s, int dchunk,
+                                                               int nd) {
+#pragma clang fp contract(off)
+    static_assert(NCAM <= 4, "one camera per lane of a quad");
+    const int q = threadIdx.x & 3;
+    const int WT = (s.Wo + 63) >> 6;
+    int L = sweep_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int wt = L % WT;
+    L /= WT;
+    const int dc = L % nd;
+    L /= nd;
+    const int ho = L % s.Ho;
+    const int b = L / s.Ho;
+    int wo = wt * 64 + (threadIdx.x >> 2);
+    const bool live = wo < s.Wo;
+    if (!live) wo = s.Wo - 1;            // keep whole quads alive for the DPP broadcasts
+    const int d0 = dc * dchunk;
+    const int d1 = d0 + dchunk < s.D ? d0 + dchunk : s.D;
+    const int HWi = s.Hi * s.Wi;
+    const long long HW = (long long)s.Ho * s.Wo;
+
+    __amdgpu_buffer_rsrc_t img[NCAM];                  // one descriptor per camera image (wave-uniform)
+#pragma unroll
+    for (int cam = 0; cam < NCAM; ++cam)
+        img[cam] = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(feats + (long long)(b * NCAM + cam) * HWi * s.C), 0, HWi * s.C * 4, 0x00020000);
+    // lane q walks camera q's grid (lanes beyond the rig re-read the last camera; unused)
+    const int mycam = q < NCAM ? q : NCAM - 1;
+    const float2* gp = reinterpret_cast<const float2*>(grids) + ((long long)(b * NCAM + mycam) * s.D + d0) * HW +
+                       (long long)ho * s.Wo + wo;
+    const unsigned char* vp = vmask + ((long long)b * s.D + d0) * HW + (long long)ho * s.Wo + wo;
+    float* out = vol + ((((long long)b * s.D + d0) * s.Ho + ho) * s.Wo + wo) * s.C;
+    const long long vstep = HW * s.C;
+    // one candidate: grid point -> taps (lane q = camera q, broadcast through the quad) -> 4 x NCAM
+    // texel gathers -> masked variance
+    auto candidate = [&](const float2 gxy, const unsigned vm, float* __restrict__ o) {
+        const Bilin mine = bilin_setup(gxy.x, gxy.y, s.Wi, s.Hi);
+        Bilin ft[NCAM];
+        ft[0] = quad_bcast<0>(mine);
+        if (NCAM > 1) ft[NCAM > 1 ? 1 : 0] = quad_bcast<1>(mine);
+        if (NCAM > 2) ft[NCAM > 2 ? 2 : 0] = quad_bcast<2>(mine);
+        if (NCAM > 3) ft[NCAM > 3 ? 3 : 0] = quad_bcast<3>(mine);
+        float vf[NCAM];
+        float n = 0.0f;
+#pragma unroll
+        for (int cam = 0; cam < NCAM; ++cam) {
+            vf[cam] = ((vm >> cam) & 1u) ? 1.0f : 0.0f;
+            n = n + vf[cam];
+        }
+        const bool ok = n > 1.0f;
+        const float cnt = ok ? n : 1.0f;
+        const float inv = 1.0f / cnt;
+#pragma unroll 1
+        for (int c = q * 4; c < s.C; c += 16) {
+            f32x4_t sv[NCAM];
+#pragma unroll
+            for (int cam = 0; cam < NCAM; ++cam) sv[cam] = bilin_fetch4_buf(img[cam], c, s.C, ft[cam]);
+            f32x4_t r;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int cam = 0; cam < NCAM; ++cam) sum = sum + sv[cam][k] * vf[cam];
+                const float avg = div_small(sum, cnt, inv);
+                float var = 0.0f;
+#pragma unroll
+                for (int cam = 0; cam < NCAM; ++cam) {
+                    const float t = vf[cam] != 0.0f ? sv[cam][k] : avg;
+                    const float df = t - avg;
+                    var = var + df * df;
+                }
+                var = div_small(var, cnt, inv);
+                r[k] = ok ? var : 0.0f;
+            }
+            if (live) *reinterpret_cast<f32x4_t*>(o + c) = r;
+        }
+    };
+    // two candidates per trip with ping-pong registers (A, B): the loads of the next candidate are
+    // issued before the gathers of the current one and nothing waits for them until its turn
+    float2 gA = *gp;
+    unsigned vA = *vp;
+    for (int d = d0; d < d1; d += 2) {
+        const bool hasB = d + 1 < d1;
+        const long long sB = hasB ? HW : 0;
+        const float2 gB = gp[sB];
+        const unsigned vB = vp[sB];
+        candidate(gA, vA, out);
+        const long long sA = d + 2 < d1 ? 2 * HW : sB;
+        gA = gp[sA];
+        vA = vp[sA];
+        if (hasB) candidate(gB, vB, out + vstep);
+        gp += 2 * HW;
+        vp += 2 * HW;
+        out += 2 * vstep;
+    }
+}
+
+// grid = ceil(Wo / 64) * N * D * Ho * B blocks (flat), logical order (b, ho, d, cam, w-tile)
 __global__ __launch_bounds__(256) void sweep_cat_nhwc_kernel(const float* __restrict__ feats,
                                                              const float* __restrict__ grids,
                                                              float* __restrict__ vol, SweepDims s) {
 #pragma clang fp contract(off)
     const int q = threadIdx.x & 3;
-    const int wo = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int WT = (s.Wo + 63) >> 6;
+    int L = sweep_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int wt = L % WT;
+    L /= WT;
+    const int cam = L % s.N;
+    L /= s.N;
+    const int d = L % s.D;
+    L /= s.D;
+    const int ho = L % s.Ho;
+    const int b = L / s.Ho;
+    const int wo = wt * 64 + (threadIdx.x >> 2);
     if (wo >= s.Wo) return;
-    const int ho = blockIdx.y / s.N, cam = blockIdx.y - ho * s.N;
-    const int b = blockIdx.z / s.D, d = blockIdx.z - b * s.D;
     const long long grow = (((long long)(b * s.N + cam) * s.D + d) * s.Ho + ho) * s.Wo;
     const float2 gxy = *reinterpret_cast<const float2*>(grids + (grow + wo) * 2);
     const Bilin ft = bilin_setup(gxy.x, gxy.y, s.Wi, s.Hi);
@@ -406,9 +592,10 @@ extern "C" int mvsgi_sweep_std_nhwc_f32(const float* feats, const float* grids, 
     MVSGI_REQUIRE(feats && grids && grid_masks && masks && vol, "mvsgi_sweep_std_nhwc_f32: null pointer");
     MVSGI_REQUIRE(N >= 1 && N <= 4, "mvsgi_sweep_std_nhwc_f32: num_cams %d not in [1, 4]", N);
     MVSGI_REQUIRE(C % 4 == 0, "mvsgi_sweep_std_nhwc_f32: C=%d must be a multiple of 4", C);
-    MVSGI_REQUIRE((long long)Hi * Wi * C < (1ll << 31) && Ho < 65536 && (long long)B * D < 65536,
+    const long long nblk = mvsgi::cdiv(Wo, 64) * Ho * D * B;
+    MVSGI_REQUIRE((long long)Hi * Wi * C < (1ll << 31) && nblk < (1ll << 31),
                   "mvsgi_sweep_std_nhwc_f32: dimensions exceed the launch geometry");
-    const dim3 grid((unsigned)mvsgi::cdiv(Wo, 64), (unsigned)Ho, (unsigned)(B * D)), block(256);
+    const dim3 grid((unsigned)nblk), block(256);
     const unsigned char* g8 = grid_mask_is_f32 ? nullptr : static_cast<const unsigned char*>(grid_masks);
     const float* g32 = grid_mask_is_f32 ? static_cast<const float*>(grid_masks) : nullptr;
     hipStream_t st = mvsgi::as_stream(stream);
@@ -427,9 +614,59 @@ extern "C" int mvsgi_sweep_cat_nhwc_f32(const float* feats, const float* grids, 
     if (check_dims(s, "mvsgi_sweep_cat_nhwc_f32")) return 1;
     MVSGI_REQUIRE(feats && grids && vol, "mvsgi_sweep_cat_nhwc_f32: null pointer");
     MVSGI_REQUIRE(C % 4 == 0, "mvsgi_sweep_cat_nhwc_f32: C=%d must be a multiple of 4", C);
-    MVSGI_REQUIRE((long long)Hi * Wi * C < (1ll << 31) && (long long)Ho * N < 65536 && (long long)B * D < 65536,
+    const long long nblk = mvsgi::cdiv(Wo, 64) * N * Ho * D * B;
+    MVSGI_REQUIRE((long long)Hi * Wi * C < (1ll << 31) && nblk < (1ll << 31),
                   "mvsgi_sweep_cat_nhwc_f32: dimensions exceed the launch geometry");
-    hipLaunchKernelGGL(sweep_cat_nhwc_kernel, dim3((unsigned)mvsgi::cdiv(Wo, 64), (unsigned)(Ho * N), (unsigned)(B * D)),
-                       dim3(256), 0, mvsgi::as_stream(stream), feats, grids, vol, s);
+    hipLaunchKernelGGL(sweep_cat_nhwc_kernel, dim3((unsigned)nblk), dim3(256), 0, mvsgi::as_stream(stream), feats,
+                       grids, vol, s);
     return mvsgi::check_launch("mvsgi_sweep_cat_nhwc_f32");
+}
+
+// Rig-constant validity byte (bit cam) per voxel [B][D][Ho][Wo]; N <= 8.
+extern "C" int mvsgi_sweep_validity_u8(const float* grids, const void* grid_masks, int grid_mask_is_f32,
+                                       const float* masks, unsigned char* vmask, int B, int N, int Hm, int Wm, int D,
+                                       int Ho, int Wo, mvsgi_stream_t stream) {
+    SweepDims s{B, N, 1, 1, 1, Hm, Wm, D, Ho, Wo};
+    if (check_dims(s, "mvsgi_sweep_validity_u8")) return 1;
+    MVSGI_REQUIRE(Hm > 0 && Wm > 0, "mvsgi_sweep_validity_u8: non-positive mask size");
+    MVSGI_REQUIRE(grids && grid_masks && masks && vmask, "mvsgi_sweep_validity_u8: null pointer");
+    MVSGI_REQUIRE(N >= 1 && N <= 8, "mvsgi_sweep_validity_u8: num_cams %d not in [1, 8]", N);
+    const long long total = (long long)B * D * Ho * Wo;
+    MVSGI_REQUIRE(mvsgi::cdiv(total, 256) < (1ll << 31), "mvsgi_sweep_validity_u8: too many voxels");
+    const unsigned char* g8 = grid_mask_is_f32 ? nullptr : static_cast<const unsigned char*>(grid_masks);
+    const float* g32 = grid_mask_is_f32 ? static_cast<const float*>(grid_masks) : nullptr;
+    hipLaunchKernelGGL(sweep_validity_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0,
+                       mvsgi::as_stream(stream), grids, g8, g32, masks, vmask, s);
+    return mvsgi::check_launch("mvsgi_sweep_validity_u8");
+}
+
+// SphericalSweepStdMasked.sweep with the validity byte of mvsgi_sweep_validity_u8 in place of
+// grid_masks / masks: feats [B][N][Hi][Wi][C] -> vol [B][D][Ho][Wo][C]; identical output.
+extern "C" int mvsgi_sweep_std_nhwc_valid_f32(const float* feats, const float* grids, const unsigned char* vmask,
+                                              float* vol, int B, int N, int C, int Hi, int Wi, int D, int Ho, int Wo,
+                                              mvsgi_stream_t stream) {
+    SweepDims s{B, N, C, Hi, Wi, 1, 1, D, Ho, Wo};
+    if (check_dims(s, "mvsgi_sweep_std_nhwc_valid_f32")) return 1;
+    MVSGI_REQUIRE(feats && grids && vmask && vol, "mvsgi_sweep_std_nhwc_valid_f32: null pointer");
+    MVSGI_REQUIRE(N >= 1 && N <= 4, "mvsgi_sweep_std_nhwc_valid_f32: num_cams %d not in [1, 4]", N);
+    MVSGI_REQUIRE(C % 4 == 0, "mvsgi_sweep_std_nhwc_valid_f32: C=%d must be a multiple of 4", C);
+    // candidates per block: as many as keeps >= ~8k blocks in the launch (latency hiding across d
+    // needs a few; filling 256 CUs x 4 resident blocks needs the rest)
+    const long long rows = mvsgi::cdiv(Wo, 64) * Ho * B;
+    long long nd = rows >= 8192 ? 1 : mvsgi::cdiv(8192, rows);
+    if (nd > D) nd = D;
+    const int dchunk = (int)mvsgi::cdiv(D, nd);
+    nd = mvsgi::cdiv(D, dchunk);
+    const long long nblk = rows * nd;
+    MVSGI_REQUIRE((long long)Hi * Wi * C < (1ll << 31) && nblk < (1ll << 31),
+                  "mvsgi_sweep_std_nhwc_valid_f32: dimensions exceed the launch geometry");
+    const dim3 grid((unsigned)nblk), block(256);
+    hipStream_t st = mvsgi::as_stream(stream);
+    switch (N) {
+        case 1: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd); break;
+        case 2: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<2>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd); break;
+        case 3: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<3>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd); break;
+        case 4: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<4>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd); break;
+    }
+    return mvsgi::check_launch("mvsgi_sweep_std_nhwc_valid_f32");
 }

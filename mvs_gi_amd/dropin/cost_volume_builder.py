@@ -12,12 +12,21 @@ from __future__ import annotations
 
 from torch import nn, Tensor
 
+import os
+import weakref
+
 from .. import hip_ops as H
 from . import common_modules as cm
 from .common_modules import NORM3D_TYPE, RELU_TYPE
 
 
+_RIG_VALIDITY = weakref.WeakKeyDictionary()      # module -> (key, vmask)
+_RIG_CACHE_ENV = os.environ.get("MVSGI_RIG_CACHE", "1") != "0"
+
+
 class _SweepBase(nn.Module):
+    cache_rig_constants = True       # class attribute: unpickled reference modules get it too
+
     def __init__(self, num_cams: int, feat_chs: int, post_k_sz: int, norm_type: str = "batch",
                  relu_type: str = "leaky"):
         super().__init__()
@@ -30,8 +39,27 @@ class _SweepBase(nn.Module):
                                          activation=self.relu_type(), norm_layer=self.norm_type(feat_chs))
 
 
-def std_sweep_ndhwc(feats, grids, grid_masks, masks) -> Tensor:
-    return H.sweep_std(feats, grids, grid_masks, masks)
+def _rig_key(*tensors):
+    return tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device) for t in tensors)
+
+
+def std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=None) -> Tensor:
+    """Masked-variance sweep.  grids / grid_masks / masks are constants of the camera rig (the
+    reference builds them once, api/inference_class.py:40-45), so the mask half of the sweep
+    (spherical_sweep_avg.py:92-102) is evaluated once per rig and cached on `owner`, keyed on the
+    three tensors' storage pointer, in-place version counter, shape and dtype: a new or modified
+    tensor recomputes it.  `owner.cache_rig_constants = False` (or MVSGI_RIG_CACHE=0) re-samples
+    the masks every call."""
+    use_cache = owner is not None and getattr(owner, "cache_rig_constants", True) and _RIG_CACHE_ENV \
+        and H.nhwc_sweep_ok(feats) and grids.is_cuda
+    if not use_cache:
+        return H.sweep_std(feats, grids, grid_masks, masks)
+    key = _rig_key(grids, grid_masks, masks)
+    cached = _RIG_VALIDITY.get(owner)
+    if cached is None or cached[0] != key:
+        cached = (key, H.sweep_validity(grids, grid_masks, masks))
+        _RIG_VALIDITY[owner] = cached            # weak: dies with the module, never pickled with it
+    return H.sweep_std_valid(feats, grids, cached[1])
 
 
 def cat_sweep_ndhwc(feats, grids) -> Tensor:
@@ -39,7 +67,7 @@ def cat_sweep_ndhwc(feats, grids) -> Tensor:
 
 
 def std_forward(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor) -> Tensor:
-    vol_raw = std_sweep_ndhwc(feats, grids, grid_masks, masks)
+    vol_raw = std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=self)
     return cm._to_ncdhw_view(cm.lower_conv_block(self.post_vol).run(vol_raw))
 
 
@@ -52,7 +80,7 @@ def cat_forward(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: T
 class SphericalSweepStdMasked(_SweepBase):
     def sweep(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor) -> Tensor:
         """vol_raw [B, C, D, Ho, Wo] (spherical_sweep_avg.py:38-136)."""
-        return cm._to_ncdhw_view(std_sweep_ndhwc(feats, grids, grid_masks, masks))
+        return cm._to_ncdhw_view(std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=self))
 
     forward = std_forward
 

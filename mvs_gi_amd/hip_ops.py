@@ -71,12 +71,58 @@ def _feats_nhwc(feats):
     return y
 
 
+def nhwc_sweep_ok(feats) -> bool:
+    return feats.dim() == 5 and feats.shape[2] % 4 == 0 and feats.shape[1] <= 4
+
+
+def sweep_validity(grids, grid_masks, masks) -> torch.Tensor:
+    """Rig-constant validity byte per voxel, [B, D, Ho, Wo] uint8 (bit cam = camera cam valid):
+    (bilinear_grid_sample(masks) > 0) & grid_masks of spherical_sweep_avg.py:92-102."""
+    lib = _lib.load()
+    grids = _dev(grids, "grids")
+    masks = _dev(masks, "masks")
+    gm, gm_f32 = _gm_arg(grid_masks)
+    B, N, D, Ho, Wo, two = grids.shape
+    if two != 2 or N > 8:
+        raise AssertionError(f"grids must be [B, N<=8, D, Ho, Wo, 2], got {tuple(grids.shape)}")
+    if tuple(gm.shape[:5]) != (B, N, D, Ho, Wo) or gm.numel() != B * N * D * Ho * Wo:
+        raise AssertionError(f"grid_masks {tuple(gm.shape)} do not match grids {tuple(grids.shape)}")
+    if masks.shape[0] != B or masks.shape[1] != N or masks.numel() != B * N * masks.shape[-2] * masks.shape[-1]:
+        raise AssertionError(f"masks {tuple(masks.shape)} do not match grids {tuple(grids.shape)}")
+    Hm, Wm = masks.shape[-2:]
+    vmask = torch.empty((B, D, Ho, Wo), device=grids.device, dtype=torch.uint8)
+    _lib.check(lib.mvsgi_sweep_validity_u8(grids.data_ptr(), gm.data_ptr(), gm_f32, masks.data_ptr(), vmask.data_ptr(),
+                                           B, N, Hm, Wm, D, Ho, Wo, _stream_ptr(grids)), "mvsgi_sweep_validity_u8")
+    return vmask
+
+
+def sweep_std_valid(feats, grids, vmask) -> torch.Tensor:
+    """sweep_std with the cached validity byte (channels-last kernel only) -> vol_raw [B, D, Ho, Wo, C]."""
+    lib = _lib.load()
+    if not nhwc_sweep_ok(feats):
+        raise AssertionError(f"sweep_std_valid needs C % 4 == 0 and N <= 4, got feats {tuple(feats.shape)}")
+    B, N, C, Hi, Wi = feats.shape
+    f = _feats_nhwc(feats)
+    grids = _dev(grids, "grids")
+    vmask = _dev(vmask, "vmask", torch.uint8)
+    Bg, Ng, D, Ho, Wo, two = grids.shape
+    if (Bg, Ng, two) != (B, N, 2):
+        raise AssertionError(f"grids {tuple(grids.shape)} do not match feats {tuple(feats.shape)}")
+    if tuple(vmask.shape) != (B, D, Ho, Wo):
+        raise AssertionError(f"vmask {tuple(vmask.shape)} does not match grids {tuple(grids.shape)}")
+    vol = torch.empty((B, D, Ho, Wo, C), device=f.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_sweep_std_nhwc_valid_f32(f.data_ptr(), grids.data_ptr(), vmask.data_ptr(), vol.data_ptr(),
+                                                  B, N, C, Hi, Wi, D, Ho, Wo, _stream_ptr(f)),
+               "mvsgi_sweep_std_nhwc_valid_f32")
+    return vol
+
+
 def sweep_std(feats, grids, grid_masks, masks, layout: str = "auto") -> torch.Tensor:
     """-> vol_raw [B, D, Ho, Wo, C] (masked variance over cameras).  layout: 'auto' uses the
     channels-last kernel when C % 4 == 0 and N <= 4 (transposing NCHW feats once), 'nchw'
     forces the plane-gather kernel."""
     lib = _lib.load()
-    if layout == "auto" and feats.dim() == 5 and feats.shape[2] % 4 == 0 and feats.shape[1] <= 4:
+    if layout == "auto" and nhwc_sweep_ok(feats):
         return _sweep_std_nhwc(feats, grids, grid_masks, masks)
     feats = _dev(feats, "feats")
     grids = _dev(grids, "grids")

@@ -54,6 +54,9 @@ def test_sweep_edges_bit_exact(golden_dir):
     for gmask in (gm, gm.float()):
         v8 = _ncdhw(H.sweep_std(f8, g, gmask, m))
         assert np.array_equal(v8[:, :5], z["vol_raw_std_bool"]) and not v8[:, 5:].any()
+        # rig-constant validity byte + the candidate-walking kernel: same bits
+        v8c = _ncdhw(H.sweep_std_valid(f8, g, H.sweep_validity(g, gmask, m)))
+        assert np.array_equal(v8c, v8)
     c8 = _ncdhw(H.sweep_cat(f8, g)).reshape(2, 3, 8, *z["vol_raw_cat"].shape[2:])
     assert np.array_equal(c8[:, :, :5].reshape(z["vol_raw_cat"].shape), z["vol_raw_cat"])
 
@@ -74,6 +77,31 @@ def test_sweep_seeded_bit_exact(golden_dir, name):
         else:
             v = H.sweep_cat(ft, _g(inp["grids"]), layout=layout)
         assert np.array_equal(_ncdhw(v), z["vol_raw"]), layout
+    if cfg.builder == "std":
+        vm = H.sweep_validity(_g(inp["grids"]), _g(inp["grid_masks"]), _g(inp["masks"]))
+        assert vm.dtype == torch.uint8 and int(vm.max()) < (1 << cfg.num_cams)
+        for ft in (feats, feats_cl):
+            assert np.array_equal(_ncdhw(H.sweep_std_valid(ft, _g(inp["grids"]), vm)), z["vol_raw"])
+
+
+def test_rig_constant_cache_follows_the_tensors():
+    """The drop-in caches the validity byte per (grids, grid_masks, masks) identity + version: an
+    in-place edit or a different tensor must be picked up, cache off must give the same volume."""
+    cfg = SMALL_CASES["std_d8"]["cfg"]
+    inp = synth.make_inputs(cfg, seed=5, batch=2)
+    w = synth.make_weights(cfg, seed=5)
+    cvb, _, _ = build_modules(cfg, w, DEV)
+    f, g, gm, m = (_g(inp[k]) for k in ("feats", "grids", "grid_masks", "masks"))
+    with torch.no_grad():
+        v_cached = cvb.sweep(f, g, gm, m).clone()
+        assert np.array_equal(cvb.sweep(f, g, gm, m).cpu().numpy(), v_cached.cpu().numpy())     # cache hit
+        cvb.cache_rig_constants = False
+        assert np.array_equal(cvb.sweep(f, g, gm, m).cpu().numpy(), v_cached.cpu().numpy())
+        cvb.cache_rig_constants = True
+        m.zero_()                                             # in-place edit: every camera masked out
+        assert not cvb.sweep(f, g, gm, m).any()
+        m2 = _g(inp["masks"])                                 # a different tensor
+        assert np.array_equal(cvb.sweep(f, g, gm, m2).cpu().numpy(), v_cached.cpu().numpy())
 
 
 # ------------------------------------------------------------------------------ K2 conv
@@ -148,6 +176,19 @@ def test_conv3d_bf16x3_vs_oracle(shape):
     y = H.conv3d(xg, wg, wp, _g(scale), _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3)
     err = _rel(_ncdhw(y), yref)
     assert err <= 1e-4, err
+
+
+def test_cost_head_whole_depth_march_and_epilogue():
+    """>= 1024 (frame, window) pairs: every workgroup marches the whole depth (no D split);
+    also the residual / LeakyReLU epilogue and ragged H, W."""
+    rng = np.random.default_rng(8)
+    for (B, dims, res, slope) in ((4, (3, 128, 512), False, 1.0), (3, (5, 125, 470), True, 0.01)):
+        x, w, scale, shift, r, yref = _conv_case(rng, B, 16, 1, *dims, 1, res, slope)
+        xg = _g(x).permute(0, 2, 3, 4, 1).contiguous()
+        rg = _g(r).permute(0, 2, 3, 4, 1).contiguous() if res else None
+        y = H.conv3d(xg, _g(w), H.pack_conv_weights(_g(w)), _g(scale), _g(shift), res=rg, neg_slope=slope)
+        assert "head" in H.conv3d_variant(B, 16, *dims, 1)
+        assert _rel(_ncdhw(y), yref) <= 2e-5
 
 
 def test_conv3d_direct_odd_channels_and_cost_head():
