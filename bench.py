@@ -35,7 +35,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="G16V")
-    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
     ap.add_argument("--mode", default="bf16x3", choices=["bf16x3", "f32"],
                     help="conv arithmetic: split-bf16 MFMA (3 bf16 MFMAs per product, fp32 accumulate) or exact fp32 MFMA")
     ap.add_argument("--graph", action="store_true",
@@ -103,6 +103,7 @@ class ConvProbe:
         import torch
         self.H, self.torch = H, torch
         self.orig = H.conv3d
+        self.orig_up2 = H.conv3d_up2
         self.records = []
         self.enabled = False
 
@@ -122,11 +123,26 @@ class ConvProbe:
             self.records.append((H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, impl), 2.0 * 27 * Cin * Cout * vox, s, e))
             return y
 
+        def probed_up2(x, w_packed_b3, scale, shift, res=None, neg_slope=0.01, out=None):
+            if not self.enabled:
+                return self.orig_up2(x, w_packed_b3, scale, shift, res, neg_slope, out)
+            B, Dl, Hl, Wl, Cin = x.shape
+            Cout = scale.numel()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = self.orig_up2(x, w_packed_b3, scale, shift, res, neg_slope, out)
+            e.record()
+            vox = y.numel() // Cout
+            self.records.append((H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout), 2.0 * 27 * Cin * Cout * vox, s, e))
+            return y
+
         H.conv3d = probed
+        H.conv3d_up2 = probed_up2
         return self
 
     def __exit__(self, *a):
         self.H.conv3d = self.orig
+        self.H.conv3d_up2 = self.orig_up2
 
     def summary(self):
         agg = {}

@@ -123,6 +123,17 @@ int mvsgi_conv3d_f32(const float* x, const float* w_oidhw, const float* w_packed
 const char* mvsgi_conv3d_variant_f32(int B, int Cin, int Din, int Hin, int Win, int Cout,
                                      int stride, int impl);
 
+/* ResizeConv3d.forward (common/common_modules.py:332-355) in ONE launch: the trilinear x2 upsample
+ * (F.interpolate, align_corners=False) of x [B][Dl][Hl][Wl][Cin] is evaluated inside the convolution's
+ * staging path, so neither the resize kernel nor the upsampled tensor exist:
+ *   y [B][2Dl][2Hl][2Wl][Cout] = act( conv3d(upsample2(x), w, pad=1) * scale + shift (+ res) )
+ * Split-bf16 MFMA arithmetic; w_packed from mvsgi_conv3d_pack_weights_bf16x3; Cin, Cout % 16 == 0.
+ * (Odd target sizes -- the second re-interpolation of :343-350 -- use mvsgi_resize_trilinear_f32 + mvsgi_conv3d_f32.) */
+int mvsgi_conv3d_up2_f32(const float* x, const void* w_packed, const float* scale, const float* shift,
+                         const float* res, float* y, int B, int Cin, int Dl, int Hl, int Wl, int Cout,
+                         float neg_slope, mvsgi_stream_t stream);
+const char* mvsgi_conv3d_up2_variant_f32(int B, int Cin, int Dl, int Hl, int Wl, int Cout);
+
 /* ---- K2-2D: convolution block of the feature extractor ----------
  * Replaces BaseConvBlk2d.forward (common/common_modules.py:56-70) on channels-last images:
  *   y = act( conv2d(x, w, pad k/2, stride) * scale[co] + shift[co] (+ res) )

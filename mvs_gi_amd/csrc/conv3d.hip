@@ -280,6 +280,8 @@ enum Variant {
     V_S1_N16_B256, V_S1_N32_B256, V_S1_N32_B64, V_S1_N64_B128, V_S1_N64_B64, V_S2_N32_B64, V_S2_N64_B64,
     // split-bf16 kernel: 16-wide bricks (conflict-free LDS reads); N = couts per workgroup
     B3_N16, B3_N32, B3_N48, B3_N64, B3_N96, B3_N32_S, B3_N64_S, B3_S2_N32, B3_S2_N64,
+    // split-bf16 kernel with the trilinear x2 upsample fused into its producers (even bricks only)
+    B3U_N16, B3U_N32, B3U_N32_M, B3U_N48, B3U_N64, B3U_N96,
     V_COUNT
 };
 const char* const kVariantNames[V_COUNT] = {
@@ -293,7 +295,27 @@ const char* const kVariantNames[V_COUNT] = {
     "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1>",
     "conv3d_bf16x3_kernel<2, 2, 2, 2, 1, 4, 16, 1>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 2, 4, 8, 2>",
     "conv3d_bf16x3_kernel<2, 2, 2, 2, 2, 4, 8, 2>",
+    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, true>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1, 3, true>",
+    "conv3d_bf16x3_kernel<2, 2, 4, 1, 2, 4, 16, 1, 3, true>", "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1, 3, true>",
+    "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, true>", "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, true>",
 };
+
+// variant of the fused upsample + conv (a holds the UPSAMPLED input size); V_COUNT when unsupported
+int select_variant_up2(const ConvArgs& a) {
+    if (a.Cin % 16 || a.Cout % 16) {
+        mvsgi::fail("mvsgi_conv3d_up2_f32: Cin, Cout must be multiples of 16 (got %d, %d)", a.Cin, a.Cout);
+        return V_COUNT;
+    }
+    if (!a.wp) { mvsgi::fail("mvsgi_conv3d_up2_f32: needs w_packed (bf16x3 layout)"); return V_COUNT; }
+    const int CT = a.Cout / 16;
+    const long long big = (long long)a.B * mvsgi::cdiv(a.Do, 4) * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
+    const long long mid = (long long)a.B * mvsgi::cdiv(a.Do, 2) * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
+    if (CT == 1) return B3U_N16;
+    if (CT == 2) return big >= 384 ? B3U_N32 : B3U_N32_M;
+    if (CT == 3) return B3U_N48;
+    if (CT % 6 == 0 && mid * (CT / 6) >= 384) return B3U_N96;
+    return B3U_N64;
+}
 
 // returns V_COUNT when the request cannot be served (error text already set)
 int select_variant(const ConvArgs& a, int impl) {
@@ -357,6 +379,12 @@ int launch_variant(int v, const ConvArgs& a, hipStream_t st) {
         case B3_N64_S: return launch_bf16x3<2, 2, 2, 2, 1, 4, 16, 1>(a, st);
         case B3_S2_N32: return launch_bf16x3<2, 1, 4, 1, 2, 4, 8, 2>(a, st);
         case B3_S2_N64: return launch_bf16x3<2, 2, 2, 2, 2, 4, 8, 2>(a, st);
+        case B3U_N16: return launch_bf16x3<1, 4, 4, 1, 4, 4, 16, 1, 3, true>(a, st);
+        case B3U_N32: return launch_bf16x3<2, 4, 4, 1, 4, 4, 16, 1, 3, true>(a, st);
+        case B3U_N32_M: return launch_bf16x3<2, 2, 4, 1, 2, 4, 16, 1, 3, true>(a, st);
+        case B3U_N48: return launch_bf16x3<3, 4, 4, 1, 4, 4, 16, 1, 3, true>(a, st);
+        case B3U_N64: return launch_bf16x3<2, 4, 2, 2, 2, 4, 16, 1, 3, true>(a, st);
+        case B3U_N96: return launch_bf16x3<3, 4, 2, 2, 2, 4, 16, 1, 3, true>(a, st);
     }
     return mvsgi::fail("mvsgi_conv3d_f32: bad variant %d", v);
 }
@@ -445,5 +473,33 @@ extern "C" const char* mvsgi_conv3d_variant_f32(int B, int Cin, int Din, int Hin
                   1.f))
         return nullptr;
     const int v = select_variant(a, impl);
+    return v == V_COUNT ? nullptr : kVariantNames[v];
+}
+
+// ResizeConv3d (common_modules.py:332-355) in one launch: trilinear x2 upsample (align_corners=False) of
+// x [B][Dl][Hl][Wl][Cin] fused into the producers of the split-bf16 convolution at (2Dl, 2Hl, 2Wl);
+// y / res [B][2Dl][2Hl][2Wl][Cout].  w_packed is the bf16x3 layout.
+extern "C" int mvsgi_conv3d_up2_f32(const float* x, const void* w_packed, const float* scale, const float* shift,
+                                    const float* res, float* y, int B, int Cin, int Dl, int Hl, int Wl, int Cout,
+                                    float neg_slope, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(x && y && scale && shift && w_packed, "mvsgi_conv3d_up2_f32: null pointer");
+    MVSGI_REQUIRE(Dl > 0 && Hl > 0 && Wl > 0 && Dl < (1 << 20) && Hl < (1 << 20) && Wl < (1 << 20),
+                  "mvsgi_conv3d_up2_f32: bad dims");
+    ConvArgs a{};
+    if (fill_args(a, x, nullptr, static_cast<const float*>(w_packed), scale, shift, res, y, B, Cin, 2 * Dl, 2 * Hl,
+                  2 * Wl, Cout, 1, neg_slope))
+        return 1;
+    const int v = select_variant_up2(a);
+    if (v == V_COUNT) return 1;
+    return launch_variant(v, a, mvsgi::as_stream(stream));
+}
+
+extern "C" const char* mvsgi_conv3d_up2_variant_f32(int B, int Cin, int Dl, int Hl, int Wl, int Cout) {
+    ConvArgs a{};
+    static const float dummy = 0.f;
+    if (fill_args(a, &dummy, nullptr, &dummy, &dummy, &dummy, nullptr, nullptr, B, Cin, 2 * Dl, 2 * Hl, 2 * Wl, Cout, 1,
+                  1.f))
+        return nullptr;
+    const int v = select_variant_up2(a);
     return v == V_COUNT ? nullptr : kVariantNames[v];
 }

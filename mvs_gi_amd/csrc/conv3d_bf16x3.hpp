@@ -76,8 +76,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 
 // KD = 3: 3x3x3 convolution of a volume; KD = 1: 3x3 convolution of images (a volume with D planes
 // that do not see each other: the feature extractor's conv2d on [B*N] channels-last images)
-template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3>
-__global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
+//
+// UPS = true fuses ResizeConv3d's trilinear x2 upsample (common_modules.py:332-341) into the producers: a.x is
+// the LOW-resolution tensor [B][Din/2][Hin/2][Win/2][Cin] and (Din, Hin, Win) the upsampled size.  A producer
+// item is one 2x2x2 cell of low-resolution voxels (8 loads, clamped = ATen's edge rule) from which the 8
+// upsampled voxels strictly inside it are blended separably (weights 0.75 / 0.25), masked to zero outside the
+// volume (the convolution's padding), split and written to the LDS image: the same one load per staged voxel
+// as the plain producer, but 1/8 of the bytes, and neither the resize kernel nor the upsampled tensor exist.
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false>
+__global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {      // 2 waves per SIMD: 256 registers
+    static_assert(!UPS || (S == 1 && KD == 3 && TD % 2 == 0 && TH % 2 == 0 && TW % 2 == 0),
+                  "fused upsample: stride 1, even bricks (halo bricks are whole 2x2x2 cells)");
     static_assert(WM * WN == 4, "4 consumer waves per workgroup");
     static_assert(WM * MW * 16 == TD * TH * TW, "brick must be covered by the voxel tiles");
     static_assert(KD == 3 || (KD == 1 && TD == 1), "2-D bricks are one plane thick");
@@ -94,6 +103,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
     constexpr int LA = WB - 1;
     constexpr int NSLOT = ((kPairs + WB - 1) / WB) * WB;
     static_assert(NSLOT % WB == 0 && NSLOT >= kPairs, "pipeline geometry");
+    constexpr bool RPRE = MW * NW <= 8;            // residual tiles requested during the last slot (register budget)
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -137,6 +147,109 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
     if (producer) {
         // =========================== producers: HBM -> split bf16 -> LDS ===========================
         const int ptid = tid - 256;
+        if constexpr (UPS) {
+            constexpr int CD = ITD / 2, CH = ITH / 2, CW = ITW / 2, NC = CD * CH * CW;
+            constexpr int NITU = (NC * 4 + 255) / 256;         // cell items (cell, channel quad) per producer thread
+            const int Dl = a.Din >> 1, Hl = a.Hin >> 1, Wl = a.Win >> 1;
+            int lo_d[NITU], lo_h[NITU], lo_w[NITU];             // lower low-res corner of the cell (may be -1)
+            unsigned inmask[NITU];                              // bit axis*2+k: upsampled voxel k of the cell is inside
+            const float* xb = a.x;
+            f32x4 cr[NITU][8];
+#define MVSGI_PLAN_UPS(UNIT)                                                                            \
+            {                                                                                           \
+                int cb_, b_, od_, oh_, ow_;                                                             \
+                MVSGI_DECODE(UNIT, cb_, b_, od_, oh_, ow_)                                              \
+                (void)cb_;                                                                              \
+                _Pragma("unroll") for (int it = 0; it < NITU; ++it) {                                   \
+                    const int c = (ptid + it * 256) >> 2;                                               \
+                    const int cw = c % CW, ch = (c / CW) % CH, cd = c / (CW * CH);                      \
+                    const int gd = od_ - 1 + 2 * cd, gh = oh_ - 1 + 2 * ch, gw = ow_ - 1 + 2 * cw;      \
+                    lo_d[it] = (gd - 1) >> 1;                                                           \
+                    lo_h[it] = (gh - 1) >> 1;                                                           \
+                    lo_w[it] = (gw - 1) >> 1;                                                           \
+                    inmask[it] = (gd >= 0 && gd < a.Din ? 1u : 0u) | (gd + 1 < a.Din ? 2u : 0u) |       \
+                                 (gh >= 0 && gh < a.Hin ? 4u : 0u) | (gh + 1 < a.Hin ? 8u : 0u) |       \
+                                 (gw >= 0 && gw < a.Win ? 16u : 0u) | (gw + 1 < a.Win ? 32u : 0u);      \
+                }                                                                                       \
+                xb = a.x + (long long)b_ * Dl * Hl * Wl * a.Cin;                                        \
+            }
+#define MVSGI_CLAMP(V, N) ((V) < 0 ? 0 : ((V) > (N) - 1 ? (N) - 1 : (V)))
+#define MVSGI_STAGE_UPS(CC, DST)                                                                        \
+            {                                                                                           \
+                _Pragma("unroll") for (int it = 0; it < NITU; ++it) {                                   \
+                    const int e = ptid + it * 256;                                                      \
+                    const int q = e & 3;                                                                \
+                    const bool live = e < NC * 4;                                                       \
+                    const int d0 = live ? MVSGI_CLAMP(lo_d[it], Dl) : 0, d1 = live ? MVSGI_CLAMP(lo_d[it] + 1, Dl) : 0; \
+                    const int h0 = live ? MVSGI_CLAMP(lo_h[it], Hl) : 0, h1 = live ? MVSGI_CLAMP(lo_h[it] + 1, Hl) : 0; \
+                    const int w0 = live ? MVSGI_CLAMP(lo_w[it], Wl) : 0, w1 = live ? MVSGI_CLAMP(lo_w[it] + 1, Wl) : 0; \
+                    const int cofs = (CC) * 16 + q * 4;                                                 \
+                    _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                     \
+                        const int dd = (k & 4) ? d1 : d0, hh = (k & 2) ? h1 : h0, ww = (k & 1) ? w1 : w0; \
+                        cr[it][k] = *reinterpret_cast<const f32x4*>(xb + ((dd * Hl + hh) * Wl + ww) * a.Cin + cofs); \
+                    }                                                                                   \
+                }                                                                                       \
+                _Pragma("unroll") for (int it = 0; it < NITU; ++it) {                                   \
+                    const int e = ptid + it * 256;                                                      \
+                    if (e < NC * 4) {                                                                   \
+                        const int c = e >> 2, q = e & 3;                                                \
+                        const int cw = c % CW, ch = (c / CW) % CH, cd = c / (CW * CH);                  \
+                        /* separable blend: along W, then H, then D; index bit = upsampled voxel 0 / 1 of the cell */ \
+                        f32x4 xw[4][2], xh[2][2][2];                                                    \
+                        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                 \
+                            xw[k][0] = cr[it][2 * k] * 0.75f + cr[it][2 * k + 1] * 0.25f;               \
+                            xw[k][1] = cr[it][2 * k] * 0.25f + cr[it][2 * k + 1] * 0.75f;               \
+                        }                                                                               \
+                        _Pragma("unroll") for (int kd = 0; kd < 2; ++kd)                                \
+                            _Pragma("unroll") for (int kw = 0; kw < 2; ++kw) {                          \
+                                xh[kd][0][kw] = xw[2 * kd][kw] * 0.75f + xw[2 * kd + 1][kw] * 0.25f;    \
+                                xh[kd][1][kw] = xw[2 * kd][kw] * 0.25f + xw[2 * kd + 1][kw] * 0.75f;    \
+                            }                                                                           \
+                        _Pragma("unroll") for (int kd = 0; kd < 2; ++kd)                                \
+                            _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                            \
+                                _Pragma("unroll") for (int kw = 0; kw < 2; ++kw) {                      \
+                                    const float fa = kd ? 0.25f : 0.75f, fb = kd ? 0.75f : 0.25f;       \
+                                    const f32x4 xv4 = xh[0][kh][kw] * fa + xh[1][kh][kw] * fb;          \
+                                    const bool ok = ((inmask[it] >> kd) & (inmask[it] >> (2 + kh)) & (inmask[it] >> (4 + kw)) & 1u) != 0; \
+                                    bf16x4 hi, lo;                                                      \
+                                    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                     \
+                                        const float xv = ok ? xv4[k] : 0.f;                             \
+                                        const __bf16 h = (__bf16)xv;                                    \
+                                        hi[k] = h;                                                      \
+                                        lo[k] = (__bf16)(xv - (float)h);                                \
+                                    }                                                                   \
+                                    const int v = ((2 * cd + kd) * ITH + 2 * ch + kh) * ITW + 2 * cw + kw; \
+                                    *reinterpret_cast<bf16x4*>((DST) + v * kVSB + q * 8) = hi;          \
+                                    *reinterpret_cast<bf16x4*>((DST) + v * kVSB + 32 + q * 8) = lo;     \
+                                }                                                                       \
+                    }                                                                                   \
+                }                                                                                       \
+            }
+            STAMP()
+            MVSGI_PLAN_UPS((int)blockIdx.x)
+            MVSGI_STAGE_UPS(0, ldsb)
+            STAMP()
+            __syncthreads();                                   // image 0 holds unit 0
+            STAMP()
+            int k = 0, cc = 0;
+            for (int u = 0; u < U; ++u) {
+                int ncc = cc + 1, nk = k;
+                if (ncc == nchunks) { ncc = 0; nk = k + 1; }
+                if (u + 1 < U) {
+                    if (ncc == 0) { MVSGI_PLAN_UPS((int)blockIdx.x + nk * G) }
+                    unsigned char* dst = ldsb + ((u + 1) & 1) * BUF;
+                    MVSGI_STAGE_UPS(ncc, dst)
+                }
+                cc = ncc;
+                k = nk;
+                STAMP()
+                __syncthreads();
+                STAMP()
+            }
+#undef MVSGI_PLAN_UPS
+#undef MVSGI_STAGE_UPS
+#undef MVSGI_CLAMP
+        } else {
         int goff[NIT];
         unsigned okmask = 0;
         const float* xb = a.x;
@@ -207,6 +320,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
         }
 #undef MVSGI_PLAN
 #undef MVSGI_STAGE
+        }
     } else {
         // =========================== consumers: LDS + L2 weights -> MFMA ===========================
         const int wm = wave % WM, wn = wave / WM;
@@ -222,6 +336,16 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
             const int w_ = v % TW, h_ = (v / TW) % TH, d_ = v / (TW * TH);
             base[i] = (((d_ * SD) * ITH + h_ * S) * ITW + w_ * S) * kVSB + (kg >> 1) * 16;
         }
+        // position of this lane's voxel of each tile inside the brick (unit-independent)
+        int tdv[MW], thv[MW], twv[MW];
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+            const int v = (wm * MW + i) * 16 + col;
+            twv[i] = v % TW;
+            thv[i] = (v / TW) % TH;
+            tdv[i] = v / (TW * TH);
+        }
+        const long long frame_elems = (long long)a.Do * a.Ho * a.Wo * a.Cout;     // < 2^31 (checked on the host)
         int ctc[NW], ctn[NW];             // clamped cout tiles of the current / the next unit
 #define MVSGI_CTILES(DST, CB)                                                         \
         _Pragma("unroll") for (int j = 0; j < NW; ++j) {                              \
@@ -296,12 +420,19 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
             }
             // per-channel scale / shift of this wave's cout tiles: requested before the last slice is
             // multiplied so the epilogue does not wait for them one tile at a time
-            f32x4 esc[NW], esh[NW];
+            f32x4 esc[NW], esh[NW], rres[RPRE ? MW : 1][RPRE ? NW : 1];
+            int eoff[MW];                  // in-frame element offset of (voxel, cout 4*kg) or -1 outside the volume
             if (last) {
 #pragma unroll
                 for (int j = 0; j < NW; ++j) {
                     esc[j] = *reinterpret_cast<const f32x4*>(a.scale + ctc[j] * 16 + kg * 4);
                     esh[j] = *reinterpret_cast<const f32x4*>(a.shift + ctc[j] * 16 + kg * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < MW; ++i) {
+                    const int od = od0 + tdv[i], oh = oh0 + thv[i], ow = ow0 + twv[i];
+                    const bool inside = od < a.Do && oh < a.Ho && ow < a.Wo;
+                    eoff[i] = inside ? ((od * a.Ho + oh) * a.Wo + ow) * a.Cout + kg * 4 : -1;
                 }
             }
             MVSGI_READX(0, 0, 0, MW)
@@ -318,6 +449,16 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
                     } else if (more) {
                         MVSGI_LOADW((s_ + LA - NSLOT) % WB, ncc, s_ + LA - NSLOT, ctn)
                     }
+                }
+                if (RPRE && s_ == kPairs - 1 && last && a.res) {
+                    // residual tiles of the brick: behind the last weight requests of the unit, ahead
+                    // of the last slot's MFMAs (loads return in issue order)
+                    const float* rb = a.res + (long long)b_ * frame_elems;
+#pragma unroll
+                    for (int i = 0; i < MW; ++i)
+#pragma unroll
+                        for (int j = 0; j < NW; ++j)
+                            rres[i][j] = *reinterpret_cast<const f32x4*>(rb + (eoff[i] >= 0 ? eoff[i] + ctc[j] * 16 : 0));
                 }
                 if (s_ < kPairs) {
                     if (XB == 2) {
@@ -350,26 +491,28 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
             STAMP()
             if (last) {
                 // epilogue of the finished brick: lane (col, kg) of tile (i, j) holds couts
-                // ct*16 + 4*kg + 0..3 of voxel i*16 + col
+                // ct*16 + 4*kg + 0..3 of voxel i*16 + col.  The residual tiles were requested during
+                // the last slot (one exposed round trip per brick, not one per tile).
                 const int ct0 = (cb_ * WN + wn) * NW;
+                float* yb = a.y + (long long)b_ * frame_elems;
+                f32x4 rl[RPRE ? 1 : MW][RPRE ? 1 : NW];
+                if (!RPRE && a.res) {         // many tiles: request them all here, still one round trip
+                    const float* rb = a.res + (long long)b_ * frame_elems;
+#pragma unroll
+                    for (int i = 0; i < (RPRE ? 1 : MW); ++i)
+#pragma unroll
+                        for (int j = 0; j < (RPRE ? 1 : NW); ++j)
+                            rl[i][j] = *reinterpret_cast<const f32x4*>(rb + (eoff[i] >= 0 ? eoff[i] + ctc[j] * 16 : 0));
+                }
 #pragma unroll
                 for (int i = 0; i < MW; ++i) {
-                    const int v = (wm * MW + i) * 16 + col;
-                    const int w_ = v % TW, h_ = (v / TW) % TH, d_ = v / (TW * TH);
-                    const int od = od0 + d_, oh = oh0 + h_, ow = ow0 + w_;
-                    const bool inside = od < a.Do && oh < a.Ho && ow < a.Wo;
-                    const long long vox = (((long long)b_ * a.Do + od) * a.Ho + oh) * a.Wo + ow;
 #pragma unroll
                     for (int j = 0; j < NW; ++j) {
-                        const int ct = ct0 + j;
-                        if (inside && ct < CT) {
-                            const int co = ct * 16 + kg * 4;
-                            f32x4 r = acc[i][j] * esc[j] + esh[j];
-                            if (a.res) r += *reinterpret_cast<const f32x4*>(a.res + vox * a.Cout + co);
+                        f32x4 r = acc[i][j] * esc[j] + esh[j];
+                        if (a.res) r += RPRE ? rres[RPRE ? i : 0][RPRE ? j : 0] : rl[RPRE ? 0 : i][RPRE ? 0 : j];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : r[e] * a.neg_slope;
-                            *reinterpret_cast<f32x4*>(a.y + vox * a.Cout + co) = r;
-                        }
+                        for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : r[e] * a.neg_slope;
+                        if (eoff[i] >= 0 && ct0 + j < CT) *reinterpret_cast<f32x4*>(yb + eoff[i] + (ct0 + j) * 16) = r;
                         acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
@@ -392,12 +535,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {
 #undef STAMP
 }
 
-template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3>
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false>
 int launch_bf16x3(ConvArgs a, hipStream_t st) {
     constexpr int ITD = (TD - 1) * (KD == 1 ? 1 : S) + KD, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
     constexpr size_t lds_bytes = (size_t)2 * ITD * ITH * ITW * kVSB;      // double-buffered image
     static_assert(lds_bytes <= 160 * 1024, "LDS images too large");
-    auto kern = conv3d_bf16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD>;
+    auto kern = conv3d_bf16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS>;
     static int wgs_per_cu = 0;       // benign race: idempotent
     if (!wgs_per_cu) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -415,6 +558,8 @@ int launch_bf16x3(ConvArgs a, hipStream_t st) {
     const long long nb = (long long)a.B * a.tiles_d * a.tiles_h * a.tiles_w * mvsgi::cdiv(CT, WN * NW);
     MVSGI_REQUIRE(nb < (1ll << 31), "conv3d: too many units");
     MVSGI_REQUIRE((long long)a.Din * a.Hin * a.Win * a.Cin < (1ll << 29), "conv3d: volume too large for 32-bit byte offsets");
+    MVSGI_REQUIRE(!UPS || (a.Din % 2 == 0 && a.Hin % 2 == 0 && a.Win % 2 == 0), "conv3d: fused upsample needs even sizes");
+    MVSGI_REQUIRE((long long)a.Do * a.Ho * a.Wo * a.Cout < (1ll << 31), "conv3d: output frame too large for 32-bit element offsets");
     a.total_units = (int)nb;
 #ifdef MVSGI_STAMPS
     {   // stamps of the PREVIOUS launch are printed when MVSGI_STAMP=2
@@ -428,7 +573,7 @@ int launch_bf16x3(ConvArgs a, hipStream_t st) {
             (void)hipMemcpy(h, dbgbuf, sizeof(h), hipMemcpyDeviceToHost);
             for (int w = 0; w < 8; ++w) {
                 fprintf(stderr, "wave %d:", w);
-                for (int i = 0; i < 44; ++i) fprintf(stderr, " %lld", (long long)(h[w * 128 + i] - h[0]));
+                for (int i = 0; i < 120; ++i) fprintf(stderr, " %lld", (long long)(h[w * 128 + i] - h[0]));
                 fprintf(stderr, "\n");
             }
         }

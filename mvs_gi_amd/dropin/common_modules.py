@@ -53,6 +53,15 @@ class ConvLaunch:
         return H.conv3d(x_ndhwc, self.w, wp, self.scale, self.shift, res=res, stride=self.stride,
                         neg_slope=self.neg_slope, impl=impl)
 
+    def can_fuse_up2(self) -> bool:
+        return H.get_conv_mode() == "bf16x3" and self.stride == 1 and self.cin % 16 == 0 and self.cout % 16 == 0
+
+    def run_up2(self, x_lowres_ndhwc: Tensor, res: Optional[Tensor] = None) -> Tensor:
+        """conv(trilinear_x2(x)) in one launch (mvsgi_conv3d_up2_f32)."""
+        if self.wp_b3 is None:
+            self.wp_b3 = H.pack_conv_weights_bf16x3(self.w)
+        return H.conv3d_up2(x_lowres_ndhwc, self.wp_b3, self.scale, self.shift, res=res, neg_slope=self.neg_slope)
+
 
 def _is_identity(m) -> bool:
     return m is None or isinstance(m, nn.Identity)
@@ -198,6 +207,9 @@ def resize_conv_ndhwc(blk, x: Tensor, res: Optional[Tensor] = None) -> Tensor:
     """ResizeConv3d.forward (common_modules.py:332-355): trilinear to int(scale*s)+out_pad,
     optional second resize to the skip's size, then conv(+res)."""
     up = [int(blk.scale * s) + blk.out_pad for s in x.shape[1:4]]
+    L = lower_conv_block(blk.conv)
+    if up == [2 * s for s in x.shape[1:4]] and (res is None or tuple(res.shape[1:4]) == tuple(up)) and L.can_fuse_up2():
+        return L.run_up2(x, res)                  # upsample evaluated inside the conv's staging path
     x = H.resize_trilinear(x, up)
     if res is not None and tuple(x.shape[1:4]) != tuple(res.shape[1:4]):
         x = H.resize_trilinear(x, res.shape[1:4])

@@ -256,6 +256,32 @@ def conv3d(x, w_oidhw, w_packed, scale, shift, res=None, stride=1, neg_slope=0.0
     return y
 
 
+def conv3d_up2(x, w_packed_b3, scale, shift, res=None, neg_slope=0.01, out=None):
+    """Fused trilinear x2 upsample + conv3d (split-bf16): x [B, Dl, Hl, Wl, Cin] -> y [B, 2Dl, 2Hl, 2Wl, Cout]."""
+    lib = _lib.load()
+    x = _dev(x, "x")
+    B, Dl, Hl, Wl, Cin = x.shape
+    Cout = scale.numel()
+    shp = (B, 2 * Dl, 2 * Hl, 2 * Wl, Cout)
+    if res is not None:
+        res = _dev(res, "res")
+        if tuple(res.shape) != shp:
+            raise AssertionError(f"residual {tuple(res.shape)} does not match output {shp}")
+    y = out if out is not None else torch.empty(shp, device=x.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_conv3d_up2_f32(x.data_ptr(), _ptr(w_packed_b3), scale.data_ptr(), shift.data_ptr(), _ptr(res),
+                                        y.data_ptr(), B, Cin, Dl, Hl, Wl, Cout, float(neg_slope), _stream_ptr(x)),
+               "mvsgi_conv3d_up2_f32")
+    return y
+
+
+def conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout) -> str:
+    lib = _lib.load()
+    name = lib.mvsgi_conv3d_up2_variant_f32(B, Cin, Dl, Hl, Wl, Cout)
+    if name is None:
+        raise RuntimeError("mvsgi_conv3d_up2_variant_f32: " + lib.mvsgi_last_error().decode())
+    return name.decode()
+
+
 def conv3d_variant(B, Cin, Din, Hin, Win, Cout, stride=1, impl=CONV_AUTO) -> str:
     """Name of the kernel mvsgi_conv3d_f32 will launch for this problem (as rocprofv3 prints it)."""
     lib = _lib.load()

@@ -178,6 +178,43 @@ def test_conv3d_bf16x3_vs_oracle(shape):
     assert err <= 1e-4, err
 
 
+@pytest.mark.parametrize("shape", [
+    # (B, Cin, Cout, Dl, Hl, Wl, res)
+    (1, 32, 16, 4, 8, 16, False),      # out_costs.0-like: exact 4x4x16 bricks
+    (2, 32, 16, 3, 5, 9, False),       # ragged bricks, odd low-res sizes
+    (1, 64, 32, 2, 6, 8, True),        # up block + skip, small-brick (TD = 2) variant
+    (3, 64, 32, 4, 20, 24, True),      # big-brick variant (>= 384 bricks)
+    (1, 128, 64, 1, 3, 5, True),       # Dl = 1: every corner clamps along D
+    (1, 96, 48, 2, 4, 8, False),       # 3 cout tiles
+    (1, 192, 96, 2, 4, 8, True),       # 6 cout tiles
+])
+def test_conv3d_fused_upsample_vs_interpolate_then_conv(shape):
+    """mvsgi_conv3d_up2_f32 == conv3d(F.interpolate(x, scale 2, trilinear, align_corners=False)):
+    ResizeConv3d.forward (common_modules.py:332-355) with the upsample inside the conv's producers."""
+    B, Cin, Cout, Dl, Hl, Wl, res = shape
+    rng = np.random.default_rng(sum(shape[:6]))
+    xl = rng.standard_normal((B, Cin, Dl, Hl, Wl)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3, 3)) / np.sqrt(27 * Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.normal(0, 0.2, Cout).astype(np.float32)
+    r = rng.standard_normal((B, Cout, 2 * Dl, 2 * Hl, 2 * Wl)).astype(np.float32) if res else None
+    up = F.interpolate(torch.from_numpy(xl), scale_factor=2, mode="trilinear", align_corners=False)
+    y = F.conv3d(up, torch.from_numpy(w), None, padding=1)
+    y = y * torch.from_numpy(scale).view(1, -1, 1, 1, 1) + torch.from_numpy(shift).view(1, -1, 1, 1, 1)
+    if res:
+        y = y + torch.from_numpy(r)
+    yref = torch.where(y > 0, y, y * 0.01).numpy()
+    xg = _g(xl).permute(0, 2, 3, 4, 1).contiguous()
+    rg = _g(r).permute(0, 2, 3, 4, 1).contiguous() if res else None
+    got = H.conv3d_up2(xg, H.pack_conv_weights_bf16x3(_g(w)), _g(scale), _g(shift), res=rg, neg_slope=0.01)
+    assert "true" in H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout)
+    assert _rel(_ncdhw(got), yref) <= 1e-4
+    # and the two-launch path it replaces
+    two = H.conv3d(H.resize_trilinear(xg, (2 * Dl, 2 * Hl, 2 * Wl)), _g(w), H.pack_conv_weights_bf16x3(_g(w)),
+                   _g(scale), _g(shift), res=rg, neg_slope=0.01, impl=H.CONV_BF16X3)
+    assert _rel(_ncdhw(got), _ncdhw(two)) <= 1e-5
+
+
 def test_cost_head_whole_depth_march_and_epilogue():
     """>= 1024 (frame, window) pairs: every workgroup marches the whole depth (no D split);
     also the residual / LeakyReLU epilogue and ragged H, W."""
