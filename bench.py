@@ -123,17 +123,17 @@ class ConvProbe:
             self.records.append((H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, impl), 2.0 * 27 * Cin * Cout * vox, s, e))
             return y
 
-        def probed_up2(x, w_packed_b3, scale, shift, res=None, neg_slope=0.01, out=None):
+        def probed_up2(x, w_packed_b3, scale, shift, res=None, neg_slope=0.01, out=None, w_layout=H.CONV_BF16X3):
             if not self.enabled:
-                return self.orig_up2(x, w_packed_b3, scale, shift, res, neg_slope, out)
+                return self.orig_up2(x, w_packed_b3, scale, shift, res, neg_slope, out, w_layout)
             B, Dl, Hl, Wl, Cin = x.shape
             Cout = scale.numel()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            y = self.orig_up2(x, w_packed_b3, scale, shift, res, neg_slope, out)
+            y = self.orig_up2(x, w_packed_b3, scale, shift, res, neg_slope, out, w_layout)
             e.record()
             vox = y.numel() // Cout
-            self.records.append((H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout), 2.0 * 27 * Cin * Cout * vox, s, e))
+            self.records.append((H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, w_layout), 2.0 * 27 * Cin * Cout * vox, s, e))
             return y
 
         H.conv3d = probed

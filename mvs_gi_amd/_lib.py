@@ -37,8 +37,10 @@ SIGNATURES = {
     "mvsgi_conv3d_pack_weights_bf16x3": (c_int, [_P, _P, c_int, c_int, _P]),
     "mvsgi_conv3d_f32": (c_int, [_P] * 7 + [c_int] * 7 + [c_float, c_int, _P]),
     "mvsgi_conv3d_variant_f32": (c_char_p, [c_int] * 8),
-    "mvsgi_conv3d_up2_f32": (c_int, [_P] * 6 + [c_int] * 6 + [c_float, _P]),
-    "mvsgi_conv3d_up2_variant_f32": (c_char_p, [c_int] * 6),
+    "mvsgi_conv3d_up2_f32": (c_int, [_P, _P, c_int] + [_P] * 4 + [c_int] * 6 + [c_float, _P]),
+    "mvsgi_conv3d_up2_variant_f32": (c_char_p, [c_int] * 7),
+    "mvsgi_conv3d_packed_weight_bytes_bf16x3_c16": (c_size_t, [c_int]),
+    "mvsgi_conv3d_pack_weights_bf16x3_c16": (c_int, [_P, _P, c_int, _P]),
     "mvsgi_conv2d_packed_weight_floats": (c_size_t, [c_int, c_int]),
     "mvsgi_conv2d_pack_weights_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "mvsgi_conv2d_packed_weight_bytes_bf16x3": (c_size_t, [c_int, c_int]),

@@ -282,6 +282,8 @@ enum Variant {
     B3_N16, B3_N32, B3_N48, B3_N64, B3_N96, B3_N32_S, B3_N64_S, B3_S2_N32, B3_S2_N64,
     // split-bf16 kernel with the trilinear x2 upsample fused into its producers (even bricks only)
     B3U_N16, B3U_N32, B3U_N32_M, B3U_N48, B3U_N64, B3U_N96,
+    // Cout == 16 plane schedule (weights from mvsgi_conv3d_pack_weights_bf16x3_c16), plain and fused-upsample
+    B3P_N16, B3PU_N16,
     V_COUNT
 };
 const char* const kVariantNames[V_COUNT] = {
@@ -290,18 +292,19 @@ const char* const kVariantNames[V_COUNT] = {
     "conv3d_mfma_kernel<2, 1, 4, 1, 2, 4, 8, 1>", "conv3d_mfma_kernel<2, 4, 2, 2, 2, 8, 8, 1>",
     "conv3d_mfma_kernel<2, 2, 2, 2, 2, 4, 8, 1>", "conv3d_mfma_kernel<2, 1, 4, 1, 2, 4, 8, 2>",
     "conv3d_mfma_kernel<2, 2, 2, 2, 2, 4, 8, 2>",
-    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1>",
-    "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1>", "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1>",
-    "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1>",
-    "conv3d_bf16x3_kernel<2, 2, 2, 2, 1, 4, 16, 1>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 2, 4, 8, 2>",
-    "conv3d_bf16x3_kernel<2, 2, 2, 2, 2, 4, 8, 2>",
-    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, true>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1, 3, true>",
-    "conv3d_bf16x3_kernel<2, 2, 4, 1, 2, 4, 16, 1, 3, true>", "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1, 3, true>",
-    "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, true>", "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, true>",
+    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, false, false>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1, 3, false, false>",
+    "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1, 3, false, false>", "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, false, false>",
+    "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false>",
+    "conv3d_bf16x3_kernel<2, 2, 2, 2, 1, 4, 16, 1, 3, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 2, 4, 8, 2, 3, false, false>",
+    "conv3d_bf16x3_kernel<2, 2, 2, 2, 2, 4, 8, 2, 3, false, false>",
+    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, true, false>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1, 3, true, false>",
+    "conv3d_bf16x3_kernel<2, 2, 4, 1, 2, 4, 16, 1, 3, true, false>", "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1, 3, true, false>",
+    "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, true, false>", "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, true, false>",
+    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, false, true>", "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, true, true>",
 };
 
 // variant of the fused upsample + conv (a holds the UPSAMPLED input size); V_COUNT when unsupported
-int select_variant_up2(const ConvArgs& a) {
+int select_variant_up2(const ConvArgs& a, bool c16_layout) {
     if (a.Cin % 16 || a.Cout % 16) {
         mvsgi::fail("mvsgi_conv3d_up2_f32: Cin, Cout must be multiples of 16 (got %d, %d)", a.Cin, a.Cout);
         return V_COUNT;
@@ -310,7 +313,7 @@ int select_variant_up2(const ConvArgs& a) {
     const int CT = a.Cout / 16;
     const long long big = (long long)a.B * mvsgi::cdiv(a.Do, 4) * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
     const long long mid = (long long)a.B * mvsgi::cdiv(a.Do, 2) * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
-    if (CT == 1) return B3U_N16;
+    if (CT == 1) return c16_layout ? B3PU_N16 : B3U_N16;
     if (CT == 2) return big >= 384 ? B3U_N32 : B3U_N32_M;
     if (CT == 3) return B3U_N48;
     if (CT % 6 == 0 && mid * (CT / 6) >= 384) return B3U_N96;
@@ -321,6 +324,15 @@ int select_variant_up2(const ConvArgs& a) {
 int select_variant(const ConvArgs& a, int impl) {
     const bool mfma_ok = (a.Cin % 16 == 0) && (a.Cout % 16 == 0);
     const bool head_ok = (a.Cout == 1) && (a.Cin % 16 == 0) && (a.stride == 1);
+    if (impl == MVSGI_CONV_BF16X3_C16) {
+        if (a.Cout != 16 || a.Cin % 16 || a.stride != 1) {
+            mvsgi::fail("mvsgi_conv3d_f32: the Cout == 16 plane kernel needs Cout == 16, Cin %% 16 == 0, stride 1 (got %d, %d, %d)",
+                        a.Cout, a.Cin, a.stride);
+            return V_COUNT;
+        }
+        if (!a.wp) { mvsgi::fail("mvsgi_conv3d_f32: tiled path needs w_packed"); return V_COUNT; }
+        return B3P_N16;
+    }
     if (impl == MVSGI_CONV_BF16X3 && !mfma_ok) impl = MVSGI_CONV_AUTO;   // head / odd channels: exact paths
     if (impl == MVSGI_CONV_AUTO) impl = (mfma_ok || head_ok) ? MVSGI_CONV_MFMA : MVSGI_CONV_DIRECT;
     if (impl == MVSGI_CONV_DIRECT) {
@@ -385,6 +397,8 @@ int launch_variant(int v, const ConvArgs& a, hipStream_t st) {
         case B3U_N48: return launch_bf16x3<3, 4, 4, 1, 4, 4, 16, 1, 3, true>(a, st);
         case B3U_N64: return launch_bf16x3<2, 4, 2, 2, 2, 4, 16, 1, 3, true>(a, st);
         case B3U_N96: return launch_bf16x3<3, 4, 2, 2, 2, 4, 16, 1, 3, true>(a, st);
+        case B3P_N16: return launch_bf16x3<1, 4, 4, 1, 4, 4, 16, 1, 3, false, true>(a, st);
+        case B3PU_N16: return launch_bf16x3<1, 4, 4, 1, 4, 4, 16, 1, 3, true, true>(a, st);
     }
     return mvsgi::fail("mvsgi_conv3d_f32: bad variant %d", v);
 }
@@ -436,6 +450,17 @@ extern "C" int mvsgi_conv3d_pack_weights_bf16x3(const float* w_oidhw, void* w_pa
     return mvsgi::check_launch("mvsgi_conv3d_pack_weights_bf16x3");
 }
 
+extern "C" size_t mvsgi_conv3d_packed_weight_bytes_bf16x3_c16(int Cin) { return (size_t)(Cin / 16) * 5 * 3 * 2 * 64 * 16; }
+
+extern "C" int mvsgi_conv3d_pack_weights_bf16x3_c16(const float* w_oidhw, void* w_packed, int Cin, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(w_oidhw && w_packed, "mvsgi_conv3d_pack_weights_bf16x3_c16: null pointer");
+    MVSGI_REQUIRE(Cin > 0 && Cin % 16 == 0, "mvsgi_conv3d_pack_weights_bf16x3_c16: Cin=%d must be a positive multiple of 16", Cin);
+    const int total = (Cin / 16) * 5 * 3 * 64;
+    hipLaunchKernelGGL(pack_weights_bf16x3_c16_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0,
+                       mvsgi::as_stream(stream), w_oidhw, reinterpret_cast<bf16x8*>(w_packed), Cin);
+    return mvsgi::check_launch("mvsgi_conv3d_pack_weights_bf16x3_c16");
+}
+
 extern "C" int mvsgi_conv3d_pack_weights_f32(const float* w_oidhw, float* w_packed, int Cout, int Cin,
                                              mvsgi_stream_t stream) {
     MVSGI_REQUIRE(w_oidhw && w_packed, "mvsgi_conv3d_pack_weights_f32: null pointer");
@@ -479,9 +504,11 @@ extern "C" const char* mvsgi_conv3d_variant_f32(int B, int Cin, int Din, int Hin
 // ResizeConv3d (common_modules.py:332-355) in one launch: trilinear x2 upsample (align_corners=False) of
 // x [B][Dl][Hl][Wl][Cin] fused into the producers of the split-bf16 convolution at (2Dl, 2Hl, 2Wl);
 // y / res [B][2Dl][2Hl][2Wl][Cout].  w_packed is the bf16x3 layout.
-extern "C" int mvsgi_conv3d_up2_f32(const float* x, const void* w_packed, const float* scale, const float* shift,
-                                    const float* res, float* y, int B, int Cin, int Dl, int Hl, int Wl, int Cout,
-                                    float neg_slope, mvsgi_stream_t stream) {
+extern "C" int mvsgi_conv3d_up2_f32(const float* x, const void* w_packed, int w_layout, const float* scale,
+                                    const float* shift, const float* res, float* y, int B, int Cin, int Dl, int Hl,
+                                    int Wl, int Cout, float neg_slope, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(w_layout == MVSGI_CONV_BF16X3 || (w_layout == MVSGI_CONV_BF16X3_C16 && Cout == 16),
+                  "mvsgi_conv3d_up2_f32: w_layout %d not valid for Cout %d", w_layout, Cout);
     MVSGI_REQUIRE(x && y && scale && shift && w_packed, "mvsgi_conv3d_up2_f32: null pointer");
     MVSGI_REQUIRE(Dl > 0 && Hl > 0 && Wl > 0 && Dl < (1 << 20) && Hl < (1 << 20) && Wl < (1 << 20),
                   "mvsgi_conv3d_up2_f32: bad dims");
@@ -489,17 +516,17 @@ extern "C" int mvsgi_conv3d_up2_f32(const float* x, const void* w_packed, const 
     if (fill_args(a, x, nullptr, static_cast<const float*>(w_packed), scale, shift, res, y, B, Cin, 2 * Dl, 2 * Hl,
                   2 * Wl, Cout, 1, neg_slope))
         return 1;
-    const int v = select_variant_up2(a);
+    const int v = select_variant_up2(a, w_layout == MVSGI_CONV_BF16X3_C16);
     if (v == V_COUNT) return 1;
     return launch_variant(v, a, mvsgi::as_stream(stream));
 }
 
-extern "C" const char* mvsgi_conv3d_up2_variant_f32(int B, int Cin, int Dl, int Hl, int Wl, int Cout) {
+extern "C" const char* mvsgi_conv3d_up2_variant_f32(int B, int Cin, int Dl, int Hl, int Wl, int Cout, int w_layout) {
     ConvArgs a{};
     static const float dummy = 0.f;
     if (fill_args(a, &dummy, nullptr, &dummy, &dummy, &dummy, nullptr, nullptr, B, Cin, 2 * Dl, 2 * Hl, 2 * Wl, Cout, 1,
                   1.f))
         return nullptr;
-    const int v = select_variant_up2(a);
+    const int v = select_variant_up2(a, w_layout == MVSGI_CONV_BF16X3_C16);
     return v == V_COUNT ? nullptr : kVariantNames[v];
 }

@@ -67,6 +67,33 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, bf16x8* 
     wp[o + 64] = lo;
 }
 
+// Cout == 16 plane schedule: [16][Cin][27] -> [Cin/16][5 pairs][3 kd][hi|lo][64 lanes][8 bf16]
+//   lane = (kg << 4) | i holds W[cout = i][cin = cc*16 + (kg>>1)*8 + j][kd][in-plane tap 2p + (kg&1)]  (tap 9: zero)
+__global__ void pack_weights_bf16x3_c16_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cin) {
+    const int total = (Cin / 16) * 5 * 3 * 64;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = idx & 63;
+    int r = idx >> 6;
+    const int kd = r % 3;
+    r /= 3;
+    const int p = r % 5;
+    const int cc = r / 5;
+    const int kg = lane >> 4, co = lane & 15;
+    const int ci = cc * 16 + (kg >> 1) * 8;
+    const int t2 = 2 * p + (kg & 1);
+    bf16x8 hi, lo;
+    for (int j = 0; j < 8; ++j) {
+        const float v = t2 < 9 ? w[((long long)co * Cin + ci + j) * 27 + kd * 9 + t2] : 0.f;
+        const __bf16 h = (__bf16)v;
+        hi[j] = h;
+        lo[j] = (__bf16)(v - (float)h);
+    }
+    const long long o = ((long long)((cc * 5 + p) * 3 + kd) * 2) * 64 + lane;
+    wp[o] = hi;
+    wp[o + 64] = lo;
+}
+
 // bijective XCD-aware remap of a flat block id (cdna_hip_programming.md T1): blocks b, b+8, ...
 // share an XCD; give each XCD a contiguous run of the logical index space.
 __device__ __forceinline__ int xcd_remap(int bid, int n) {
@@ -83,8 +110,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // upsampled voxels strictly inside it are blended separably (weights 0.75 / 0.25), masked to zero outside the
 // volume (the convolution's padding), split and written to the LDS image: the same one load per staged voxel
 // as the plain producer, but 1/8 of the bytes, and neither the resize kernel nor the upsampled tensor exist.
-template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false>
+//
+// PLANE = true is the consumer schedule for Cout == 16 layers (one cout tile: an activation fragment would
+// feed only 3 MFMAs and the loop is LDS-read bound).  A consumer wave owns one h-row of the brick and ALL its
+// TD output planes; the 27 taps are walked as (in-plane tap pair p' of 5) x (input plane ip of TD + 2), and
+// the fragment of (ip, p') is multiplied with the kd = 0, 1, 2 weights into the accumulators of output
+// planes ip, ip - 1, ip - 2: up to 9 MFMAs per fragment, 60 instead of 112 ds_read_b128 per 16-channel slice.
+// Weights are packed per (slice, pair, kd) by pack_weights_bf16x3_c16_kernel.
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false, bool PLANE = false>
 __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {      // 2 waves per SIMD: 256 registers
+    static_assert(!PLANE || (NW == 1 && WN == 1 && WM == 4 && TH == 4 && MW == TD && TW == 16 && S == 1 && KD == 3),
+                  "plane schedule: Cout == 16, 4 h-rows x TD planes x 16 w per brick");
     static_assert(!UPS || (S == 1 && KD == 3 && TD % 2 == 0 && TH % 2 == 0 && TW % 2 == 0),
                   "fused upsample: stride 1, even bricks (halo bricks are whole 2x2x2 cells)");
     static_assert(WM * WN == 4, "4 consumer waves per workgroup");
@@ -340,7 +376,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
         int tdv[MW], thv[MW], twv[MW];
 #pragma unroll
         for (int i = 0; i < MW; ++i) {
-            const int v = (wm * MW + i) * 16 + col;
+            const int v = PLANE ? (i * TH + wm) * TW + col : (wm * MW + i) * 16 + col;     // PLANE: tile i = plane i of row wm
             twv[i] = v % TW;
             thv[i] = (v / TW) % TH;
             tdv[i] = v / (TW * TH);
@@ -396,7 +432,39 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
         int cb_, b_, od0, oh0, ow0;
         MVSGI_DECODE((int)blockIdx.x, cb_, b_, od0, oh0, ow0)
         MVSGI_CTILES(ctc, cb_)
-        {
+        // ---- plane schedule (Cout == 16): fragments of one in-plane tap pair at a time ----
+        constexpr int NPP = 5;                              // in-plane tap pairs (9 taps)
+        constexpr int PD = PLANE ? TD + 2 : 1;
+        bf16x8 pwh[2][PLANE ? 3 : 1], pwl[2][PLANE ? 3 : 1];             // [buffer][kd]
+        bf16x8 pxh[2][PD], pxl[2][PD];                                   // [buffer][input plane]
+        const int pbase = (wm * ITW + col) * kVSB + (kg >> 1) * 16;      // row wm, plane 0, tap (0, 0)
+#define MVSGI_PL_LOADW(BUFI, CC, P)                                                                    \
+        _Pragma("unroll") for (int kd = 0; kd < 3; ++kd) {                                             \
+            const char* q_ = wpb + ((long long)(((CC) * NPP + (P)) * 3 + kd)) * 2048;   /* wave-uniform */ \
+            pwh[BUFI][kd] = *reinterpret_cast<const bf16x8*>(q_ + l16);                                \
+            pwl[BUFI][kd] = *reinterpret_cast<const bf16x8*>(q_ + l16 + 1024u);                        \
+        }
+#define MVSGI_PL_READX(BUFI, P)                                                                        \
+        {                                                                                              \
+            const int t0_ = 2 * (P), t1_ = 2 * (P) + 1 < 9 ? 2 * (P) + 1 : 2 * (P);                    \
+            const int o0_ = ((t0_ / 3) * ITW + t0_ % 3) * kVSB, o1_ = ((t1_ / 3) * ITW + t1_ % 3) * kVSB; \
+            const int off_ = pbase + (second ? o1_ : o0_);                                             \
+            _Pragma("unroll") for (int ip = 0; ip < PD; ++ip) {                                        \
+                pxh[BUFI][ip] = *reinterpret_cast<const bf16x8*>(img + off_ + ip * (ITH * ITW * kVSB)); \
+                pxl[BUFI][ip] = *reinterpret_cast<const bf16x8*>(img + off_ + ip * (ITH * ITW * kVSB) + 32); \
+            }                                                                                          \
+        }
+// term-major, then kd, then plane: the three products of one accumulator are >= TD MFMAs apart
+#define MVSGI_PL_MFMAS(BUFI)                                                                           \
+        _Pragma("unroll") for (int tr = 0; tr < 3; ++tr)                                               \
+            _Pragma("unroll") for (int kd = 0; kd < 3; ++kd)                                           \
+                _Pragma("unroll") for (int i = 0; i < TD; ++i)                                         \
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr == 0 ? pwl[BUFI][kd] : pwh[BUFI][kd], \
+                                                                         tr == 1 ? pxl[BUFI][i + kd] : pxh[BUFI][i + kd], acc[i][0], 0, 0, 0);
+        if constexpr (PLANE) {
+            unsigned l16 = lane16;
+            MVSGI_PL_LOADW(0, 0, 0)
+        } else {
             unsigned l16 = lane16;
 #pragma unroll
             for (int s0 = 0; s0 < LA; ++s0) { MVSGI_LOADW(s0, 0, s0, ctc) }
@@ -435,6 +503,40 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                     eoff[i] = inside ? ((od * a.Ho + oh) * a.Wo + ow) * a.Cout + kg * 4 : -1;
                 }
             }
+            if constexpr (PLANE) {
+                MVSGI_PL_READX(0, 0)
+#pragma unroll
+                for (int p_ = 0; p_ < NPP; ++p_) {
+                    const int cur = p_ & 1, nxt = cur ^ 1;
+                    unsigned l16 = lane16;
+                    asm volatile("" : "+v"(l16));
+                    if (p_ + 1 < NPP) {
+                        MVSGI_PL_LOADW(nxt, cc, p_ + 1)
+                        MVSGI_PL_READX(nxt, p_ + 1)
+                    } else if (last && a.res) {
+                        // residual planes of this row: behind the unit's last weight requests
+                        const float* rb = a.res + (long long)b_ * frame_elems;
+#pragma unroll
+                        for (int i = 0; i < MW; ++i)
+                            rres[i][0] = *reinterpret_cast<const f32x4*>(rb + (eoff[i] >= 0 ? eoff[i] : 0));
+                    }
+                    MVSGI_PL_MFMAS(cur)
+                    if (p_ + 1 < NPP) {
+                        // 18 fragment requests spread over the 36 MFMAs of the pair
+#pragma unroll
+                        for (int q_ = 0; q_ < 6 + 2 * PD; ++q_) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 36 / (6 + 2 * PD) > 0 ? 36 / (6 + 2 * PD) : 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, 36, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (more) {                                  // first pair of the next unit (hidden by the epilogue / barrier)
+                    unsigned l16 = lane16;
+                    MVSGI_PL_LOADW(0, ncc, 0)
+                }
+            } else {
             MVSGI_READX(0, 0, 0, MW)
 #pragma unroll
             for (int s_ = 0; s_ < NSLOT; ++s_) {
@@ -488,6 +590,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            }
             STAMP()
             if (last) {
                 // epilogue of the finished brick: lane (col, kg) of tile (i, j) holds couts
@@ -526,6 +629,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
             __syncthreads();                               // image of unit u+1 complete, image u free
             STAMP()
         }
+#undef MVSGI_PL_LOADW
+#undef MVSGI_PL_READX
+#undef MVSGI_PL_MFMAS
 #undef MVSGI_CTILES
 #undef MVSGI_LOADW
 #undef MVSGI_READX
@@ -535,12 +641,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
 #undef STAMP
 }
 
-template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false>
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false, bool PLANE = false>
 int launch_bf16x3(ConvArgs a, hipStream_t st) {
     constexpr int ITD = (TD - 1) * (KD == 1 ? 1 : S) + KD, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
     constexpr size_t lds_bytes = (size_t)2 * ITD * ITH * ITW * kVSB;      // double-buffered image
     static_assert(lds_bytes <= 160 * 1024, "LDS images too large");
-    auto kern = conv3d_bf16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS>;
+    auto kern = conv3d_bf16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE>;
     static int wgs_per_cu = 0;       // benign race: idempotent
     if (!wgs_per_cu) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -36,16 +36,19 @@ NORM3D_TYPE: Dict[str, Type[nn.Module]] = {"batch": nn.BatchNorm3d, "instance": 
 class ConvLaunch:
     """Device-resident launch arguments of one BaseConvBlk3d: PyTorch-layout weight, packed
     MFMA weight (or None), per-channel scale/shift (eval BatchNorm3d or bias), stride, slope."""
-    __slots__ = ("w", "wp", "wp_b3", "scale", "shift", "stride", "neg_slope", "cin", "cout", "key")
+    __slots__ = ("w", "wp", "wp_b3", "wp_c16", "scale", "shift", "stride", "neg_slope", "cin", "cout", "key")
 
     def run(self, x_ndhwc: Tensor, res: Optional[Tensor] = None, impl: Optional[int] = None) -> Tensor:
         wp = self.wp
         if impl is None:
             impl = H.CONV_AUTO
             if H.get_conv_mode() == "bf16x3" and self.cin % 16 == 0 and self.cout % 16 == 0:
-                if self.wp_b3 is None:
-                    self.wp_b3 = H.pack_conv_weights_bf16x3(self.w)
-                impl, wp = H.CONV_BF16X3, self.wp_b3
+                if self._c16():
+                    impl, wp = H.CONV_BF16X3_C16, self._wp_c16()
+                else:
+                    if self.wp_b3 is None:
+                        self.wp_b3 = H.pack_conv_weights_bf16x3(self.w)
+                    impl, wp = H.CONV_BF16X3, self.wp_b3
         elif impl == H.CONV_BF16X3:
             if self.wp_b3 is None:
                 self.wp_b3 = H.pack_conv_weights_bf16x3(self.w)
@@ -53,11 +56,23 @@ class ConvLaunch:
         return H.conv3d(x_ndhwc, self.w, wp, self.scale, self.shift, res=res, stride=self.stride,
                         neg_slope=self.neg_slope, impl=impl)
 
+    def _c16(self) -> bool:
+        """Cout == 16, stride 1: the plane-schedule kernel (MVSGI_CONV_BF16X3_C16)."""
+        return self.cout == 16 and self.stride == 1 and self.cin % 16 == 0
+
+    def _wp_c16(self):
+        if getattr(self, "wp_c16", None) is None:
+            self.wp_c16 = H.pack_conv_weights_bf16x3_c16(self.w)
+        return self.wp_c16
+
     def can_fuse_up2(self) -> bool:
         return H.get_conv_mode() == "bf16x3" and self.stride == 1 and self.cin % 16 == 0 and self.cout % 16 == 0
 
     def run_up2(self, x_lowres_ndhwc: Tensor, res: Optional[Tensor] = None) -> Tensor:
         """conv(trilinear_x2(x)) in one launch (mvsgi_conv3d_up2_f32)."""
+        if self._c16():
+            return H.conv3d_up2(x_lowres_ndhwc, self._wp_c16(), self.scale, self.shift, res=res,
+                                neg_slope=self.neg_slope, w_layout=H.CONV_BF16X3_C16)
         if self.wp_b3 is None:
             self.wp_b3 = H.pack_conv_weights_bf16x3(self.w)
         return H.conv3d_up2(x_lowres_ndhwc, self.wp_b3, self.scale, self.shift, res=res, neg_slope=self.neg_slope)
@@ -136,6 +151,7 @@ def lower_conv_block(blk) -> ConvLaunch:
     L.w = w
     L.wp = H.pack_conv_weights(w)
     L.wp_b3 = None
+    L.wp_c16 = None
     L.scale = scale.contiguous()
     L.shift = shift.contiguous()
     L.stride = int(conv.stride[0])

@@ -13,7 +13,7 @@ from . import _lib
 
 import os
 
-CONV_AUTO, CONV_DIRECT, CONV_MFMA, CONV_BF16X3 = 0, 1, 2, 3
+CONV_AUTO, CONV_DIRECT, CONV_MFMA, CONV_BF16X3, CONV_BF16X3_C16 = 0, 1, 2, 3, 4
 
 # Arithmetic of the conv layers: "f32" = exact fp32 MFMA (v_mfma_f32_16x16x4_f32),
 # "bf16x3" = split-bf16 MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate; ~2^-16 per product).
@@ -237,6 +237,19 @@ def pack_conv_weights_bf16x3(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
     return wp
 
 
+def pack_conv_weights_bf16x3_c16(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
+    """[16, Cin, 3, 3, 3] -> plane-schedule split-bf16 layout (impl CONV_BF16X3_C16), or None when unsupported."""
+    lib = _lib.load()
+    w = _dev(w_oidhw, "conv weight")
+    Cout, Cin = w.shape[:2]
+    if tuple(w.shape[2:]) != (3, 3, 3) or Cin % 16 or Cout != 16:
+        return None
+    wp = torch.empty(lib.mvsgi_conv3d_packed_weight_bytes_bf16x3_c16(Cin), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.mvsgi_conv3d_pack_weights_bf16x3_c16(w.data_ptr(), wp.data_ptr(), Cin, _stream_ptr(w)),
+               "mvsgi_conv3d_pack_weights_bf16x3_c16")
+    return wp
+
+
 def conv3d(x, w_oidhw, w_packed, scale, shift, res=None, stride=1, neg_slope=0.01, impl=CONV_AUTO, out=None):
     """x [B, D, H, W, Cin] -> y [B, Do, Ho, Wo, Cout] = act(conv(x) * scale + shift (+ res));
     act(v) = v if v > 0 else v * neg_slope (1.0 = no activation)."""
@@ -256,8 +269,9 @@ def conv3d(x, w_oidhw, w_packed, scale, shift, res=None, stride=1, neg_slope=0.0
     return y
 
 
-def conv3d_up2(x, w_packed_b3, scale, shift, res=None, neg_slope=0.01, out=None):
-    """Fused trilinear x2 upsample + conv3d (split-bf16): x [B, Dl, Hl, Wl, Cin] -> y [B, 2Dl, 2Hl, 2Wl, Cout]."""
+def conv3d_up2(x, w_packed_b3, scale, shift, res=None, neg_slope=0.01, out=None, w_layout=CONV_BF16X3):
+    """Fused trilinear x2 upsample + conv3d (split-bf16): x [B, Dl, Hl, Wl, Cin] -> y [B, 2Dl, 2Hl, 2Wl, Cout].
+    w_layout: CONV_BF16X3 (pack_conv_weights_bf16x3) or CONV_BF16X3_C16 (pack_conv_weights_bf16x3_c16, Cout == 16)."""
     lib = _lib.load()
     x = _dev(x, "x")
     B, Dl, Hl, Wl, Cin = x.shape
@@ -268,15 +282,15 @@ def conv3d_up2(x, w_packed_b3, scale, shift, res=None, neg_slope=0.01, out=None)
         if tuple(res.shape) != shp:
             raise AssertionError(f"residual {tuple(res.shape)} does not match output {shp}")
     y = out if out is not None else torch.empty(shp, device=x.device, dtype=torch.float32)
-    _lib.check(lib.mvsgi_conv3d_up2_f32(x.data_ptr(), _ptr(w_packed_b3), scale.data_ptr(), shift.data_ptr(), _ptr(res),
+    _lib.check(lib.mvsgi_conv3d_up2_f32(x.data_ptr(), _ptr(w_packed_b3), w_layout, scale.data_ptr(), shift.data_ptr(), _ptr(res),
                                         y.data_ptr(), B, Cin, Dl, Hl, Wl, Cout, float(neg_slope), _stream_ptr(x)),
                "mvsgi_conv3d_up2_f32")
     return y
 
 
-def conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout) -> str:
+def conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, w_layout=CONV_BF16X3) -> str:
     lib = _lib.load()
-    name = lib.mvsgi_conv3d_up2_variant_f32(B, Cin, Dl, Hl, Wl, Cout)
+    name = lib.mvsgi_conv3d_up2_variant_f32(B, Cin, Dl, Hl, Wl, Cout, w_layout)
     if name is None:
         raise RuntimeError("mvsgi_conv3d_up2_variant_f32: " + lib.mvsgi_last_error().decode())
     return name.decode()

@@ -119,6 +119,8 @@ CONV_SHAPES = [
     (1, 128, 128, 2, 5, 9, 1, True, 0.01),
     (1, 128, 64, 4, 6, 8, 1, True, 0.01),       # up conv + skip
     (1, 32, 16, 6, 10, 12, 1, False, 0.01),     # out_costs.0
+    (2, 16, 16, 9, 7, 37, 1, True, 0.01),       # Cout 16 with residual, ragged in every axis
+    (1, 64, 16, 4, 8, 32, 1, False, 0.0),       # 4 slices into 16 couts
     (1, 48, 48, 4, 8, 12, 1, False, 0.01),      # concat builder post_vol (3 cout tiles)
     (1, 48, 96, 4, 8, 12, 2, False, 0.01),
     (1, 96, 96, 3, 6, 10, 1, True, 0.0),        # ReLU
@@ -176,6 +178,12 @@ def test_conv3d_bf16x3_vs_oracle(shape):
     y = H.conv3d(xg, wg, wp, _g(scale), _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3)
     err = _rel(_ncdhw(y), yref)
     assert err <= 1e-4, err
+    if Cout == 16 and stride == 1:       # the plane-schedule kernel of the Cout == 16 layers
+        assert "true>" in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3_C16)
+        yp = H.conv3d(xg, wg, H.pack_conv_weights_bf16x3_c16(wg), _g(scale), _g(shift), res=rg, stride=stride,
+                      neg_slope=slope, impl=H.CONV_BF16X3_C16)
+        assert _rel(_ncdhw(yp), yref) <= 1e-4
+        assert _rel(_ncdhw(yp), _ncdhw(y)) <= 2e-6      # same products, different summation order
 
 
 @pytest.mark.parametrize("shape", [
@@ -209,6 +217,11 @@ def test_conv3d_fused_upsample_vs_interpolate_then_conv(shape):
     got = H.conv3d_up2(xg, H.pack_conv_weights_bf16x3(_g(w)), _g(scale), _g(shift), res=rg, neg_slope=0.01)
     assert "true" in H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout)
     assert _rel(_ncdhw(got), yref) <= 1e-4
+    if Cout == 16:
+        assert "true, true>" in H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, H.CONV_BF16X3_C16)
+        gp = H.conv3d_up2(xg, H.pack_conv_weights_bf16x3_c16(_g(w)), _g(scale), _g(shift), res=rg, neg_slope=0.01,
+                          w_layout=H.CONV_BF16X3_C16)
+        assert _rel(_ncdhw(gp), yref) <= 1e-4
     # and the two-launch path it replaces
     two = H.conv3d(H.resize_trilinear(xg, (2 * Dl, 2 * Hl, 2 * Wl)), _g(w), H.pack_conv_weights_bf16x3(_g(w)),
                    _g(scale), _g(shift), res=rg, neg_slope=0.01, impl=H.CONV_BF16X3)
