@@ -190,7 +190,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
             int lo_d[NITU], lo_h[NITU], lo_w[NITU];             // lower low-res corner of the cell (may be -1)
             unsigned inmask[NITU];                              // bit axis*2+k: upsampled voxel k of the cell is inside
             const float* xb = a.x;
-            f32x4 cr[NITU][8];
+            f32x4 crA[NITU][8], crB[NITU][8];                  // two register sets: loads run two units ahead
+            unsigned imA[NITU], imB[NITU];
 #define MVSGI_PLAN_UPS(UNIT)                                                                            \
             {                                                                                           \
                 int cb_, b_, od_, oh_, ow_;                                                             \
@@ -210,8 +211,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                 xb = a.x + (long long)b_ * Dl * Hl * Wl * a.Cin;                                        \
             }
 #define MVSGI_CLAMP(V, N) ((V) < 0 ? 0 : ((V) > (N) - 1 ? (N) - 1 : (V)))
-#define MVSGI_STAGE_UPS(CC, DST)                                                                        \
+            int k2 = 0, cc2 = 0;                               // next unit to request, in walking order
+#define MVSGI_ISSUE_UPS(CR, IM)                                                                         \
             {                                                                                           \
+                if (cc2 == 0 && k2 > 0) { MVSGI_PLAN_UPS((int)blockIdx.x + k2 * G) }                    \
                 _Pragma("unroll") for (int it = 0; it < NITU; ++it) {                                   \
                     const int e = ptid + it * 256;                                                      \
                     const int q = e & 3;                                                                \
@@ -219,12 +222,17 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                     const int d0 = live ? MVSGI_CLAMP(lo_d[it], Dl) : 0, d1 = live ? MVSGI_CLAMP(lo_d[it] + 1, Dl) : 0; \
                     const int h0 = live ? MVSGI_CLAMP(lo_h[it], Hl) : 0, h1 = live ? MVSGI_CLAMP(lo_h[it] + 1, Hl) : 0; \
                     const int w0 = live ? MVSGI_CLAMP(lo_w[it], Wl) : 0, w1 = live ? MVSGI_CLAMP(lo_w[it] + 1, Wl) : 0; \
-                    const int cofs = (CC) * 16 + q * 4;                                                 \
+                    const int cofs = cc2 * 16 + q * 4;                                                  \
                     _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                     \
                         const int dd = (k & 4) ? d1 : d0, hh = (k & 2) ? h1 : h0, ww = (k & 1) ? w1 : w0; \
-                        cr[it][k] = *reinterpret_cast<const f32x4*>(xb + ((dd * Hl + hh) * Wl + ww) * a.Cin + cofs); \
+                        CR[it][k] = *reinterpret_cast<const f32x4*>(xb + ((dd * Hl + hh) * Wl + ww) * a.Cin + cofs); \
                     }                                                                                   \
+                    IM[it] = inmask[it];                                                                \
                 }                                                                                       \
+                if (++cc2 == nchunks) { cc2 = 0; ++k2; }                                                \
+            }
+#define MVSGI_PUT_UPS(CR, IM, DST)                                                                      \
+            {                                                                                           \
                 _Pragma("unroll") for (int it = 0; it < NITU; ++it) {                                   \
                     const int e = ptid + it * 256;                                                      \
                     if (e < NC * 4) {                                                                   \
@@ -233,8 +241,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                         /* separable blend: along W, then H, then D; index bit = upsampled voxel 0 / 1 of the cell */ \
                         f32x4 xw[4][2], xh[2][2][2];                                                    \
                         _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                 \
-                            xw[k][0] = cr[it][2 * k] * 0.75f + cr[it][2 * k + 1] * 0.25f;               \
-                            xw[k][1] = cr[it][2 * k] * 0.25f + cr[it][2 * k + 1] * 0.75f;               \
+                            xw[k][0] = CR[it][2 * k] * 0.75f + CR[it][2 * k + 1] * 0.25f;               \
+                            xw[k][1] = CR[it][2 * k] * 0.25f + CR[it][2 * k + 1] * 0.75f;               \
                         }                                                                               \
                         _Pragma("unroll") for (int kd = 0; kd < 2; ++kd)                                \
                             _Pragma("unroll") for (int kw = 0; kw < 2; ++kw) {                          \
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                                 _Pragma("unroll") for (int kw = 0; kw < 2; ++kw) {                      \
                                     const float fa = kd ? 0.25f : 0.75f, fb = kd ? 0.75f : 0.25f;       \
                                     const f32x4 xv4 = xh[0][kh][kw] * fa + xh[1][kh][kw] * fb;          \
-                                    const bool ok = ((inmask[it] >> kd) & (inmask[it] >> (2 + kh)) & (inmask[it] >> (4 + kw)) & 1u) != 0; \
+                                    const bool ok = ((IM[it] >> kd) & (IM[it] >> (2 + kh)) & (IM[it] >> (4 + kw)) & 1u) != 0; \
                                     bf16x4 hi, lo;                                                      \
                                     _Pragma("unroll") for (int k = 0; k < 4; ++k) {                     \
                                         const float xv = ok ? xv4[k] : 0.f;                             \
@@ -263,33 +271,39 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
             }
             STAMP()
             MVSGI_PLAN_UPS((int)blockIdx.x)
-            MVSGI_STAGE_UPS(0, ldsb)
+            MVSGI_ISSUE_UPS(crA, imA)                          // unit 0
+            MVSGI_PUT_UPS(crA, imA, ldsb)
+            if (1 < U) MVSGI_ISSUE_UPS(crA, imA)               // unit 1 in flight
             STAMP()
             __syncthreads();                                   // image 0 holds unit 0
             STAMP()
-            int k = 0, cc = 0;
-            for (int u = 0; u < U; ++u) {
-                int ncc = cc + 1, nk = k;
-                if (ncc == nchunks) { ncc = 0; nk = k + 1; }
-                if (u + 1 < U) {
-                    if (ncc == 0) { MVSGI_PLAN_UPS((int)blockIdx.x + nk * G) }
-                    unsigned char* dst = ldsb + ((u + 1) & 1) * BUF;
-                    MVSGI_STAGE_UPS(ncc, dst)
-                }
-                cc = ncc;
-                k = nk;
+            for (int u = 0; u < U; u += 2) {
+                if (u + 2 < U) MVSGI_ISSUE_UPS(crB, imB)
+                if (u + 1 < U) MVSGI_PUT_UPS(crA, imA, ldsb + ((u + 1) & 1) * BUF)
                 STAMP()
                 __syncthreads();
                 STAMP()
+                if (u + 1 < U) {
+                    if (u + 3 < U) MVSGI_ISSUE_UPS(crA, imA)
+                    if (u + 2 < U) MVSGI_PUT_UPS(crB, imB, ldsb + ((u + 2) & 1) * BUF)
+                    STAMP()
+                    __syncthreads();
+                    STAMP()
+                }
             }
+#undef MVSGI_ISSUE_UPS
+#undef MVSGI_PUT_UPS
 #undef MVSGI_PLAN_UPS
-#undef MVSGI_STAGE_UPS
 #undef MVSGI_CLAMP
         } else {
         int goff[NIT];
-        unsigned okmask = 0;
+        unsigned okmask = 0, okA = 0, okB = 0;
         const float* xb = a.x;
-        f32x4 pre[NIT];
+        // Two register sets: the loads of unit u+2 are requested BEFORE the loads of unit u+1 are waited
+        // for, split and written, so an HBM / L2 round trip overlaps a whole unit period instead of being
+        // exposed once per unit (stamps: a staged unit took ~8k ticks of which ~5k were that wait, which made
+        // the Cout == 16 layers producer-bound).
+        f32x4 preA[NIT], preB[NIT];
         // staging plan of a brick: item e = ptid + it*256 -> (halo voxel e>>2, channel quad e&3);
         // padding / surplus items read a valid dummy address and are zeroed by a select (a branch
         // per load would make hipcc wait for each one in turn)
@@ -311,19 +325,27 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
             }                                                                                           \
             xb = a.x + (long long)b_ * a.Din * a.Hin * a.Win * a.Cin;                                   \
         }
-#define MVSGI_STAGE(CC, DST)                                                                            \
+        // request the next unit in walking order (k2, cc2) into a register set; the plan moves on with it
+        int k2 = 0, cc2 = 0;
+#define MVSGI_ISSUE(PRE, OK)                                                                            \
         {                                                                                               \
+            if (cc2 == 0 && k2 > 0) { MVSGI_PLAN((int)blockIdx.x + k2 * G) }                            \
             _Pragma("unroll") for (int it = 0; it < NIT; ++it)                                          \
-                pre[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xb) +           \
-                                                          (unsigned)((goff[it] + (CC) * 16) * 4));      \
+                PRE[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xb) +           \
+                                                          (unsigned)((goff[it] + cc2 * 16) * 4));       \
+            OK = okmask;                                                                                \
+            if (++cc2 == nchunks) { cc2 = 0; ++k2; }                                                    \
+        }
+#define MVSGI_PUT(PRE, OK, DST)                                                                         \
+        {                                                                                               \
             _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                        \
                 const int e = ptid + it * 256;                                                          \
                 if (e < IV * 4) {                                                                       \
                     const int v = e >> 2, q = e & 3;                                                    \
-                    const bool ok = (okmask >> it) & 1u;                                                \
+                    const bool ok = ((OK) >> it) & 1u;                                                  \
                     bf16x4 hi, lo;                                                                      \
                     _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                     \
-                        const float xv = ok ? pre[it][k] : 0.f;                                         \
+                        const float xv = ok ? PRE[it][k] : 0.f;                                         \
                         const __bf16 h = (MVSGI_ABL & 4) ? __builtin_bit_cast(__bf16, (unsigned short)(__builtin_bit_cast(unsigned, xv) >> 16)) : (__bf16)xv; \
                         hi[k] = h;                                                                      \
                         lo[k] = (MVSGI_ABL & 4) ? h : (__bf16)(xv - (float)h);                          \
@@ -335,27 +357,34 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
         }
         STAMP()
         MVSGI_PLAN((int)blockIdx.x)
-        MVSGI_STAGE(0, ldsb)
+        MVSGI_ISSUE(preA, okA)                             // unit 0
+        MVSGI_PUT(preA, okA, ldsb)
+        if (1 < U && !(MVSGI_ABL & 8)) MVSGI_ISSUE(preA, okA)      // unit 1 in flight
         STAMP()
         __syncthreads();                                   // image 0 holds unit 0
         STAMP()
-        int k = 0, cc = 0;                                 // (brick ordinal, slice) of the unit being multiplied
-        for (int u = 0; u < U; ++u) {
-            int ncc = cc + 1, nk = k;
-            if (ncc == nchunks) { ncc = 0; nk = k + 1; }
-            if (u + 1 < U && !(MVSGI_ABL & 8)) {
-                if (ncc == 0) { MVSGI_PLAN((int)blockIdx.x + nk * G) }
-                unsigned char* dst = ldsb + ((u + 1) & 1) * BUF;
-                MVSGI_STAGE(ncc, dst)
+        for (int u = 0; u < U; u += 2) {
+            // set A holds unit u+1 (in flight); request u+2 into B, then finish u+1
+            if (!(MVSGI_ABL & 8)) {
+                if (u + 2 < U) MVSGI_ISSUE(preB, okB)
+                if (u + 1 < U) MVSGI_PUT(preA, okA, ldsb + ((u + 1) & 1) * BUF)
             }
-            cc = ncc;
-            k = nk;
             STAMP()
             __syncthreads();                               // unit u multiplied, image of unit u+1 complete
             STAMP()
+            if (u + 1 < U) {
+                if (!(MVSGI_ABL & 8)) {
+                    if (u + 3 < U) MVSGI_ISSUE(preA, okA)
+                    if (u + 2 < U) MVSGI_PUT(preB, okB, ldsb + ((u + 2) & 1) * BUF)
+                }
+                STAMP()
+                __syncthreads();
+                STAMP()
+            }
         }
+#undef MVSGI_ISSUE
+#undef MVSGI_PUT
 #undef MVSGI_PLAN
-#undef MVSGI_STAGE
         }
     } else {
         // =========================== consumers: LDS + L2 weights -> MFMA ===========================
