@@ -193,6 +193,23 @@ int mvsgi_softargmin_div_f32(const float* costs, const float* inv_idx, float* in
 int mvsgi_ncv_to_nvc_f32(const float* x, float* y, int B, int C, long long V, mvsgi_stream_t stream);
 int mvsgi_nvc_to_ncv_f32(const float* x, float* y, int B, int C, long long V, mvsgi_stream_t stream);
 
+/* ---- sampling-grid generator ---------------------------------------
+ * The closed forms of dsta_mvs/support/dataset/torch_cuda_sweep.py, composed as
+ * MultiViewCameraModelDataset.make_sweep_grid_cuda does (support/dataset/multi_view_camera_model_dataset.py:474-521):
+ *   rays   = RayMaker_UEPanorama.make_rays_for_candidates        (:76-132)   [3][N][H][W]
+ *   points = transform_3D_points_torch(inverse camera pose, rays) (:385-408)  [B][3][M]
+ *   grid, mask = DoubleSphereSampleGridMaker.make_grid(points)    (:262-298)  [B][M][2], [B][M] u8
+ *   grid       = EquirectangularSampleGridMaker.make_grid(points) (:305-335)  [B][M][2]
+ * fp32, operation order of the reference's torch expressions.  Run once per rig. */
+int mvsgi_rays_panorama_f32(const float* dist, float* rays, int N, int H, int W,
+                            float lat0, float lat1, float lon0, float lon1, mvsgi_stream_t stream);
+int mvsgi_transform_points_f32(const float* T /* [B][4][4] */, const float* points, float* out,
+                               int B, long long M, mvsgi_stream_t stream);
+int mvsgi_grid_double_sphere_f32(const float* points, float* grid, unsigned char* mask, int B, long long M,
+                                 float xi, float alpha, float fx, float fy, float cx, float cy,
+                                 int calib_h, int calib_w, float w2, mvsgi_stream_t stream);
+int mvsgi_grid_equirect_f32(const float* points, float* grid, int B, long long M, mvsgi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

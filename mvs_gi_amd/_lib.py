@@ -50,6 +50,10 @@ SIGNATURES = {
     "mvsgi_resize_trilinear_f32": (c_int, [_P, _P] + [c_int] * 8 + [_P]),
     "mvsgi_softargmin_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
     "mvsgi_softargmin_div_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [c_float, _P]),
+    "mvsgi_rays_panorama_f32": (c_int, [_P, _P, c_int, c_int, c_int] + [c_float] * 4 + [_P]),
+    "mvsgi_transform_points_f32": (c_int, [_P, _P, _P, c_int, c_longlong, _P]),
+    "mvsgi_grid_double_sphere_f32": (c_int, [_P, _P, _P, c_int, c_longlong] + [c_float] * 6 + [c_int, c_int, c_float, _P]),
+    "mvsgi_grid_equirect_f32": (c_int, [_P, _P, c_int, c_longlong, _P]),
     "mvsgi_ncv_to_nvc_f32": (c_int, [_P, _P, c_int, c_int, c_longlong, _P]),
     "mvsgi_nvc_to_ncv_f32": (c_int, [_P, _P, c_int, c_int, c_longlong, _P]),
 }

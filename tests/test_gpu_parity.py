@@ -548,3 +548,47 @@ def test_inference_pipeline_uint8_in_metric_out(golden_dir, conv_mode):
     err = _rel(out, z["inv_dist_over_bf"])
     print(f"pipeline u8 [{conv_mode}]: max-rel {err:.3e}")
     assert err <= 1e-3
+
+
+# ------------------------------------------------------------------ sampling-grid generator
+def test_sweep_grid_generator_vs_reference_goldens(golden_dir):
+    """HIP closed forms (dropin/sweep_grids.py, reference class names) vs the reference's own outputs.
+    Tolerances: device sin/cos/atan2/sqrt are within ~2 ulp of the host libm; projections are compared
+    where they are well conditioned (inside the field of view, away from the atan2 branch cut)."""
+    from mvs_gi_amd.dropin import sweep_grids as SG
+    z = _load(golden_dir, "sweep_grids")
+    for name in ("g16", "e8_full_sphere"):
+        shape = tuple(int(v) for v in z[name + "_shape"])
+        rm = SG.RayMaker_UEPanorama(z[name + "_dist"], tuple(z[name + "_lon"]), tuple(z[name + "_lat"]), device=DEV)
+        rays = rm.make_rays_for_candidates(shape)
+        ref_rays = z[name + "_rays"]
+        assert rays.shape == ref_rays.shape and _rel(rays.cpu().numpy(), ref_rays) <= 2e-6
+        ds, eq = SG.DoubleSphereSampleGridMaker(), SG.EquirectangularSampleGridMaker()
+        for i, pose in enumerate(z[name + "_poses"]):
+            inv = torch.linalg.inv(torch.from_numpy(pose)).to(torch.float32)
+            ref_pts = z[f"{name}_pts{i}"]
+            pts = SG.transform_3D_points_torch(inv.unsqueeze(0).to(DEV), _g(ref_rays).unsqueeze(0))
+            assert _rel(pts.cpu().numpy(), ref_pts) <= 2e-6
+            gp = _g(ref_pts)                                   # projections on the reference's exact points
+            g, m = ds.make_grid(gp)
+            rg, rm_ = z[f"{name}_ds_grid{i}"], z[f"{name}_ds_mask{i}"]
+            x, y, zz = ref_pts[:, 0], ref_pts[:, 1], ref_pts[:, 2]
+            d1 = np.sqrt(x * x + y * y + zz * zz)
+            edge = np.abs(zz + ds.w2 * d1) < 1e-5 * d1        # on the field-of-view boundary either answer is right
+            assert np.array_equal(m.cpu().numpy()[~edge], rm_[~edge])
+            well = rm_ & (np.abs(rg).max(-1) < 4)
+            assert well.sum() > 100 and np.abs(g.cpu().numpy() - rg)[well].max() <= 2e-5
+            e = eq.make_grid(gp).cpu().numpy()
+            cut = (x < 0) & (np.abs(zz) < 1e-4 * np.abs(x))    # atan2 branch cut: u flips between -1 and +1
+            assert np.abs(e - z[f"{name}_eq_grid{i}"])[~cut].max() <= 2e-6
+        # the composed rig call: layout the cv_builder takes
+        grids, gms = SG.make_sweep_grids(rm, [ds] * len(z[name + "_poses"]), list(z[name + "_poses"]), shape)
+        D = len(z[name + "_dist"])
+        assert tuple(grids.shape) == (1, len(z[name + "_poses"]), D, *shape, 2)
+        assert tuple(gms.shape) == (1, len(z[name + "_poses"]), D, *shape, 1) and gms.dtype == torch.bool
+        ok = z[f"{name}_ds_mask0"][0] & (np.abs(z[f"{name}_ds_grid0"][0]).max(-1) < 4)
+        assert np.abs(grids[0, 0].cpu().numpy() - z[f"{name}_ds_grid0"][0])[ok].max() <= 5e-5
+    g2, m2 = SG.DoubleSphereSampleGridMaker(params=[0.1, 0.45, 300.0, 310.0, 320.0, 240.0],
+                                            calib_shape=[480, 640]).make_grid(_g(z["g16_pts1"]))
+    well = z["ds2_mask"] & (np.abs(z["ds2_grid"]).max(-1) < 4)
+    assert np.abs(g2.cpu().numpy() - z["ds2_grid"])[well].max() <= 2e-5

@@ -112,3 +112,24 @@ def test_feature_extractor_and_end_to_end_match_reference(golden_dir):
     t = O.to_torch(inp)
     inv = O.full_model(torch.from_numpy(imgs), t["grids"], t["grid_masks"], t["masks"], wt, cfg.builder, cfg.dist_cands)
     assert _rel(inv.numpy(), z["inv_dist"]) <= 1e-5
+
+
+# ------------------------------------------------------------------ sampling-grid generator
+def test_grid_oracle_matches_reference_closed_forms(golden_dir):
+    """oracle/grid_oracle.py vs outputs of the reference's torch_cuda_sweep.py (tools/make_grid_goldens.py)."""
+    from oracle import grid_oracle as G
+    z = _load(golden_dir, "sweep_grids")
+    for name in ("g16", "e8_full_sphere"):
+        rays = G.rays_panorama(z[name + "_dist"], tuple(z[name + "_lon"]), tuple(z[name + "_lat"]),
+                               tuple(int(v) for v in z[name + "_shape"]))
+        assert np.array_equal(rays.numpy(), z[name + "_rays"])
+        for i, pose in enumerate(z[name + "_poses"]):
+            inv = torch.linalg.inv(torch.from_numpy(pose)).to(torch.float32)
+            pts = G.transform_points(inv.unsqueeze(0), rays.unsqueeze(0))
+            assert np.array_equal(pts.numpy(), z[f"{name}_pts{i}"])
+            g, m = G.grid_double_sphere(pts, (-0.203, 0.589, 232.0, 232.0, 611.5, 513.5), (1028, 1224))
+            assert np.array_equal(g.numpy(), z[f"{name}_ds_grid{i}"]) and np.array_equal(m.numpy(), z[f"{name}_ds_mask{i}"])
+            assert np.array_equal(G.grid_equirect(pts).numpy(), z[f"{name}_eq_grid{i}"])
+    g, m = G.grid_double_sphere(torch.from_numpy(z["g16_pts1"]), (0.1, 0.45, 300.0, 310.0, 320.0, 240.0), (480, 640))
+    assert np.array_equal(g.numpy(), z["ds2_grid"]) and np.array_equal(m.numpy(), z["ds2_mask"])
+    assert abs(G.double_sphere_w2(0.1, 0.45) - float(z["ds2_w2"])) < 1e-15
