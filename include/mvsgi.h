@@ -210,6 +210,20 @@ int mvsgi_grid_double_sphere_f32(const float* points, float* grid, unsigned char
                                  int calib_h, int calib_w, float w2, mvsgi_stream_t stream);
 int mvsgi_grid_equirect_f32(const float* points, float* grid, int B, long long M, mvsgi_stream_t stream);
 
+/* ---- deformable 2-D convolution with a given offset field ------------
+ * SphereConvEquirect2d.forward + SphereConvBlk (common/common_modules.py:411-425, :509-547):
+ *   y = act( deform_conv2d(x, offset, w, stride, padding, dilation) * scale + shift (+ res) )
+ * with torchvision.ops.deform_conv2d's definition (offset channel 2*(i*Kw+j) = dy, +1 = dx of tap (i, j);
+ * bilinear sampling, zero outside the image; no modulation mask).  Channels-last:
+ *   x [N][H][W][Cin], offset [2*Kh*Kw][Ho][Wo] (shared) or [N][2*Kh*Kw][Ho][Wo] (offset_per_image),
+ *   w_packed [Kh*Kw][Cin][Cout] from mvsgi_deform_conv2d_pack_weights_f32, y / res [N][Ho][Wo][Cout]. */
+int mvsgi_deform_conv2d_pack_weights_f32(const float* w_oihw, float* w_packed, int Cout, int Cin, int Kh, int Kw,
+                                         mvsgi_stream_t stream);
+int mvsgi_deform_conv2d_f32(const float* x, const float* offset, int offset_per_image, const float* w_packed,
+                            const float* scale, const float* shift, const float* res, float* y,
+                            int N, int Cin, int H, int W, int Cout, int Kh, int Kw, int stride_h, int stride_w,
+                            int pad_h, int pad_w, int dil_h, int dil_w, float neg_slope, mvsgi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

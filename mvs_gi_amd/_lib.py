@@ -54,6 +54,8 @@ SIGNATURES = {
     "mvsgi_transform_points_f32": (c_int, [_P, _P, _P, c_int, c_longlong, _P]),
     "mvsgi_grid_double_sphere_f32": (c_int, [_P, _P, _P, c_int, c_longlong] + [c_float] * 6 + [c_int, c_int, c_float, _P]),
     "mvsgi_grid_equirect_f32": (c_int, [_P, _P, c_int, c_longlong, _P]),
+    "mvsgi_deform_conv2d_pack_weights_f32": (c_int, [_P, _P] + [c_int] * 4 + [_P]),
+    "mvsgi_deform_conv2d_f32": (c_int, [_P, _P, c_int] + [_P] * 5 + [c_int] * 13 + [c_float, _P]),
     "mvsgi_ncv_to_nvc_f32": (c_int, [_P, _P, c_int, c_int, c_longlong, _P]),
     "mvsgi_nvc_to_ncv_f32": (c_int, [_P, _P, c_int, c_int, c_longlong, _P]),
 }

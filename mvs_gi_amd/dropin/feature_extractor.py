@@ -9,6 +9,7 @@ channels-last strides (storage [B*N, H/4, W/4, chs]), which is exactly what the 
 from __future__ import annotations
 
 import copy
+import math
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -205,3 +206,204 @@ class SimpleFeatExtraction(nn.Module):
                                          norm_layer=self.norm_type(chs))
 
     forward = extractor_forward
+
+
+
+# ------------------------------------------------------------------------------------------
+# the sphere-convolution final layer of the G16VV extractor (config103)
+# ------------------------------------------------------------------------------------------
+def _pair(v):
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+
+
+def sphere_conv_offsets(input_size, kernel_size, stride, padding, dilation, lat_range=(-math.pi / 2, 0),
+                        lon_range=(0, 2 * math.pi)) -> Tensor:
+    """Offset field of SphereConvEquirect2d.gen_offset (common/common_modules.py:427-507): for every output pixel
+    of an equirect image, where the taps of a kernel laid on the tangent plane of the sphere fall, as
+    deform_conv2d offsets [1, 2*Kh*Kw, Ho, Wo] (channel 2*(i*Kw+j) = row offset, +1 = column offset).
+    Same fp32 operation sequence as the reference, evaluated by broadcasting instead of per-latitude loops."""
+    height, width = int(input_size[-2]), int(input_size[-1])
+    Kh, Kw = kernel_size
+    sh, sw = stride
+    dh, dw = dilation
+    lat_dist, lon_dist = lat_range[1] - lat_range[0], lon_range[1] - lon_range[0]
+    lat_center, lon_center = lat_dist / 2 + lat_range[0], lon_dist / 2 + lon_range[0]
+    delta_lat, delta_lon = lat_dist / height, lon_dist / width                                 # :438-439
+    ry = torch.arange(-(Kh // 2), Kh // 2 + 1)
+    rx = torch.arange(-(Kw // 2), Kw // 2 + 1)
+    if Kw % 2 == 0:
+        rx = rx[:-1]
+    if Kh % 2 == 0:
+        ry = ry[:-1]
+    ker_x = torch.tan(rx * dw * delta_lon)                                                      # :452
+    ker_y = torch.tan(ry * dh * delta_lat) / torch.cos(ry * delta_lon)                          # :453 (delta_lon, as upstream)
+    ker_y, ker_x = torch.meshgrid(ker_y, ker_x, indexing="ij")                                  # [Kh, Kw]
+    rho = torch.sqrt(ker_x ** 2 + ker_y ** 2)
+    if Kh % 2 and Kw % 2:
+        rho[Kh // 2][Kw // 2] = 1e-8                                                            # :462-463
+    nu = torch.arctan(rho)
+    cos_nu, sin_nu = torch.cos(nu), torch.sin(nu)
+    h_range = torch.arange(0, height, sh) + 0.5
+    w_range = torch.arange(0, width, sw) + 0.5
+    lat_c = ((h_range / height) - 0.5) * lat_dist + lat_center                                  # [Ho]
+    lon_c = ((w_range / width) - 0.5) * lon_dist + lon_center                                   # [Wo]
+    sl, cl = torch.sin(lat_c)[:, None, None], torch.cos(lat_c)[:, None, None]
+    lat = torch.arcsin(cos_nu * sl + ker_y * sin_nu * cl / rho)                                 # :476  [Ho, Kh, Kw]
+    lon = torch.arctan2(ker_x * sin_nu, (rho * cl * cos_nu - ker_y * sl * sin_nu))              # :483
+    lat = lat[:, None].expand(-1, lon_c.numel(), -1, -1)                                        # [Ho, Wo, Kh, Kw]
+    lon = lon[:, None] + lon_c[None, :, None, None]                                             # :485
+    lat = ((lat - lat_center) / lat_dist + 0.5) * height                                        # :489-490 -> pixels
+    lon = ((lon - lon_center) / lon_dist + 0.5) * width
+    lon = lon % (width - 1)                                                                     # :493 then :495, both as upstream
+    lon = lon % width
+    lat = lat - (h_range[:, None, None, None] - 0.5)                                            # :499-500 -> offsets
+    lon = lon - (w_range[None, :, None, None] - 0.5)
+    ll = torch.stack((lat, lon)).to(torch.float)                                                # [2, Ho, Wo, Kh, Kw]
+    ll = ll.permute(3, 4, 0, 1, 2)                                                              # [Kh, Kw, 2, Ho, Wo]
+    return ll.reshape(1, 2 * Kh * Kw, ll.shape[3], ll.shape[4])
+
+
+class SphereConvEquirect2d(nn.Module):
+    """common/common_modules.py:360-425: Conv2d whose taps follow the sphere; parameters `weight`
+    [Cout, Cin/groups, Kh, Kw], optional `bias`, buffer `offset` (state-dict compatible)."""
+
+    def __init__(self, in_size, in_channels: int, out_channels: int, kernel_size, stride=1, padding=0, dilation=1,
+                 groups: int = 1, bias: bool = True):
+        super().__init__()
+        if in_channels % groups != 0:
+            raise ValueError("in_channels must be divisible by groups")
+        if out_channels % groups != 0:
+            raise ValueError("out_channels must be divisible by groups")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.dilation, self.groups = _pair(padding), _pair(dilation), groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, *self.kernel_size))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.weight)
+            nn.init.uniform_(self.bias, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
+        self.register_buffer("offset", sphere_conv_offsets(in_size, self.kernel_size, self.stride, self.padding,
+                                                           self.dilation))
+
+    def forward(self, input: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+        return _nchw_view(sphere_conv_nhwc(self, _nhwc(input), mask=mask))
+
+
+def _lower_sphere(conv, norm=None, act=None):
+    """Launch record of a SphereConvEquirect2d (+ optional eval BatchNorm2d / activation), cached on the module."""
+    parts = [conv.weight.data_ptr(), conv.weight._version, id(norm), id(act)]
+    if isinstance(norm, nn.BatchNorm2d):
+        parts += [t.data_ptr() + t._version for t in (norm.weight, norm.bias, norm.running_mean, norm.running_var)
+                  if t is not None]
+    key = tuple(parts)
+    cached = conv.__dict__.get("_mvsgi_launch")
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    if getattr(conv, "groups", 1) != 1:
+        raise NotImplementedError("SphereConvEquirect2d with groups != 1 has no HIP implementation")
+    w = conv.weight.detach()
+    if not w.is_cuda:
+        raise RuntimeError("mvs_gi_amd modules run on the GPU only: call .cuda() on the model (there is no CPU fallback)")
+    w = w.float().contiguous()
+    cout = w.shape[0]
+    bias = conv.bias.detach().float() if conv.bias is not None else None
+    if isinstance(norm, nn.BatchNorm2d):
+        if norm.training:
+            raise RuntimeError("HIP path implements eval-mode BatchNorm2d only: call model.eval()")
+        gamma = norm.weight.detach().float() if norm.weight is not None else torch.ones(cout, device=w.device)
+        beta = norm.bias.detach().float() if norm.bias is not None else torch.zeros(cout, device=w.device)
+        alpha = gamma / torch.sqrt(norm.running_var.detach().float() + norm.eps)
+        scale, shift = alpha, beta - norm.running_mean.detach().float() * alpha
+        if bias is not None:
+            shift = shift + bias * alpha
+    elif _is_identity(norm) or norm is None:
+        scale = torch.ones(cout, device=w.device)
+        shift = bias.clone() if bias is not None else torch.zeros(cout, device=w.device)
+    else:
+        raise NotImplementedError(f"norm layer {type(norm).__name__} has no HIP implementation")
+    if isinstance(act, nn.LeakyReLU):
+        slope = float(act.negative_slope)
+    elif isinstance(act, nn.ReLU):
+        slope = 0.0
+    elif _is_identity(act) or act is None:
+        slope = 1.0
+    else:
+        raise NotImplementedError(f"activation {type(act).__name__} has no HIP implementation")
+    rec = dict(wp=H.pack_deform_conv2d_weights(w), scale=scale.contiguous(), shift=shift.contiguous(), slope=slope)
+    conv.__dict__["_mvsgi_launch"] = (key, rec)
+    return rec
+
+
+def sphere_conv_nhwc(conv, x: Tensor, norm=None, act=None, res: Optional[Tensor] = None, mask=None) -> Tensor:
+    if mask is not None:
+        raise NotImplementedError("modulated deform_conv2d (mask) is not on the extractor path")
+    rec = _lower_sphere(conv, norm, act)
+    return H.deform_conv2d(x, conv.offset.float(), rec["wp"], rec["scale"], rec["shift"], _pair(conv.kernel_size),
+                           _pair(conv.stride), _pair(conv.padding), _pair(conv.dilation), res=res,
+                           neg_slope=rec["slope"])
+
+
+def sphere_blk_nhwc(blk, x: Tensor, res: Optional[Tensor] = None) -> Tensor:
+    """SphereConvBlk.forward (:538-547): blk = Sequential(SphereConvEquirect2d, norm); + res; activation."""
+    return sphere_conv_nhwc(blk.blk[0], x, norm=blk.blk[1], act=blk.activation, res=res)
+
+
+class SphereConvBlk(nn.Module):
+    def __init__(self, in_size, in_chs: int, out_chs: int, k_sz: int, stride: int = 1, extra_pad: int = 0,
+                 bias: bool = False, dilation: int = 1, norm_layer: nn.Module = NoOp(), activation: nn.Module = NoOp()):
+        super().__init__()
+        self.activation = activation
+        self.blk = nn.Sequential(
+            SphereConvEquirect2d(in_size=in_size, in_channels=in_chs, out_channels=out_chs, kernel_size=k_sz,
+                                 stride=stride, padding=k_sz // 2 + extra_pad, dilation=dilation, bias=bias),
+            norm_layer)
+
+    def forward(self, x: Tensor, res: Optional[Tensor] = None) -> Tensor:
+        r = None if res is None else _nhwc(res)
+        return _nchw_view(sphere_blk_nhwc(self, _nhwc(x), r))
+
+
+def sphere_extractor_forward(self, x: Tensor) -> Tensor:
+    """SphereEquirectFeatExtraction.forward (feature_extractor/sphere_feature_extractor.py:80-83)."""
+    xin = x if x.dtype == torch.uint8 else H._dev(x, "imgs")
+    y = lower_conv2d_block(self.first).run(xin, in_nchw=True)
+    for blk in self.blks:
+        if hasattr(blk, "blk1"):
+            y = res_block2d_nhwc(blk, y)
+        else:
+            y = lower_conv2d_block(blk).run(y)
+    return _nchw_view(sphere_blk_nhwc(self.final_layer, y))
+
+
+class SphereEquirectFeatExtraction(nn.Module):
+    """feature_extractor/sphere_feature_extractor.py:8-83: SimpleFeatExtraction whose final layer is a SphereConvBlk."""
+
+    def __init__(self, in_size: Tuple[int, int], in_chs=3, chs: int = 8, k_sz: int = 3,
+                 layers: Sequence[int] = [5, 10], norm_type: str = "batch", relu_type: str = "leaky"):
+        super().__init__()
+        self.chs, self.k_sz, self.layers = chs, k_sz, layers
+        self.num_steps = len(layers)
+        self.in_size = in_size
+        self.norm_type = NORM2D_TYPE[norm_type]
+        self.relu_type = RELU_TYPE[relu_type]
+        self.first = BaseConvBlk2d(in_chs=in_chs, out_chs=chs, kernel_size=5, stride=2,
+                                   activation=self.relu_type(), norm_layer=self.norm_type(chs))
+        blks = []
+        for step, n in enumerate(layers):
+            blks += [ResConvBlk2d(in_chs=chs, out_chs=chs, kernel_size=k_sz, activation=self.relu_type(),
+                                  norm_layer=self.norm_type(chs)) for _ in range(n)]
+            if step != self.num_steps - 1:
+                blks.append(BaseConvBlk2d(in_chs=chs, out_chs=chs, kernel_size=3, stride=2,
+                                          activation=self.relu_type(), norm_layer=self.norm_type(chs)))
+        self.blks = nn.Sequential(*blks)
+        size = self.first.infer_size(self.in_size)
+        for layer in self.blks:
+            size = layer.infer_size(size)
+        self.final_layer = SphereConvBlk(in_size=size, in_chs=chs, out_chs=chs, k_sz=k_sz,
+                                         activation=self.relu_type(), norm_layer=self.norm_type(chs))
+
+    forward = sphere_extractor_forward

@@ -66,7 +66,7 @@ def _install_aliases():
     dr = _pkg("dsta_mvs.model.distance_regressor")
     _export(dr, _dr, ["DistanceRegressorWithFixedCandidates"])
     fe = _pkg("dsta_mvs.model.feature_extractor")
-    _export(fe, _fe, ["SimpleFeatExtraction"])
+    _export(fe, _fe, ["SimpleFeatExtraction", "SphereEquirectFeatExtraction"])
     mm = _pkg("dsta_mvs.model.mvs_model")
     _export(mm, _to, ["SphericalSweepStereoBase"])
     mods.update({"dsta_mvs": root, "dsta_mvs.model": model, "dsta_mvs.model.common": common,
@@ -74,9 +74,10 @@ def _install_aliases():
                  "dsta_mvs.model.distance_regressor": dr, "dsta_mvs.model.mvs_model": mm,
                  "dsta_mvs.model.feature_extractor": fe})
     fe.simple_feature_extractor = leaf("dsta_mvs.model.feature_extractor.simple_feature_extractor", _fe)
+    fe.sphere_feature_extractor = leaf("dsta_mvs.model.feature_extractor.sphere_feature_extractor", _fe)
 
     common.common_modules = leaf("dsta_mvs.model.common.common_modules", _cm)
-    for n in ("BaseConvBlk2d", "ResConvBlk2d"):      # the 2-D blocks live in common_modules upstream
+    for n in ("BaseConvBlk2d", "ResConvBlk2d", "SphereConvEquirect2d", "SphereConvBlk"):   # 2-D blocks live in common_modules upstream
         setattr(common.common_modules, n, getattr(_fe, n))
     cvb.spherical_sweep_avg = leaf("dsta_mvs.model.cost_volume_builder.spherical_sweep_avg", _cvb)
     cvb.spherical_sweep = leaf("dsta_mvs.model.cost_volume_builder.spherical_sweep", _cvb)
@@ -116,6 +117,10 @@ def _patch_reference():
     rebind(c.ResConvBlk2d, forward=_fe.ResConvBlk2d.forward)
     f = importlib.import_module("dsta_mvs.model.feature_extractor.simple_feature_extractor")
     rebind(f.SimpleFeatExtraction, forward=_fe.extractor_forward)
+    rebind(c.SphereConvEquirect2d, forward=_fe.SphereConvEquirect2d.forward)
+    rebind(c.SphereConvBlk, forward=_fe.SphereConvBlk.forward)
+    fs = importlib.import_module("dsta_mvs.model.feature_extractor.sphere_feature_extractor")
+    rebind(fs.SphereEquirectFeatExtraction, forward=_fe.sphere_extractor_forward)
     _state["saved"] = saved
 
 

@@ -425,3 +425,44 @@ def as_ndhwc(vol: torch.Tensor) -> torch.Tensor:
     if v.is_contiguous():
         return v
     return ncdhw_to_ndhwc(vol.contiguous())
+
+
+# --------------------------------------------------------------------------------------
+def pack_deform_conv2d_weights(w_oihw: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, Kh, Kw] -> [Kh*Kw, Cin, Cout] for mvsgi_deform_conv2d_f32."""
+    lib = _lib.load()
+    w = _dev(w_oihw, "deform conv weight")
+    Cout, Cin, Kh, Kw = w.shape
+    wp = torch.empty((Kh * Kw, Cin, Cout), device=w.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_deform_conv2d_pack_weights_f32(w.data_ptr(), wp.data_ptr(), Cout, Cin, Kh, Kw, _stream_ptr(w)),
+               "mvsgi_deform_conv2d_pack_weights_f32")
+    return wp
+
+
+def deform_conv2d(x_nhwc, offset, w_packed, scale, shift, kernel_size, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
+                  res=None, neg_slope=1.0) -> torch.Tensor:
+    """x [N, H, W, Cin], offset [1 | N, 2*Kh*Kw, Ho, Wo] -> y [N, Ho, Wo, Cout] (torchvision.ops.deform_conv2d
+    semantics + per-channel scale / shift, residual, LeakyReLU)."""
+    lib = _lib.load()
+    x = _dev(x_nhwc, "x")
+    offset = _dev(offset, "offset")
+    N, Hh, W, Cin = x.shape
+    Kh, Kw = kernel_size
+    Cout = scale.numel()
+    Ho = (Hh + 2 * padding[0] - (dilation[0] * (Kh - 1) + 1)) // stride[0] + 1
+    Wo = (W + 2 * padding[1] - (dilation[1] * (Kw - 1) + 1)) // stride[1] + 1
+    if offset.dim() != 4 or tuple(offset.shape[1:]) != (2 * Kh * Kw, Ho, Wo) or offset.shape[0] not in (1, N):
+        raise AssertionError(f"offset {tuple(offset.shape)} does not match [1|{N}, {2 * Kh * Kw}, {Ho}, {Wo}]")
+    if tuple(w_packed.shape) != (Kh * Kw, Cin, Cout):
+        raise AssertionError(f"w_packed {tuple(w_packed.shape)} does not match {(Kh * Kw, Cin, Cout)}")
+    if res is not None:
+        res = _dev(res, "res")
+        if tuple(res.shape) != (N, Ho, Wo, Cout):
+            raise AssertionError(f"residual {tuple(res.shape)} does not match output {(N, Ho, Wo, Cout)}")
+    y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_deform_conv2d_f32(x.data_ptr(), offset.data_ptr(), int(offset.shape[0] == N and N > 1),
+                                           w_packed.data_ptr(), scale.data_ptr(), shift.data_ptr(), _ptr(res),
+                                           y.data_ptr(), N, Cin, Hh, W, Cout, Kh, Kw, stride[0], stride[1], padding[0],
+                                           padding[1], dilation[0], dilation[1], float(neg_slope), _stream_ptr(x)),
+               "mvsgi_deform_conv2d_f32")
+    return y

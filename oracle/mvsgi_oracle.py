@@ -215,6 +215,86 @@ def feature_extractor(imgs: Tensor, p: Dict[str, Tensor], layers: Sequence[int] 
     return conv_block2d(x, p, "final_layer")
 
 
+# ----------------------------------------------------------------------------
+# sphere-convolution final layer.  PARITY UNPINNED for deform_conv2d itself:
+# torchvision (the reference's dependency for this operator) is neither vendored in /root/reference nor
+# installed in the build container, so the operator is restated from its published definition (Dai et al.,
+# "Deformable Convolutional Networks", 2017; torchvision/csrc/ops/cpu/deform_conv2d_kernel.cpp) and anchored
+# by the identities the tests check (zero offsets == F.conv2d, integer offsets == shifted taps).  The offset
+# field IS pinned: the reference's own gen_offset output is a golden (tests/golden/sphere_offsets.npz).
+# ----------------------------------------------------------------------------
+def deform_conv2d(x: Tensor, offset: Tensor, w: Tensor, bias: Optional[Tensor] = None, stride=(1, 1),
+                  padding=(0, 0), dilation=(1, 1)) -> Tensor:
+    """torchvision.ops.deform_conv2d(input, offset, weight, bias, stride, padding, dilation, mask=None), as
+    SphereConvEquirect2d.forward calls it (common_modules.py:411-425).  x [N, Cin, H, W], offset [N, 2*Kh*Kw,
+    Ho, Wo] (channel 2k = dy, 2k+1 = dx of tap k = i*Kw + j), w [Cout, Cin, Kh, Kw]."""
+    N, Cin, H, W = x.shape
+    Cout, _, Kh, Kw = w.shape
+    Ho = (H + 2 * padding[0] - (dilation[0] * (Kh - 1) + 1)) // stride[0] + 1
+    Wo = (W + 2 * padding[1] - (dilation[1] * (Kw - 1) + 1)) // stride[1] + 1
+    offset = offset.expand(N, -1, -1, -1)
+    ho = torch.arange(Ho, dtype=torch.float32).view(1, Ho, 1)
+    wo = torch.arange(Wo, dtype=torch.float32).view(1, 1, Wo)
+    xf = x.reshape(N, Cin, H * W)
+    cols = []
+    for i in range(Kh):
+        for j in range(Kw):
+            k = i * Kw + j
+            y = ho * stride[0] - padding[0] + i * dilation[0] + offset[:, 2 * k]            # [N, Ho, Wo]
+            xx = wo * stride[1] - padding[1] + j * dilation[1] + offset[:, 2 * k + 1]
+            inside = ~((y <= -1) | (y >= H) | (xx <= -1) | (xx >= W))
+            yl, xl = torch.floor(y), torch.floor(xx)
+            ly, lx = y - yl, xx - xl
+            hy, hx = 1 - ly, 1 - lx
+            yl, xl = yl.long(), xl.long()
+            yh, xh = yl + 1, xl + 1
+
+            def corner(yy, xc, ok):
+                ok = ok & inside
+                idx = (yy.clamp(0, H - 1) * W + xc.clamp(0, W - 1)).view(N, 1, Ho * Wo).expand(-1, Cin, -1)
+                v = torch.gather(xf, 2, idx).view(N, Cin, Ho, Wo)
+                return torch.where(ok.unsqueeze(1), v, torch.zeros((), dtype=x.dtype))
+            v1 = corner(yl, xl, (yl >= 0) & (xl >= 0))
+            v2 = corner(yl, xh, (yl >= 0) & (xh <= W - 1))
+            v3 = corner(yh, xl, (yh <= H - 1) & (xl >= 0))
+            v4 = corner(yh, xh, (yh <= H - 1) & (xh <= W - 1))
+            cols.append((hy * hx).unsqueeze(1) * v1 + (hy * lx).unsqueeze(1) * v2 + (ly * hx).unsqueeze(1) * v3 +
+                        (ly * lx).unsqueeze(1) * v4)
+    col = torch.stack(cols, dim=2)                                     # [N, Cin, K, Ho, Wo]
+    out = torch.einsum("ock,nckhw->nohw", w.reshape(Cout, Cin, Kh * Kw), col)
+    if bias is not None:
+        out = out + bias.view(1, -1, 1, 1)
+    return out
+
+
+def sphere_block2d(x: Tensor, p: Dict[str, Tensor], prefix: str, res: Optional[Tensor] = None) -> Tensor:
+    """SphereConvBlk.forward (common_modules.py:538-547) with the extractor's settings (k 3, stride 1, padding 1,
+    eval BatchNorm2d, LeakyReLU): state-dict keys {prefix}.blk.0.{weight,offset[,bias]}, {prefix}.blk.1.*."""
+    w = p[f"{prefix}.blk.0.weight"]
+    k = w.shape[-1]
+    y = deform_conv2d(x, p[f"{prefix}.blk.0.offset"], w, p.get(f"{prefix}.blk.0.bias"), padding=(k // 2, k // 2))
+    y = F.batch_norm(y, p[f"{prefix}.blk.1.running_mean"], p[f"{prefix}.blk.1.running_var"],
+                     p[f"{prefix}.blk.1.weight"], p[f"{prefix}.blk.1.bias"], training=False, eps=BN_EPS)
+    if res is not None:
+        y = y + res
+    return F.leaky_relu(y, LRELU_SLOPE)
+
+
+def sphere_feature_extractor(imgs: Tensor, p: Dict[str, Tensor], layers: Sequence[int] = (5, 10)) -> Tensor:
+    """SphereEquirectFeatExtraction.forward (feature_extractor/sphere_feature_extractor.py:80-83)."""
+    x = conv_block2d(imgs, p, "first", stride=2)
+    i = 0
+    for step, n in enumerate(layers):
+        for _ in range(n):
+            r = conv_block2d(x, p, f"blks.{i}.blk1")
+            x = conv_block2d(r, p, f"blks.{i}.blk2", res=x)
+            i += 1
+        if step != len(layers) - 1:
+            x = conv_block2d(x, p, f"blks.{i}", stride=2)
+            i += 1
+    return sphere_block2d(x, p, "final_layer")
+
+
 def full_model(imgs: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor, weights, builder: str,
                dist_cands: Sequence[float], **kw) -> Tensor:
     """SphericalSweepStereoBase.forward (mvs_model/torch_only.py:20-36): imgs [B, N, 3, H, W]."""

@@ -592,3 +592,84 @@ def test_sweep_grid_generator_vs_reference_goldens(golden_dir):
                                             calib_shape=[480, 640]).make_grid(_g(z["g16_pts1"]))
     well = z["ds2_mask"] & (np.abs(z["ds2_grid"]).max(-1) < 4)
     assert np.abs(g2.cpu().numpy() - z["ds2_grid"])[well].max() <= 2e-5
+
+
+# ------------------------------------------------------------------ sphere convolution
+@pytest.mark.parametrize("case", [
+    # (N, Cin, Cout, H, W, k, stride, pad, dil, res, slope)
+    (2, 16, 16, 12, 40, 3, 1, 1, 1, True, 0.01),       # quad-lane kernel, SphereConvBlk-like
+    (1, 16, 16, 9, 21, 5, 2, 2, 1, False, 1.0),        # 5x5 stride 2, ragged pixel count
+    (1, 16, 16, 10, 16, 3, 1, 2, 2, False, 0.0),       # dilation 2, ReLU
+    (2, 8, 12, 7, 11, 3, 1, 1, 1, True, 0.01),         # generic kernel (other channel counts)
+])
+def test_deform_conv2d_vs_oracle(case):
+    N, Cin, Cout, Hh, W, k, st, pad, dil, res, slope = case
+    rng = np.random.default_rng(sum(case[:9]))
+    x = rng.standard_normal((N, Cin, Hh, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.normal(0, 0.2, Cout).astype(np.float32)
+    Ho = (Hh + 2 * pad - (dil * (k - 1) + 1)) // st + 1
+    Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // st + 1
+    # offsets: sub-pixel, a few pixels, far outside, exactly on the -1 / H borders
+    off = rng.normal(0, 1.5, (N, 2 * k * k, Ho, Wo)).astype(np.float32)
+    off[:, :, 0, :] = np.round(off[:, :, 0, :])
+    off[:, 0, 1, :] = -50.0
+    off[:, 3, 2 % Ho, :] = 1e4
+    r = rng.standard_normal((N, Cout, Ho, Wo)).astype(np.float32) if res else None
+    y = O.deform_conv2d(torch.from_numpy(x), torch.from_numpy(off), torch.from_numpy(w), None, (st, st), (pad, pad), (dil, dil))
+    y = y * torch.from_numpy(scale).view(1, -1, 1, 1) + torch.from_numpy(shift).view(1, -1, 1, 1)
+    if res:
+        y = y + torch.from_numpy(r)
+    yref = torch.where(y > 0, y, y * slope).numpy()
+    xg = _g(x).permute(0, 2, 3, 1).contiguous()
+    rg = _g(r).permute(0, 2, 3, 1).contiguous() if res else None
+    got = H.deform_conv2d(xg, _g(off), H.pack_deform_conv2d_weights(_g(w)), _g(scale), _g(shift), (k, k), (st, st),
+                          (pad, pad), (dil, dil), res=rg, neg_slope=slope)
+    assert _rel(got.permute(0, 3, 1, 2).cpu().numpy(), yref) <= 2e-5
+    # a single shared offset field (what SphereConvEquirect2d registers) == the same field per image
+    shared = H.deform_conv2d(xg, _g(off[:1]), H.pack_deform_conv2d_weights(_g(w)), _g(scale), _g(shift), (k, k),
+                             (st, st), (pad, pad), (dil, dil), neg_slope=slope)
+    per = H.deform_conv2d(xg, _g(np.repeat(off[:1], N, 0)), H.pack_deform_conv2d_weights(_g(w)), _g(scale), _g(shift),
+                          (k, k), (st, st), (pad, pad), (dil, dil), neg_slope=slope)
+    assert torch.equal(shared, per)
+
+
+def _sphere_weights(seed, chs=16):
+    sd = synth.make_extractor_weights(seed, chs=chs)
+    out = {}
+    for k_, v in sd.items():
+        k_ = k_.replace("final_layer.conv_layer.", "final_layer.blk.0.").replace("final_layer.norm_layer.", "final_layer.blk.1.")
+        out[k_] = v
+    return out
+
+
+def test_sphere_feature_extractor_vs_oracle(conv_mode):
+    """SphereEquirectFeatExtraction (G16VV's extractor, sphere_feature_extractor.py:8-83) as HIP: 2-D MFMA convs +
+    the deformable final layer with the reference's offset field, vs the oracle (deform_conv2d restated from
+    torchvision's definition: parity unpinned for that operator, offsets pinned)."""
+    Hh, W = 64, 256
+    fe = dropin.SphereEquirectFeatExtraction(in_size=(Hh, W), in_chs=3, chs=16, k_sz=3, layers=[5, 10])
+    sd = {k_: torch.from_numpy(v) for k_, v in _sphere_weights(3).items()}
+    missing = fe.load_state_dict(sd, strict=False)
+    assert missing.missing_keys == ["final_layer.blk.0.offset"] and not missing.unexpected_keys
+    assert tuple(fe.final_layer.blk[0].offset.shape) == (1, 18, Hh // 4, W // 4)
+    fe = fe.eval().to(DEV)
+    rng = np.random.default_rng(12)
+    imgs = rng.random((3, 3, Hh, W), dtype=np.float32)
+    with torch.no_grad():
+        f = fe(_g(imgs))
+    p = dict(sd)
+    p["final_layer.blk.0.offset"] = fe.final_layer.blk[0].offset.cpu()
+    with torch.no_grad():
+        ref = O.sphere_feature_extractor(torch.from_numpy(imgs), p).numpy()
+    assert f.shape == ref.shape
+    assert _rel(f.cpu().numpy(), ref) <= (2e-4 if conv_mode == "bf16x3" else 2e-5)
+    # module-level pieces keep the reference's call signatures
+    blk = fe.final_layer
+    x = torch.from_numpy(rng.standard_normal((2, 16, Hh // 4, W // 4)).astype(np.float32))
+    with torch.no_grad():
+        y = blk(_g(x), res=_g(x))
+    p2 = {"fl." + k_[len("final_layer."):]: v for k_, v in p.items() if k_.startswith("final_layer.")}
+    yref = O.sphere_block2d(x, p2, "fl", res=x).numpy()
+    assert _rel(y.cpu().numpy(), yref) <= 2e-5

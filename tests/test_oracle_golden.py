@@ -133,3 +133,46 @@ def test_grid_oracle_matches_reference_closed_forms(golden_dir):
     g, m = G.grid_double_sphere(torch.from_numpy(z["g16_pts1"]), (0.1, 0.45, 300.0, 310.0, 320.0, 240.0), (480, 640))
     assert np.array_equal(g.numpy(), z["ds2_grid"]) and np.array_equal(m.numpy(), z["ds2_mask"])
     assert abs(G.double_sphere_w2(0.1, 0.45) - float(z["ds2_w2"])) < 1e-15
+
+
+# ------------------------------------------------------------------ sphere convolution
+def _sphere_args(a):
+    a = [int(v) for v in a]
+    return (a[0], a[1]), (a[2], a[3]), (a[4], a[5]), (a[6], a[7]), (a[8], a[9])
+
+
+def test_sphere_offsets_match_reference_gen_offset(golden_dir):
+    """dropin sphere_conv_offsets (vectorised restatement) == the reference's gen_offset, bit for bit."""
+    from mvs_gi_amd.dropin.feature_extractor import sphere_conv_offsets
+    z = _load(golden_dir, "sphere_offsets")
+    names = [k for k in z.files if not k.endswith("_args")]
+    assert "g16vv_final" in names
+    for name in names:
+        mine = sphere_conv_offsets(*_sphere_args(z[name + "_args"])).numpy()
+        assert mine.shape == z[name].shape and np.array_equal(mine, z[name], equal_nan=True), name
+
+
+def test_deform_conv_oracle_identities():
+    """The restated torchvision operator reduces to known answers: zero offsets == F.conv2d (any stride /
+    padding / dilation); an integer offset field == the same convolution of the shifted image."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(4)
+    for (Cin, Cout, k, s, p, d) in ((4, 6, 3, 1, 1, 1), (3, 5, 3, 2, 1, 1), (4, 4, 5, 1, 4, 2), (2, 3, 2, 1, 0, 1)):
+        x = torch.from_numpy(rng.standard_normal((2, Cin, 9, 13)).astype(np.float32))
+        w = torch.from_numpy(rng.standard_normal((Cout, Cin, k, k)).astype(np.float32))
+        b = torch.from_numpy(rng.standard_normal(Cout).astype(np.float32))
+        ref = F.conv2d(x, w, b, stride=s, padding=p, dilation=d)
+        off = torch.zeros((2, 2 * k * k, *ref.shape[2:]))
+        got = O.deform_conv2d(x, off, w, b, (s, s), (p, p), (d, d))
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    x = torch.from_numpy(rng.standard_normal((1, 3, 10, 12)).astype(np.float32))
+    w = torch.from_numpy(rng.standard_normal((4, 3, 3, 3)).astype(np.float32))
+    off = torch.zeros((1, 18, 10, 12))
+    off[:, 0::2] = 2.0      # every tap two rows down
+    off[:, 1::2] = -1.0     # and one column left
+    shifted = torch.zeros_like(x)
+    shifted[:, :, :-2, 1:] = x[:, :, 2:, :-1]
+    ref = F.conv2d(shifted, w, None, padding=1)
+    got = O.deform_conv2d(x, off, w, None, (1, 1), (1, 1), (1, 1))
+    # identical away from the borders the shift drags zeros across
+    assert float((got - ref)[:, :, 1:-3, 2:-1].abs().max()) <= 1e-5
