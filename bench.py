@@ -332,6 +332,8 @@ def main(argv=None):
         "config": {"workload": f"{cfg.tag}: {cfg.num_cams} cams, D={cfg.num_cands}, builder={cfg.builder}, "
                                f"regulator=({cfg.reg_in_chs},{cfg.reg_f_int_chs}), feats {cfg.feat_hw}, cv {cfg.cv_hw}",
                    "frames_per_gpu_per_step": B, "parallelism": f"frame-sharded x{world} (no collective)",
+                   "rig_constants": "grids / grid_masks / masks resident in HBM; validity byte and packed weights lowered "
+                                    "once during warm-up (DESIGN.md section 1)",
                    "path_gflop_per_frame": round(path_gflop(cfg), 2)},
         "frames_per_sec_per_gpu": round(value / world, 2),
         "path_tflops": round(value * path_gflop(cfg) / 1e3, 2),
