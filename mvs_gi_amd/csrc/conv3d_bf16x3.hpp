@@ -33,7 +33,24 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kVSB = 80;      // LDS bytes per staged voxel
+
+// x = hi + lo for four fp32 values, hi = bf16(x) (RNE), lo = bf16(x - hi), packed two per dword:
+// 2 x (v_cvt_pk_bf16_f32, shift, and, v_pk_add_f32, v_cvt_pk_bf16_f32) = 10 VALU instructions
+// (converting element by element cost 16, and the producers share their SIMD's issue port with the MFMAs)
+__device__ __forceinline__ void split_bf16x4(const f32x4 x, u32x2& hi, u32x2& lo) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const f32x2v v = {x[2 * p], x[2 * p + 1]};
+        const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+        const f32x2v hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        hi[p] = hb;
+        lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, bf16x2));
+    }
+}
 constexpr int pairs_of(int kd) { return (kd * 9 + 1) / 2; }      // KD = 3: 14 pairs of 27 taps; KD = 1 (2-D 3x3): 5 of 9
 
 // [Cout][Cin][taps] -> [Cin/16][Cout/16][pairs][hi|lo][64 lanes][8 bf16]   (taps = 27 or 9)
@@ -231,6 +248,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                 }                                                                                       \
                 if (++cc2 == nchunks) { cc2 = 0; ++k2; }                                                \
             }
+#define MVSGI_LERP2(A, B, O0, O1)   /* O0 = 0.75 A + 0.25 B, O1 = 0.25 A + 0.75 B as A + f (B - A): 6 v_pk_fma_f32 */ \
+            {                                                                                           \
+                const f32x4 d_ = __builtin_elementwise_fma((A), f32x4{-1.f, -1.f, -1.f, -1.f}, (B));   /* B - A, exact, packed */ \
+                O0 = __builtin_elementwise_fma(d_, f32x4{0.25f, 0.25f, 0.25f, 0.25f}, (A));             \
+                O1 = __builtin_elementwise_fma(d_, f32x4{0.75f, 0.75f, 0.75f, 0.75f}, (A));             \
+            }
 #define MVSGI_PUT_UPS(CR, IM, DST)                                                                      \
             {                                                                                           \
                 _Pragma("unroll") for (int it = 0; it < NITU; ++it) {                                   \
@@ -239,32 +262,25 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                         const int c = e >> 2, q = e & 3;                                                \
                         const int cw = c % CW, ch = (c / CW) % CH, cd = c / (CW * CH);                  \
                         /* separable blend: along W, then H, then D; index bit = upsampled voxel 0 / 1 of the cell */ \
-                        f32x4 xw[4][2], xh[2][2][2];                                                    \
-                        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                 \
-                            xw[k][0] = CR[it][2 * k] * 0.75f + CR[it][2 * k + 1] * 0.25f;               \
-                            xw[k][1] = CR[it][2 * k] * 0.25f + CR[it][2 * k + 1] * 0.75f;               \
-                        }                                                                               \
+                        f32x4 xw[4][2], xh[2][2][2], xo[2][2][2];                                       \
+                        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                   \
+                            MVSGI_LERP2(CR[it][2 * k], CR[it][2 * k + 1], xw[k][0], xw[k][1])           \
                         _Pragma("unroll") for (int kd = 0; kd < 2; ++kd)                                \
-                            _Pragma("unroll") for (int kw = 0; kw < 2; ++kw) {                          \
-                                xh[kd][0][kw] = xw[2 * kd][kw] * 0.75f + xw[2 * kd + 1][kw] * 0.25f;    \
-                                xh[kd][1][kw] = xw[2 * kd][kw] * 0.25f + xw[2 * kd + 1][kw] * 0.75f;    \
-                            }                                                                           \
+                            _Pragma("unroll") for (int kw = 0; kw < 2; ++kw)                            \
+                                MVSGI_LERP2(xw[2 * kd][kw], xw[2 * kd + 1][kw], xh[kd][0][kw], xh[kd][1][kw]) \
+                        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                \
+                            _Pragma("unroll") for (int kw = 0; kw < 2; ++kw)                            \
+                                MVSGI_LERP2(xh[0][kh][kw], xh[1][kh][kw], xo[0][kh][kw], xo[1][kh][kw])  \
                         _Pragma("unroll") for (int kd = 0; kd < 2; ++kd)                                \
                             _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                            \
                                 _Pragma("unroll") for (int kw = 0; kw < 2; ++kw) {                      \
-                                    const float fa = kd ? 0.25f : 0.75f, fb = kd ? 0.75f : 0.25f;       \
-                                    const f32x4 xv4 = xh[0][kh][kw] * fa + xh[1][kh][kw] * fb;          \
                                     const bool ok = ((IM[it] >> kd) & (IM[it] >> (2 + kh)) & (IM[it] >> (4 + kw)) & 1u) != 0; \
-                                    bf16x4 hi, lo;                                                      \
-                                    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                     \
-                                        const float xv = ok ? xv4[k] : 0.f;                             \
-                                        const __bf16 h = (__bf16)xv;                                    \
-                                        hi[k] = h;                                                      \
-                                        lo[k] = (__bf16)(xv - (float)h);                                \
-                                    }                                                                   \
+                                    u32x2 hi, lo;                                                       \
+                                    split_bf16x4(xo[kd][kh][kw], hi, lo);                               \
+                                    if (!ok) hi = lo = u32x2{0u, 0u};                                   \
                                     const int v = ((2 * cd + kd) * ITH + 2 * ch + kh) * ITW + 2 * cw + kw; \
-                                    *reinterpret_cast<bf16x4*>((DST) + v * kVSB + q * 8) = hi;          \
-                                    *reinterpret_cast<bf16x4*>((DST) + v * kVSB + 32 + q * 8) = lo;     \
+                                    *reinterpret_cast<u32x2*>((DST) + v * kVSB + q * 8) = hi;           \
+                                    *reinterpret_cast<u32x2*>((DST) + v * kVSB + 32 + q * 8) = lo;      \
                                 }                                                                       \
                     }                                                                                   \
                 }                                                                                       \
@@ -293,6 +309,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
             }
 #undef MVSGI_ISSUE_UPS
 #undef MVSGI_PUT_UPS
+#undef MVSGI_LERP2
 #undef MVSGI_PLAN_UPS
 #undef MVSGI_CLAMP
         } else {
@@ -342,16 +359,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                 const int e = ptid + it * 256;                                                          \
                 if (e < IV * 4) {                                                                       \
                     const int v = e >> 2, q = e & 3;                                                    \
-                    const bool ok = ((OK) >> it) & 1u;                                                  \
-                    bf16x4 hi, lo;                                                                      \
-                    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                     \
-                        const float xv = ok ? PRE[it][k] : 0.f;                                         \
-                        const __bf16 h = (MVSGI_ABL & 4) ? __builtin_bit_cast(__bf16, (unsigned short)(__builtin_bit_cast(unsigned, xv) >> 16)) : (__bf16)xv; \
-                        hi[k] = h;                                                                      \
-                        lo[k] = (MVSGI_ABL & 4) ? h : (__bf16)(xv - (float)h);                          \
-                    }                                                                                   \
-                    *reinterpret_cast<bf16x4*>((DST) + v * kVSB + q * 8) = hi;                          \
-                    *reinterpret_cast<bf16x4*>((DST) + v * kVSB + 32 + q * 8) = lo;                     \
+                    u32x2 hi, lo;                                                                       \
+                    split_bf16x4(PRE[it], hi, lo);                                                      \
+                    if (!(((OK) >> it) & 1u)) hi = lo = u32x2{0u, 0u};                                  \
+                    *reinterpret_cast<u32x2*>((DST) + v * kVSB + q * 8) = hi;                           \
+                    *reinterpret_cast<u32x2*>((DST) + v * kVSB + 32 + q * 8) = lo;                      \
                 }                                                                                       \
             }                                                                                           \
         }
