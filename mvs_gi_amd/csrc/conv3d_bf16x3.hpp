@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
     // weight pipeline of the consumers: WB register buffers, fragments requested LA slots ahead.
     // A slice has NSLOT slots = the tap pairs rounded up to a multiple of WB (rotation-only slots), so
     // that every register-buffer index is a compile-time constant.
-    constexpr int WB = NW <= 2 ? 3 : 2;
+    constexpr int WB = NW <= 2 ? 4 : 2;
     constexpr int LA = WB - 1;
     constexpr int NSLOT = ((kPairs + WB - 1) / WB) * WB;
     static_assert(NSLOT % WB == 0 && NSLOT >= kPairs, "pipeline geometry");
