@@ -50,6 +50,9 @@ typedef void* mvsgi_stream_t;
 #define MVSGI_CONV_BF16X3_C16 4 /* the same arithmetic for Cout == 16, stride 1 (post_vol, out_costs.0): "plane"
                                    schedule -- one activation fragment feeds the kd = 0, 1, 2 taps of three output
                                    planes -- with weights from mvsgi_conv3d_pack_weights_bf16x3_c16            */
+#define MVSGI_CONV_BF16X3_V32 5 /* the same arithmetic on v_mfma_f32_32x32x16_bf16 (one tap x 16 channels per MFMA, half the
+                                   issue-port time per flop) where mvsgi_conv3d_v32_applies(); weights from
+                                   mvsgi_conv3d_pack_weights_bf16x3_v32                                                  */
 
 int         mvsgi_abi_version(void);
 const char* mvsgi_last_error(void);
@@ -132,10 +135,14 @@ const char* mvsgi_conv3d_variant_f32(int B, int Cin, int Din, int Hin, int Win, 
  *   y [B][2Dl][2Hl][2Wl][Cout] = act( conv3d(upsample2(x), w, pad=1) * scale + shift (+ res) )
  * Split-bf16 MFMA arithmetic; w_packed from mvsgi_conv3d_pack_weights_bf16x3; Cin, Cout % 16 == 0.
  * (Odd target sizes -- the second re-interpolation of :343-350 -- use mvsgi_resize_trilinear_f32 + mvsgi_conv3d_f32.) */
-int mvsgi_conv3d_up2_f32(const float* x, const void* w_packed, int w_layout /* MVSGI_CONV_BF16X3 | _C16 */,
+int mvsgi_conv3d_up2_f32(const float* x, const void* w_packed, int w_layout /* MVSGI_CONV_BF16X3 | _C16 | _V32 */,
                          const float* scale, const float* shift, const float* res, float* y,
                          int B, int Cin, int Dl, int Hl, int Wl, int Cout, float neg_slope, mvsgi_stream_t stream);
 const char* mvsgi_conv3d_up2_variant_f32(int B, int Cin, int Dl, int Hl, int Wl, int Cout, int w_layout);
+/* 32x32x16-MFMA schedule (MVSGI_CONV_BF16X3_V32): Cout % 32 == 0, stride 1, enough bricks to fill the chip */
+int mvsgi_conv3d_v32_applies(int B, int Cin, int Din, int Hin, int Win, int Cout, int stride);
+size_t mvsgi_conv3d_packed_weight_bytes_bf16x3_v32(int Cout, int Cin);
+int mvsgi_conv3d_pack_weights_bf16x3_v32(const float* w_oidhw, void* w_packed, int Cout, int Cin, mvsgi_stream_t stream);
 /* weights of a Cout == 16 layer in the plane-schedule layout (MVSGI_CONV_BF16X3_C16) */
 size_t mvsgi_conv3d_packed_weight_bytes_bf16x3_c16(int Cin);
 int mvsgi_conv3d_pack_weights_bf16x3_c16(const float* w_oidhw, void* w_packed, int Cin, mvsgi_stream_t stream);

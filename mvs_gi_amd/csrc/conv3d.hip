@@ -284,6 +284,8 @@ enum Variant {
     B3U_N16, B3U_N32, B3U_N32_M, B3U_N48, B3U_N64, B3U_N96,
     // Cout == 16 plane schedule (weights from mvsgi_conv3d_pack_weights_bf16x3_c16), plain and fused-upsample
     B3P_N16, B3PU_N16,
+    // 32x32x16 schedule (Cout % 32 == 0, stride 1; weights from mvsgi_conv3d_pack_weights_bf16x3_v32), plain / fused upsample
+    B3V_N32, B3V_N64, B3VU_N32, B3VU_N64,
     V_COUNT
 };
 const char* const kVariantNames[V_COUNT] = {
@@ -292,19 +294,34 @@ const char* const kVariantNames[V_COUNT] = {
     "conv3d_mfma_kernel<2, 1, 4, 1, 2, 4, 8, 1>", "conv3d_mfma_kernel<2, 4, 2, 2, 2, 8, 8, 1>",
     "conv3d_mfma_kernel<2, 2, 2, 2, 2, 4, 8, 1>", "conv3d_mfma_kernel<2, 1, 4, 1, 2, 4, 8, 2>",
     "conv3d_mfma_kernel<2, 2, 2, 2, 2, 4, 8, 2>",
-    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, false, false>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1, 3, false, false>",
-    "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1, 3, false, false>", "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, false, false>",
-    "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false>",
-    "conv3d_bf16x3_kernel<2, 2, 2, 2, 1, 4, 16, 1, 3, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 2, 4, 8, 2, 3, false, false>",
-    "conv3d_bf16x3_kernel<2, 2, 2, 2, 2, 4, 8, 2, 3, false, false>",
-    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, true, false>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1, 3, true, false>",
-    "conv3d_bf16x3_kernel<2, 2, 4, 1, 2, 4, 16, 1, 3, true, false>", "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1, 3, true, false>",
-    "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, true, false>", "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, true, false>",
-    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, false, true>", "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, true, true>",
+    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false>",
+    "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, false, false, false>",
+    "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false>",
+    "conv3d_bf16x3_kernel<2, 2, 2, 2, 1, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 2, 4, 8, 2, 3, false, false, false>",
+    "conv3d_bf16x3_kernel<2, 2, 2, 2, 2, 4, 8, 2, 3, false, false, false>",
+    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, true, false, false>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1, 3, true, false, false>",
+    "conv3d_bf16x3_kernel<2, 2, 4, 1, 2, 4, 16, 1, 3, true, false, false>", "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1, 3, true, false, false>",
+    "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, true, false, false>", "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, true, false, false>",
+    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, false, true, false>", "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, true, true, false>",
+    "conv3d_bf16x3_kernel<1, 2, 4, 1, 4, 4, 16, 1, 3, false, false, true>", "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 16, 1, 3, false, false, true>",
+    "conv3d_bf16x3_kernel<1, 2, 4, 1, 4, 4, 16, 1, 3, true, false, true>", "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 16, 1, 3, true, false, true>",
 };
 
+// 32x32x16 schedule: Cout % 32 == 0, stride 1, and enough bricks to fill the chip with its two brick shapes
+bool v32_applies(const ConvArgs& a) {
+    if (a.Cout % 32 || a.Cin % 16 || a.stride != 1) return false;
+    const long long big = (long long)a.B * mvsgi::cdiv(a.Do, 4) * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
+    const long long mid = (long long)a.B * mvsgi::cdiv(a.Do, 2) * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
+    return a.Cout == 32 ? big >= 384 : mid * mvsgi::cdiv(a.Cout, 64) >= 384;
+}
+
 // variant of the fused upsample + conv (a holds the UPSAMPLED input size); V_COUNT when unsupported
-int select_variant_up2(const ConvArgs& a, bool c16_layout) {
+int select_variant_up2(const ConvArgs& a, int w_layout) {
+    const bool c16_layout = w_layout == MVSGI_CONV_BF16X3_C16;
+    if (w_layout == MVSGI_CONV_BF16X3_V32) {
+        if (!v32_applies(a) || !a.wp) { mvsgi::fail("mvsgi_conv3d_up2_f32: the 32x32x16 kernel does not apply to this problem"); return V_COUNT; }
+        return a.Cout == 32 ? B3VU_N32 : B3VU_N64;
+    }
     if (a.Cin % 16 || a.Cout % 16) {
         mvsgi::fail("mvsgi_conv3d_up2_f32: Cin, Cout must be multiples of 16 (got %d, %d)", a.Cin, a.Cout);
         return V_COUNT;
@@ -332,6 +349,14 @@ int select_variant(const ConvArgs& a, int impl) {
         }
         if (!a.wp) { mvsgi::fail("mvsgi_conv3d_f32: tiled path needs w_packed"); return V_COUNT; }
         return B3P_N16;
+    }
+    if (impl == MVSGI_CONV_BF16X3_V32) {
+        if (!v32_applies(a)) {
+            mvsgi::fail("mvsgi_conv3d_f32: the 32x32x16 kernel does not apply to this problem (see mvsgi_conv3d_v32_applies)");
+            return V_COUNT;
+        }
+        if (!a.wp) { mvsgi::fail("mvsgi_conv3d_f32: tiled path needs w_packed"); return V_COUNT; }
+        return a.Cout == 32 ? B3V_N32 : B3V_N64;
     }
     if (impl == MVSGI_CONV_BF16X3 && !mfma_ok) impl = MVSGI_CONV_AUTO;   // head / odd channels: exact paths
     if (impl == MVSGI_CONV_AUTO) impl = (mfma_ok || head_ok) ? MVSGI_CONV_MFMA : MVSGI_CONV_DIRECT;
@@ -399,6 +424,10 @@ int launch_variant(int v, const ConvArgs& a, hipStream_t st) {
         case B3U_N96: return launch_bf16x3<3, 4, 2, 2, 2, 4, 16, 1, 3, true>(a, st);
         case B3P_N16: return launch_bf16x3<1, 4, 4, 1, 4, 4, 16, 1, 3, false, true>(a, st);
         case B3PU_N16: return launch_bf16x3<1, 4, 4, 1, 4, 4, 16, 1, 3, true, true>(a, st);
+        case B3V_N32: return launch_bf16x3<1, 2, 4, 1, 4, 4, 16, 1, 3, false, false, true>(a, st);
+        case B3V_N64: return launch_bf16x3<1, 2, 2, 2, 2, 4, 16, 1, 3, false, false, true>(a, st);
+        case B3VU_N32: return launch_bf16x3<1, 2, 4, 1, 4, 4, 16, 1, 3, true, false, true>(a, st);
+        case B3VU_N64: return launch_bf16x3<1, 2, 2, 2, 2, 4, 16, 1, 3, true, false, true>(a, st);
     }
     return mvsgi::fail("mvsgi_conv3d_f32: bad variant %d", v);
 }
@@ -448,6 +477,30 @@ extern "C" int mvsgi_conv3d_pack_weights_bf16x3(const float* w_oidhw, void* w_pa
     hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0,
                        mvsgi::as_stream(stream), w_oidhw, reinterpret_cast<bf16x8*>(w_packed), Cout, Cin, 27);
     return mvsgi::check_launch("mvsgi_conv3d_pack_weights_bf16x3");
+}
+
+extern "C" size_t mvsgi_conv3d_packed_weight_bytes_bf16x3_v32(int Cout, int Cin) {
+    return (size_t)(Cin / 16) * (Cout / 32) * 27 * 2 * 64 * 16;
+}
+
+extern "C" int mvsgi_conv3d_pack_weights_bf16x3_v32(const float* w_oidhw, void* w_packed, int Cout, int Cin,
+                                                    mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(w_oidhw && w_packed, "mvsgi_conv3d_pack_weights_bf16x3_v32: null pointer");
+    MVSGI_REQUIRE(Cout > 0 && Cin > 0 && Cout % 32 == 0 && Cin % 16 == 0,
+                  "mvsgi_conv3d_pack_weights_bf16x3_v32: Cout=%d must be a multiple of 32, Cin=%d of 16", Cout, Cin);
+    const long long total = (long long)(Cin / 16) * (Cout / 32) * 27 * 64;
+    hipLaunchKernelGGL(pack_weights_bf16x3_v32_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0,
+                       mvsgi::as_stream(stream), w_oidhw, reinterpret_cast<bf16x8*>(w_packed), Cout, Cin);
+    return mvsgi::check_launch("mvsgi_conv3d_pack_weights_bf16x3_v32");
+}
+
+// 1 when mvsgi_conv3d_f32 / mvsgi_conv3d_up2_f32 (pass the UPSAMPLED input size) accept MVSGI_CONV_BF16X3_V32 for this problem
+extern "C" int mvsgi_conv3d_v32_applies(int B, int Cin, int Din, int Hin, int Win, int Cout, int stride) {
+    ConvArgs a{};
+    static const float dummy = 0.f;
+    if (fill_args(a, &dummy, &dummy, &dummy, &dummy, &dummy, nullptr, nullptr, B, Cin, Din, Hin, Win, Cout, stride, 1.f))
+        return 0;
+    return v32_applies(a) ? 1 : 0;
 }
 
 extern "C" size_t mvsgi_conv3d_packed_weight_bytes_bf16x3_c16(int Cin) { return (size_t)(Cin / 16) * 5 * 3 * 2 * 64 * 16; }
@@ -507,7 +560,8 @@ extern "C" const char* mvsgi_conv3d_variant_f32(int B, int Cin, int Din, int Hin
 extern "C" int mvsgi_conv3d_up2_f32(const float* x, const void* w_packed, int w_layout, const float* scale,
                                     const float* shift, const float* res, float* y, int B, int Cin, int Dl, int Hl,
                                     int Wl, int Cout, float neg_slope, mvsgi_stream_t stream) {
-    MVSGI_REQUIRE(w_layout == MVSGI_CONV_BF16X3 || (w_layout == MVSGI_CONV_BF16X3_C16 && Cout == 16),
+    MVSGI_REQUIRE(w_layout == MVSGI_CONV_BF16X3 || (w_layout == MVSGI_CONV_BF16X3_C16 && Cout == 16) ||
+                      (w_layout == MVSGI_CONV_BF16X3_V32 && Cout % 32 == 0),
                   "mvsgi_conv3d_up2_f32: w_layout %d not valid for Cout %d", w_layout, Cout);
     MVSGI_REQUIRE(x && y && scale && shift && w_packed, "mvsgi_conv3d_up2_f32: null pointer");
     MVSGI_REQUIRE(Dl > 0 && Hl > 0 && Wl > 0 && Dl < (1 << 20) && Hl < (1 << 20) && Wl < (1 << 20),
@@ -516,7 +570,7 @@ extern "C" int mvsgi_conv3d_up2_f32(const float* x, const void* w_packed, int w_
     if (fill_args(a, x, nullptr, static_cast<const float*>(w_packed), scale, shift, res, y, B, Cin, 2 * Dl, 2 * Hl,
                   2 * Wl, Cout, 1, neg_slope))
         return 1;
-    const int v = select_variant_up2(a, w_layout == MVSGI_CONV_BF16X3_C16);
+    const int v = select_variant_up2(a, w_layout);
     if (v == V_COUNT) return 1;
     return launch_variant(v, a, mvsgi::as_stream(stream));
 }
@@ -527,6 +581,6 @@ extern "C" const char* mvsgi_conv3d_up2_variant_f32(int B, int Cin, int Dl, int 
     if (fill_args(a, &dummy, nullptr, &dummy, &dummy, &dummy, nullptr, nullptr, B, Cin, 2 * Dl, 2 * Hl, 2 * Wl, Cout, 1,
                   1.f))
         return nullptr;
-    const int v = select_variant_up2(a, w_layout == MVSGI_CONV_BF16X3_C16);
+    const int v = select_variant_up2(a, w_layout);
     return v == V_COUNT ? nullptr : kVariantNames[v];
 }

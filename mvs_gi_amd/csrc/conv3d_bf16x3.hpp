@@ -111,6 +111,33 @@ __global__ void pack_weights_bf16x3_c16_kernel(const float* __restrict__ w, bf16
     wp[o + 64] = lo;
 }
 
+// 32x32x16 schedule: [Cout][Cin][27] -> [Cin/16][Cout/32][27 taps][hi|lo][64 lanes][8 bf16]
+//   lane = (khalf << 5) | r holds W[cout = ct*32 + r][cin = cc*16 + khalf*8 + j][tap]
+__global__ void pack_weights_bf16x3_v32_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout, int Cin) {
+    const int CT = Cout / 32;
+    const long long total = (long long)(Cin / 16) * CT * 27 * 64;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    long long r = idx >> 6;
+    const int tap = (int)(r % 27);
+    r /= 27;
+    const int ct = (int)(r % CT);
+    const int cc = (int)(r / CT);
+    const int co = ct * 32 + (lane & 31);
+    const int ci = cc * 16 + (lane >> 5) * 8;
+    bf16x8 hi, lo;
+    for (int j = 0; j < 8; ++j) {
+        const float v = w[((long long)co * Cin + ci + j) * 27 + tap];
+        const __bf16 h = (__bf16)v;
+        hi[j] = h;
+        lo[j] = (__bf16)(v - (float)h);
+    }
+    const long long o = ((((long long)cc * CT + ct) * 27 + tap) * 2) * 64 + lane;
+    wp[o] = hi;
+    wp[o + 64] = lo;
+}
+
 // bijective XCD-aware remap of a flat block id (cdna_hip_programming.md T1): blocks b, b+8, ...
 // share an XCD; give each XCD a contiguous run of the logical index space.
 __device__ __forceinline__ int xcd_remap(int bid, int n) {
@@ -134,21 +161,33 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // the fragment of (ip, p') is multiplied with the kd = 0, 1, 2 weights into the accumulators of output
 // planes ip, ip - 1, ip - 2: up to 9 MFMAs per fragment, 60 instead of 112 ds_read_b128 per 16-channel slice.
 // Weights are packed per (slice, pair, kd) by pack_weights_bf16x3_c16_kernel.
-template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false, bool PLANE = false>
+//
+// V32 = true is the consumer schedule for Cout % 32 == 0, stride 1: v_mfma_f32_32x32x16_bf16 (32 couts x 32 voxels,
+// K = 16 = ONE tap x 16 channels).  The same flops per cycle as 16x16x32, but an MFMA holds the SIMD's vector
+// issue port for 8 of its 32 cycles instead of 8 of 16 (MI355X_MICROARCH.md), which is what the consumer's own
+// fragment requests and the producer wave sharing its SIMD compete for; 27 taps instead of 14 pairs (no 3.6 %
+// padding).  NW / MW count 32-wide tiles; a voxel tile is two 16-runs of adjacent h rows.  The LDS image's row
+// pitch is padded to a multiple of 256 B, which makes the 16-lane ds_read_b128 groups conflict-free for every
+// tap (rows differ by 0 mod 256 B, so the two half-rows of a group tile the 16 bank units exactly).
+// Weights: pack_weights_bf16x3_v32_kernel.
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false, bool PLANE = false,
+          bool V32 = false>
 __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {      // 2 waves per SIMD: 256 registers
+    static_assert(!V32 || (S == 1 && KD == 3 && TW == 16 && TH % 2 == 0 && !PLANE), "32x32x16 schedule: stride 1, 16-wide even bricks");
     static_assert(!PLANE || (NW == 1 && WN == 1 && WM == 4 && TH == 4 && MW == TD && TW == 16 && S == 1 && KD == 3),
                   "plane schedule: Cout == 16, 4 h-rows x TD planes x 16 w per brick");
     static_assert(!UPS || (S == 1 && KD == 3 && TD % 2 == 0 && TH % 2 == 0 && TW % 2 == 0),
                   "fused upsample: stride 1, even bricks (halo bricks are whole 2x2x2 cells)");
     static_assert(WM * WN == 4, "4 consumer waves per workgroup");
-    static_assert(WM * MW * 16 == TD * TH * TW, "brick must be covered by the voxel tiles");
+    static_assert(WM * MW * (V32 ? 32 : 16) == TD * TH * TW, "brick must be covered by the voxel tiles");
     static_assert(KD == 3 || (KD == 1 && TD == 1), "2-D bricks are one plane thick");
     constexpr int SD = KD == 1 ? 1 : S;               // images are never strided over
     constexpr int kTaps = KD * 9, kPairs = pairs_of(KD);
     constexpr int ITD = (TD - 1) * SD + KD, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
     constexpr int IV = ITD * ITH * ITW;
     constexpr int NIT = (IV * 4 + 255) / 256;      // staging items per producer thread and unit
-    constexpr int BUF = IV * kVSB;                 // bytes of one LDS image
+    constexpr int ROWP = V32 ? ((ITW * kVSB + 255) / 256) * 256 : ITW * kVSB;    // LDS bytes per halo row
+    constexpr int BUF = ITD * ITH * ROWP;          // bytes of one LDS image
     // weight pipeline of the consumers: WB register buffers, fragments requested LA slots ahead.
     // A slice has NSLOT slots = the tap pairs rounded up to a multiple of WB (rotation-only slots), so
     // that every register-buffer index is a compile-time constant.
@@ -162,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform
     const bool producer = wave >= 4;
-    const int CT = a.Cout / 16;
+    const int CT = a.Cout / (V32 ? 32 : 16);       // cout tiles
     const int ny = (CT + WN * NW - 1) / (WN * NW);
     const int nchunks = a.Cin / 16;
     const int total = a.total_units;               // bricks x cout blocks
@@ -229,24 +268,33 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
             }
 #define MVSGI_CLAMP(V, N) ((V) < 0 ? 0 : ((V) > (N) - 1 ? (N) - 1 : (V)))
             int k2 = 0, cc2 = 0;                               // next unit to request, in walking order
+#define MVSGI_ISSUE_UPS_BEGIN()                                                                         \
+            if (cc2 == 0 && k2 > 0) { MVSGI_PLAN_UPS((int)blockIdx.x + k2 * G) }
+#define MVSGI_ISSUE_UPS1(CR, IM, IT)                                                                    \
+            {                                                                                           \
+                const int e = ptid + (IT) * 256;                                                        \
+                const int q = e & 3;                                                                    \
+                const bool live = e < NC * 4;                                                           \
+                const int d0 = live ? MVSGI_CLAMP(lo_d[IT], Dl) : 0, d1 = live ? MVSGI_CLAMP(lo_d[IT] + 1, Dl) : 0; \
+                const int h0 = live ? MVSGI_CLAMP(lo_h[IT], Hl) : 0, h1 = live ? MVSGI_CLAMP(lo_h[IT] + 1, Hl) : 0; \
+                const int w0 = live ? MVSGI_CLAMP(lo_w[IT], Wl) : 0, w1 = live ? MVSGI_CLAMP(lo_w[IT] + 1, Wl) : 0; \
+                const int cofs = cc2 * 16 + q * 4;                                                      \
+                _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                         \
+                    const int dd = (k & 4) ? d1 : d0, hh = (k & 2) ? h1 : h0, ww = (k & 1) ? w1 : w0;   \
+                    CR[IT][k] = *reinterpret_cast<const f32x4*>(xb + ((dd * Hl + hh) * Wl + ww) * a.Cin + cofs); \
+                }                                                                                       \
+                IM[IT] = inmask[IT];                                                                    \
+            }
+#define MVSGI_ISSUE_UPS_END()                                                                           \
+            {                                                                                           \
+                if (++cc2 == nchunks) { cc2 = 0; ++k2; }                                                \
+                if (k2 >= nmine) { k2 = nmine - 1; cc2 = nchunks - 1; }                                 \
+            }
 #define MVSGI_ISSUE_UPS(CR, IM)                                                                         \
             {                                                                                           \
-                if (cc2 == 0 && k2 > 0) { MVSGI_PLAN_UPS((int)blockIdx.x + k2 * G) }                    \
-                _Pragma("unroll") for (int it = 0; it < NITU; ++it) {                                   \
-                    const int e = ptid + it * 256;                                                      \
-                    const int q = e & 3;                                                                \
-                    const bool live = e < NC * 4;                                                       \
-                    const int d0 = live ? MVSGI_CLAMP(lo_d[it], Dl) : 0, d1 = live ? MVSGI_CLAMP(lo_d[it] + 1, Dl) : 0; \
-                    const int h0 = live ? MVSGI_CLAMP(lo_h[it], Hl) : 0, h1 = live ? MVSGI_CLAMP(lo_h[it] + 1, Hl) : 0; \
-                    const int w0 = live ? MVSGI_CLAMP(lo_w[it], Wl) : 0, w1 = live ? MVSGI_CLAMP(lo_w[it] + 1, Wl) : 0; \
-                    const int cofs = cc2 * 16 + q * 4;                                                  \
-                    _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                     \
-                        const int dd = (k & 4) ? d1 : d0, hh = (k & 2) ? h1 : h0, ww = (k & 1) ? w1 : w0; \
-                        CR[it][k] = *reinterpret_cast<const f32x4*>(xb + ((dd * Hl + hh) * Wl + ww) * a.Cin + cofs); \
-                    }                                                                                   \
-                    IM[it] = inmask[it];                                                                \
-                }                                                                                       \
-                if (++cc2 == nchunks) { cc2 = 0; ++k2; }                                                \
+                MVSGI_ISSUE_UPS_BEGIN()                                                                 \
+                _Pragma("unroll") for (int it = 0; it < NITU; ++it) MVSGI_ISSUE_UPS1(CR, IM, it)        \
+                MVSGI_ISSUE_UPS_END()                                                                   \
             }
 #define MVSGI_LERP2(A, B, O0, O1)   /* O0 = 0.75 A + 0.25 B, O1 = 0.25 A + 0.75 B as A + f (B - A): 6 v_pk_fma_f32 */ \
             {                                                                                           \
@@ -254,54 +302,63 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                 O0 = __builtin_elementwise_fma(d_, f32x4{0.25f, 0.25f, 0.25f, 0.25f}, (A));             \
                 O1 = __builtin_elementwise_fma(d_, f32x4{0.75f, 0.75f, 0.75f, 0.75f}, (A));             \
             }
-#define MVSGI_PUT_UPS(CR, IM, DST)                                                                      \
+#define MVSGI_PUT_UPS1(CR, IM, DST, IT)                                                                 \
             {                                                                                           \
-                _Pragma("unroll") for (int it = 0; it < NITU; ++it) {                                   \
-                    const int e = ptid + it * 256;                                                      \
-                    if (e < NC * 4) {                                                                   \
-                        const int c = e >> 2, q = e & 3;                                                \
-                        const int cw = c % CW, ch = (c / CW) % CH, cd = c / (CW * CH);                  \
-                        /* separable blend: along W, then H, then D; index bit = upsampled voxel 0 / 1 of the cell */ \
-                        f32x4 xw[4][2], xh[2][2][2], xo[2][2][2];                                       \
-                        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                   \
-                            MVSGI_LERP2(CR[it][2 * k], CR[it][2 * k + 1], xw[k][0], xw[k][1])           \
-                        _Pragma("unroll") for (int kd = 0; kd < 2; ++kd)                                \
-                            _Pragma("unroll") for (int kw = 0; kw < 2; ++kw)                            \
-                                MVSGI_LERP2(xw[2 * kd][kw], xw[2 * kd + 1][kw], xh[kd][0][kw], xh[kd][1][kw]) \
+                const int e = ptid + (IT) * 256;                                                        \
+                if (e < NC * 4) {                                                                       \
+                    const int c = e >> 2, q = e & 3;                                                    \
+                    const int cw = c % CW, ch = (c / CW) % CH, cd = c / (CW * CH);                      \
+                    /* separable blend: along W, then H, then D; index bit = upsampled voxel 0 / 1 of the cell */ \
+                    f32x4 xw[4][2], xh[2][2][2], xo[2][2][2];                                           \
+                    _Pragma("unroll") for (int k = 0; k < 4; ++k)                                       \
+                        MVSGI_LERP2(CR[IT][2 * k], CR[IT][2 * k + 1], xw[k][0], xw[k][1])               \
+                    _Pragma("unroll") for (int kd = 0; kd < 2; ++kd)                                    \
+                        _Pragma("unroll") for (int kw = 0; kw < 2; ++kw)                                \
+                            MVSGI_LERP2(xw[2 * kd][kw], xw[2 * kd + 1][kw], xh[kd][0][kw], xh[kd][1][kw]) \
+                    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                    \
+                        _Pragma("unroll") for (int kw = 0; kw < 2; ++kw)                                \
+                            MVSGI_LERP2(xh[0][kh][kw], xh[1][kh][kw], xo[0][kh][kw], xo[1][kh][kw])      \
+                    _Pragma("unroll") for (int kd = 0; kd < 2; ++kd)                                    \
                         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                \
-                            _Pragma("unroll") for (int kw = 0; kw < 2; ++kw)                            \
-                                MVSGI_LERP2(xh[0][kh][kw], xh[1][kh][kw], xo[0][kh][kw], xo[1][kh][kw])  \
-                        _Pragma("unroll") for (int kd = 0; kd < 2; ++kd)                                \
-                            _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                            \
-                                _Pragma("unroll") for (int kw = 0; kw < 2; ++kw) {                      \
-                                    const bool ok = ((IM[it] >> kd) & (IM[it] >> (2 + kh)) & (IM[it] >> (4 + kw)) & 1u) != 0; \
-                                    u32x2 hi, lo;                                                       \
-                                    split_bf16x4(xo[kd][kh][kw], hi, lo);                               \
-                                    if (!ok) hi = lo = u32x2{0u, 0u};                                   \
-                                    const int v = ((2 * cd + kd) * ITH + 2 * ch + kh) * ITW + 2 * cw + kw; \
-                                    *reinterpret_cast<u32x2*>((DST) + v * kVSB + q * 8) = hi;           \
-                                    *reinterpret_cast<u32x2*>((DST) + v * kVSB + 32 + q * 8) = lo;      \
-                                }                                                                       \
-                    }                                                                                   \
+                            _Pragma("unroll") for (int kw = 0; kw < 2; ++kw) {                          \
+                                const bool ok = ((IM[IT] >> kd) & (IM[IT] >> (2 + kh)) & (IM[IT] >> (4 + kw)) & 1u) != 0; \
+                                u32x2 hi, lo;                                                           \
+                                split_bf16x4(xo[kd][kh][kw], hi, lo);                                   \
+                                if (!ok) hi = lo = u32x2{0u, 0u};                                       \
+                                const int vo_ = ((2 * cd + kd) * ITH + 2 * ch + kh) * ROWP + (2 * cw + kw) * kVSB; \
+                                *reinterpret_cast<u32x2*>((DST) + vo_ + q * 8) = hi;                    \
+                                *reinterpret_cast<u32x2*>((DST) + vo_ + 32 + q * 8) = lo;               \
+                            }                                                                           \
                 }                                                                                       \
+            }
+#define MVSGI_PUT_UPS(CR, IM, DST)                                                                      \
+            { _Pragma("unroll") for (int it = 0; it < NITU; ++it) MVSGI_PUT_UPS1(CR, IM, DST, it) }
+// request unit u+2 / finish unit u+1 cell by cell (no request bursts in front of the consumers' weight fragments)
+#define MVSGI_STEP_UPS(NEW, IMNEW, OLD, IMOLD, DST, DOPUT)                                              \
+            {                                                                                           \
+                MVSGI_ISSUE_UPS_BEGIN()                                                                 \
+                _Pragma("unroll") for (int it = 0; it < NITU; ++it) {                                   \
+                    MVSGI_ISSUE_UPS1(NEW, IMNEW, it)                                                    \
+                    if (DOPUT) MVSGI_PUT_UPS1(OLD, IMOLD, DST, it)                                      \
+                    __builtin_amdgcn_sched_barrier(0);                                                  \
+                }                                                                                       \
+                MVSGI_ISSUE_UPS_END()                                                                   \
             }
             STAMP()
             MVSGI_PLAN_UPS((int)blockIdx.x)
             MVSGI_ISSUE_UPS(crA, imA)                          // unit 0
             MVSGI_PUT_UPS(crA, imA, ldsb)
-            if (1 < U) MVSGI_ISSUE_UPS(crA, imA)               // unit 1 in flight
+            MVSGI_ISSUE_UPS(crA, imA)                          // unit 1 in flight (requests are unconditional, see below)
             STAMP()
             __syncthreads();                                   // image 0 holds unit 0
             STAMP()
             for (int u = 0; u < U; u += 2) {
-                if (u + 2 < U) MVSGI_ISSUE_UPS(crB, imB)
-                if (u + 1 < U) MVSGI_PUT_UPS(crA, imA, ldsb + ((u + 1) & 1) * BUF)
+                MVSGI_STEP_UPS(crB, imB, crA, imA, ldsb + ((u + 1) & 1) * BUF, u + 1 < U)
                 STAMP()
                 __syncthreads();
                 STAMP()
                 if (u + 1 < U) {
-                    if (u + 3 < U) MVSGI_ISSUE_UPS(crA, imA)
-                    if (u + 2 < U) MVSGI_PUT_UPS(crB, imB, ldsb + ((u + 2) & 1) * BUF)
+                    MVSGI_STEP_UPS(crA, imA, crB, imB, ldsb + ((u + 2) & 1) * BUF, u + 2 < U)
                     STAMP()
                     __syncthreads();
                     STAMP()
@@ -310,6 +367,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
 #undef MVSGI_ISSUE_UPS
 #undef MVSGI_PUT_UPS
 #undef MVSGI_LERP2
+#undef MVSGI_ISSUE_UPS_BEGIN
+#undef MVSGI_ISSUE_UPS1
+#undef MVSGI_ISSUE_UPS_END
+#undef MVSGI_PUT_UPS1
+#undef MVSGI_STEP_UPS
 #undef MVSGI_PLAN_UPS
 #undef MVSGI_CLAMP
         } else {
@@ -344,51 +406,70 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
         }
         // request the next unit in walking order (k2, cc2) into a register set; the plan moves on with it
         int k2 = 0, cc2 = 0;
-#define MVSGI_ISSUE(PRE, OK)                                                                            \
+#define MVSGI_ISSUE_BEGIN()                                                                             \
+        if (cc2 == 0 && k2 > 0) { MVSGI_PLAN((int)blockIdx.x + k2 * G) }
+#define MVSGI_ISSUE1(PRE, IT)                                                                           \
+        PRE[IT] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xb) +                   \
+                                                  (unsigned)((goff[IT] + cc2 * 16) * 4));
+#define MVSGI_ISSUE_END(OK)                                                                             \
         {                                                                                               \
-            if (cc2 == 0 && k2 > 0) { MVSGI_PLAN((int)blockIdx.x + k2 * G) }                            \
-            _Pragma("unroll") for (int it = 0; it < NIT; ++it)                                          \
-                PRE[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xb) +           \
-                                                          (unsigned)((goff[it] + cc2 * 16) * 4));       \
             OK = okmask;                                                                                \
             if (++cc2 == nchunks) { cc2 = 0; ++k2; }                                                    \
+            if (k2 >= nmine) { k2 = nmine - 1; cc2 = nchunks - 1; }   /* past the end: re-request the last unit */ \
+        }
+#define MVSGI_ISSUE(PRE, OK)                                                                            \
+        {                                                                                               \
+            MVSGI_ISSUE_BEGIN()                                                                         \
+            _Pragma("unroll") for (int it = 0; it < NIT; ++it) { MVSGI_ISSUE1(PRE, it) }                \
+            MVSGI_ISSUE_END(OK)                                                                         \
+        }
+#define MVSGI_PUT1(PRE, OK, DST, IT)                                                                    \
+        {                                                                                               \
+            const int e = ptid + (IT) * 256;                                                            \
+            if (e < IV * 4) {                                                                           \
+                const int v = e >> 2, q = e & 3;                                                        \
+                u32x2 hi, lo;                                                                           \
+                split_bf16x4(PRE[IT], hi, lo);                                                          \
+                if (!(((OK) >> (IT)) & 1u)) hi = lo = u32x2{0u, 0u};                                    \
+                const int vo_ = V32 ? (v / ITW) * ROWP + (v % ITW) * kVSB : v * kVSB;                   \
+                *reinterpret_cast<u32x2*>((DST) + vo_ + q * 8) = hi;                                    \
+                *reinterpret_cast<u32x2*>((DST) + vo_ + 32 + q * 8) = lo;                               \
+            }                                                                                           \
         }
 #define MVSGI_PUT(PRE, OK, DST)                                                                         \
+        { _Pragma("unroll") for (int it = 0; it < NIT; ++it) MVSGI_PUT1(PRE, OK, DST, it) }
+// one producer step: request unit u+2 into NEW while unit u+1 (OLD, in flight since the last step) is split and
+// written, ITEM BY ITEM.  A burst of NIT x 4 waves x 1 KiB requests would sit in the CU's vector-memory queue in
+// front of the consumers' weight fragments (measured: the burst form of this pipeline was 7 % SLOWER end to end).
+#define MVSGI_STEP(NEW, OKNEW, OLD, OKOLD, DST, DOPUT)                                                  \
         {                                                                                               \
+            MVSGI_ISSUE_BEGIN()                                                                         \
             _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                        \
-                const int e = ptid + it * 256;                                                          \
-                if (e < IV * 4) {                                                                       \
-                    const int v = e >> 2, q = e & 3;                                                    \
-                    u32x2 hi, lo;                                                                       \
-                    split_bf16x4(PRE[it], hi, lo);                                                      \
-                    if (!(((OK) >> it) & 1u)) hi = lo = u32x2{0u, 0u};                                  \
-                    *reinterpret_cast<u32x2*>((DST) + v * kVSB + q * 8) = hi;                           \
-                    *reinterpret_cast<u32x2*>((DST) + v * kVSB + 32 + q * 8) = lo;                      \
-                }                                                                                       \
+                MVSGI_ISSUE1(NEW, it)                                                                   \
+                if (DOPUT) MVSGI_PUT1(OLD, OKOLD, DST, it)                                              \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
             }                                                                                           \
+            MVSGI_ISSUE_END(OKNEW)                                                                      \
         }
         STAMP()
         MVSGI_PLAN((int)blockIdx.x)
         MVSGI_ISSUE(preA, okA)                             // unit 0
         MVSGI_PUT(preA, okA, ldsb)
-        if (1 < U && !(MVSGI_ABL & 8)) MVSGI_ISSUE(preA, okA)      // unit 1 in flight
+        // Every request below is UNCONDITIONAL (past the last unit it re-reads that unit): a request under
+        // `if (u + 2 < U)` makes the register set a phi of old and new values, the compiler materialises the
+        // phi as copies of the freshly loaded registers, and a copy is a use -- s_waitcnt right behind the loads.
+        MVSGI_ISSUE(preA, okA)                             // unit 1 in flight
         STAMP()
         __syncthreads();                                   // image 0 holds unit 0
         STAMP()
         for (int u = 0; u < U; u += 2) {
             // set A holds unit u+1 (in flight); request u+2 into B, then finish u+1
-            if (!(MVSGI_ABL & 8)) {
-                if (u + 2 < U) MVSGI_ISSUE(preB, okB)
-                if (u + 1 < U) MVSGI_PUT(preA, okA, ldsb + ((u + 1) & 1) * BUF)
-            }
+            MVSGI_STEP(preB, okB, preA, okA, ldsb + ((u + 1) & 1) * BUF, u + 1 < U && !(MVSGI_ABL & 8))
             STAMP()
             __syncthreads();                               // unit u multiplied, image of unit u+1 complete
             STAMP()
             if (u + 1 < U) {
-                if (!(MVSGI_ABL & 8)) {
-                    if (u + 3 < U) MVSGI_ISSUE(preA, okA)
-                    if (u + 2 < U) MVSGI_PUT(preB, okB, ldsb + ((u + 2) & 1) * BUF)
-                }
+                MVSGI_STEP(preA, okA, preB, okB, ldsb + ((u + 2) & 1) * BUF, u + 2 < U && !(MVSGI_ABL & 8))
                 STAMP()
                 __syncthreads();
                 STAMP()
@@ -396,8 +477,183 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
         }
 #undef MVSGI_ISSUE
 #undef MVSGI_PUT
+#undef MVSGI_ISSUE_BEGIN
+#undef MVSGI_ISSUE1
+#undef MVSGI_ISSUE_END
+#undef MVSGI_PUT1
+#undef MVSGI_STEP
 #undef MVSGI_PLAN
         }
+    } else if constexpr (V32) {
+        // =========================== consumers, 32x32x16 schedule ===========================
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        const int wm = wave % WM, wn = wave / WM;
+        const int n32 = lane & 31, kh2 = lane >> 5;
+        const char* wpb = reinterpret_cast<const char*>(a.wp);
+        const unsigned lane16 = lane * 16;
+        constexpr int HP = TH / 2;                         // h-row pairs per plane
+        int xbase[MW], tdv[MW], thv[MW], twv[MW];
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+            const int t = wm * MW + i;                     // 32-voxel tile: plane t / HP, rows 2*(t % HP) + {0, 1}
+            tdv[i] = t / HP;
+            thv[i] = 2 * (t % HP) + (n32 >> 4);
+            twv[i] = n32 & 15;
+            xbase[i] = (tdv[i] * ITH + thv[i]) * ROWP + twv[i] * kVSB + kh2 * 16;
+        }
+        const long long frame_elems = (long long)a.Do * a.Ho * a.Wo * a.Cout;
+        int ctc[NW], ctn[NW];
+#define MVSGI_CTILES(DST, CB)                                                         \
+        _Pragma("unroll") for (int j = 0; j < NW; ++j) {                              \
+            const int c_ = ((CB) * WN + wn) * NW + j;                                 \
+            DST[j] = c_ < CT ? c_ : CT - 1;                                           \
+        }
+        // register buffers: 27 taps = 3 x 9 = 9 x 3, so buffer indices are compile-time constants.  Weight
+        // fragments come from L2 (~1 k cycles under load): requested LAW taps (LAW x 192 cycles) ahead;
+        // activation fragments come from LDS: 2 taps ahead.
+        constexpr int VB = 3, VWB = 9, LAW = NW == 1 ? 6 : 4;
+        bf16x8 wh[VWB][NW], wl[VWB][NW], xh[VB][MW], xl[VB][MW];
+        f32x16 acc[MW][NW];
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int j = 0; j < NW; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#define MVSGI_V_LOADW(BUFI, CC, T, CTS)                                                                \
+        _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                               \
+            const char* q_ = wpb + (((long long)(CC) * CT + CTS[j]) * 27 + (T)) * 2048;  /* wave-uniform */ \
+            wh[BUFI][j] = *reinterpret_cast<const bf16x8*>(q_ + l16);                                  \
+            wl[BUFI][j] = *reinterpret_cast<const bf16x8*>(q_ + l16 + 1024u);                          \
+        }
+#define MVSGI_V_READX(BUFI, T)                                                                         \
+        {                                                                                              \
+            const int off_ = (((T) / 9) * ITH + ((T) / 3) % 3) * ROWP + ((T) % 3) * kVSB;              \
+            _Pragma("unroll") for (int i = 0; i < MW; ++i) {                                           \
+                xh[BUFI][i] = *reinterpret_cast<const bf16x8*>(img + xbase[i] + off_);                 \
+                xl[BUFI][i] = *reinterpret_cast<const bf16x8*>(img + xbase[i] + off_ + 32);            \
+            }                                                                                          \
+        }
+#define MVSGI_V_MFMAS(WBUFI, BUFI)                                                                          \
+        _Pragma("unroll") for (int tr = 0; tr < 3; ++tr)                                               \
+            _Pragma("unroll") for (int i = 0; i < MW; ++i)                                             \
+                _Pragma("unroll") for (int j = 0; j < NW; ++j)                                         \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr == 0 ? wl[WBUFI][j] : wh[WBUFI][j], \
+                                                                         tr == 1 ? xl[BUFI][i] : xh[BUFI][i], acc[i][j], 0, 0, 0);
+        int cb_, b_, od0, oh0, ow0;
+        MVSGI_DECODE((int)blockIdx.x, cb_, b_, od0, oh0, ow0)
+        MVSGI_CTILES(ctc, cb_)
+        {
+            unsigned l16 = lane16;
+#pragma unroll
+            for (int t0 = 0; t0 < LAW; ++t0) { MVSGI_V_LOADW(t0, 0, t0, ctc) }
+        }
+        STAMP()
+        __syncthreads();                                   // image 0 holds unit 0
+        STAMP()
+        int k = 0, cc = 0;
+        for (int u = 0; u < U; ++u) {
+            const unsigned char* img = ldsb + (u & 1) * BUF;
+            const bool last = cc + 1 == nchunks;
+            const bool more = u + 1 < U;
+            const int ncc = last ? 0 : cc + 1;
+            int ncb = cb_, nb = b_, nod0 = od0, noh0 = oh0, now0 = ow0;
+            if (last && more) {
+                MVSGI_DECODE((int)blockIdx.x + (k + 1) * G, ncb, nb, nod0, noh0, now0)
+                MVSGI_CTILES(ctn, ncb)
+            } else {
+#pragma unroll
+                for (int j = 0; j < NW; ++j) ctn[j] = ctc[j];
+            }
+            int eoff[MW];                  // in-frame element offset of this lane's voxel (cout 0) or -1
+            f32x4 rres[MW][NW][4], esc[NW][4], esh[NW][4];
+            if (last) {
+                // per-channel scale / shift of this wave's cout tiles: requested before the last slice is
+                // multiplied, so the epilogue does not wait for them one group at a time
+#pragma unroll
+                for (int j = 0; j < NW; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        esc[j][g] = *reinterpret_cast<const f32x4*>(a.scale + ctc[j] * 32 + 8 * g + 4 * kh2);
+                        esh[j][g] = *reinterpret_cast<const f32x4*>(a.shift + ctc[j] * 32 + 8 * g + 4 * kh2);
+                    }
+#pragma unroll
+                for (int i = 0; i < MW; ++i) {
+                    const int od = od0 + tdv[i], oh = oh0 + thv[i], ow = ow0 + twv[i];
+                    const bool inside = od < a.Do && oh < a.Ho && ow < a.Wo;
+                    eoff[i] = inside ? ((od * a.Ho + oh) * a.Wo + ow) * a.Cout + kh2 * 4 : -1;
+                }
+            }
+            MVSGI_V_READX(0, 0)
+            MVSGI_V_READX(1, 1)
+#pragma unroll
+            for (int t_ = 0; t_ < 27; ++t_) {
+                const int cur = t_ % VB, nx2 = (t_ + 2) % VB, wcur = t_ % VWB;
+                unsigned l16 = lane16;
+                asm volatile("" : "+v"(l16));
+                if (t_ + LAW < 27) {
+                    MVSGI_V_LOADW((t_ + LAW) % VWB, cc, t_ + LAW, ctc)
+                } else if (more) {
+                    MVSGI_V_LOADW((t_ + LAW - 27) % VWB, ncc, t_ + LAW - 27, ctn)    // first taps of the next unit
+                }
+                if (t_ + 2 < 27) { MVSGI_V_READX(nx2, t_ + 2) }
+                if (t_ == 26 && last && a.res) {
+                    const float* rb = a.res + (long long)b_ * frame_elems;
+#pragma unroll
+                    for (int i = 0; i < MW; ++i)
+#pragma unroll
+                        for (int j = 0; j < NW; ++j)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                rres[i][j][g] = *reinterpret_cast<const f32x4*>(rb + (eoff[i] >= 0 ? eoff[i] + ctc[j] * 32 + 8 * g : 0));
+                }
+                MVSGI_V_MFMAS(wcur, cur)
+                if (t_ + 2 < 27) {
+                    constexpr int NMEM = 2 * NW + 2 * MW, NMFMA = 3 * MW * NW;
+                    constexpr int RATIO = NMFMA / NMEM > 0 ? NMFMA / NMEM : 1;
+#pragma unroll
+                    for (int q_ = 0; q_ < NMEM; ++q_) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, RATIO, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            STAMP()
+            if (last) {
+                // lane (n32, kh2), register 4g + e of tile (i, j): cout ct*32 + 8g + 4*kh2 + e of voxel n32
+                const int ct0 = (cb_ * WN + wn) * NW;
+                float* yb = a.y + (long long)b_ * frame_elems;
+#pragma unroll
+                for (int i = 0; i < MW; ++i)
+#pragma unroll
+                    for (int j = 0; j < NW; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 r = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} * esc[j][g] + esh[j][g];
+                            if (a.res) r += rres[i][j][g];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                r[e] = r[e] > 0.f ? r[e] : r[e] * a.neg_slope;
+                                acc[i][j][4 * g + e] = 0.f;
+                            }
+                            if (eoff[i] >= 0 && ct0 + j < CT) *reinterpret_cast<f32x4*>(yb + eoff[i] + (ct0 + j) * 32 + 8 * g) = r;
+                        }
+                k += 1;
+                cb_ = ncb; b_ = nb; od0 = nod0; oh0 = noh0; ow0 = now0;
+#pragma unroll
+                for (int j = 0; j < NW; ++j) ctc[j] = ctn[j];
+            }
+            cc = ncc;
+            STAMP()
+            __syncthreads();
+            STAMP()
+        }
+#undef MVSGI_CTILES
+#undef MVSGI_V_LOADW
+#undef MVSGI_V_READX
+#undef MVSGI_V_MFMAS
     } else {
         // =========================== consumers: LDS + L2 weights -> MFMA ===========================
         const int wm = wave % WM, wn = wave / WM;
@@ -682,12 +938,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
 #undef STAMP
 }
 
-template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false, bool PLANE = false>
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false, bool PLANE = false,
+          bool V32 = false>
 int launch_bf16x3(ConvArgs a, hipStream_t st) {
     constexpr int ITD = (TD - 1) * (KD == 1 ? 1 : S) + KD, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
-    constexpr size_t lds_bytes = (size_t)2 * ITD * ITH * ITW * kVSB;      // double-buffered image
+    constexpr int ROWP = V32 ? ((ITW * kVSB + 255) / 256) * 256 : ITW * kVSB;
+    constexpr size_t lds_bytes = (size_t)2 * ITD * ITH * ROWP;             // double-buffered image
     static_assert(lds_bytes <= 160 * 1024, "LDS images too large");
-    auto kern = conv3d_bf16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE>;
+    auto kern = conv3d_bf16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32>;
     static int wgs_per_cu = 0;       // benign race: idempotent
     if (!wgs_per_cu) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -701,7 +959,7 @@ int launch_bf16x3(ConvArgs a, hipStream_t st) {
     a.tiles_d = (int)mvsgi::cdiv(a.Do, TD);
     a.tiles_h = (int)mvsgi::cdiv(a.Ho, TH);
     a.tiles_w = (int)mvsgi::cdiv(a.Wo, TW);
-    const int CT = a.Cout / 16;
+    const int CT = a.Cout / (V32 ? 32 : 16);
     const long long nb = (long long)a.B * a.tiles_d * a.tiles_h * a.tiles_w * mvsgi::cdiv(CT, WN * NW);
     MVSGI_REQUIRE(nb < (1ll << 31), "conv3d: too many units");
     MVSGI_REQUIRE((long long)a.Din * a.Hin * a.Win * a.Cin < (1ll << 29), "conv3d: volume too large for 32-bit byte offsets");

@@ -10,6 +10,8 @@ computes on the CPU.
 """
 from __future__ import annotations
 
+import os
+
 import copy
 from typing import Dict, Optional, Type
 
@@ -33,18 +35,25 @@ NORM3D_TYPE: Dict[str, Type[nn.Module]] = {"batch": nn.BatchNorm3d, "instance": 
 # ------------------------------------------------------------------------------------------
 # lowering of one conv block to the arguments of mvsgi_conv3d_f32
 # ------------------------------------------------------------------------------------------
+# MVSGI_V32=1: 32x32x16-MFMA kernels for the Cout % 32 == 0 layers (measured on par with the 16x16x32 kernels, so off by default)
+_USE_V32 = os.environ.get("MVSGI_V32", "0") != "0"
+
+
 class ConvLaunch:
     """Device-resident launch arguments of one BaseConvBlk3d: PyTorch-layout weight, packed
     MFMA weight (or None), per-channel scale/shift (eval BatchNorm3d or bias), stride, slope."""
-    __slots__ = ("w", "wp", "wp_b3", "wp_c16", "scale", "shift", "stride", "neg_slope", "cin", "cout", "key")
+    __slots__ = ("w", "wp", "wp_b3", "wp_c16", "wp_v32", "scale", "shift", "stride", "neg_slope", "cin", "cout", "key")
 
     def run(self, x_ndhwc: Tensor, res: Optional[Tensor] = None, impl: Optional[int] = None) -> Tensor:
         wp = self.wp
         if impl is None:
             impl = H.CONV_AUTO
             if H.get_conv_mode() == "bf16x3" and self.cin % 16 == 0 and self.cout % 16 == 0:
+                B, D, Hh, W, _ = x_ndhwc.shape
                 if self._c16():
                     impl, wp = H.CONV_BF16X3_C16, self._wp_c16()
+                elif _USE_V32 and self.cout % 32 == 0 and H.conv3d_v32_applies(B, self.cin, D, Hh, W, self.cout, self.stride):
+                    impl, wp = H.CONV_BF16X3_V32, self._wp_v32()
                 else:
                     if self.wp_b3 is None:
                         self.wp_b3 = H.pack_conv_weights_bf16x3(self.w)
@@ -65,6 +74,11 @@ class ConvLaunch:
             self.wp_c16 = H.pack_conv_weights_bf16x3_c16(self.w)
         return self.wp_c16
 
+    def _wp_v32(self):
+        if self.wp_v32 is None:
+            self.wp_v32 = H.pack_conv_weights_bf16x3_v32(self.w)
+        return self.wp_v32
+
     def can_fuse_up2(self) -> bool:
         return H.get_conv_mode() == "bf16x3" and self.stride == 1 and self.cin % 16 == 0 and self.cout % 16 == 0
 
@@ -73,6 +87,10 @@ class ConvLaunch:
         if self._c16():
             return H.conv3d_up2(x_lowres_ndhwc, self._wp_c16(), self.scale, self.shift, res=res,
                                 neg_slope=self.neg_slope, w_layout=H.CONV_BF16X3_C16)
+        B, Dl, Hl, Wl, _ = x_lowres_ndhwc.shape
+        if _USE_V32 and self.cout % 32 == 0 and H.conv3d_v32_applies(B, self.cin, 2 * Dl, 2 * Hl, 2 * Wl, self.cout, 1):
+            return H.conv3d_up2(x_lowres_ndhwc, self._wp_v32(), self.scale, self.shift, res=res,
+                                neg_slope=self.neg_slope, w_layout=H.CONV_BF16X3_V32)
         if self.wp_b3 is None:
             self.wp_b3 = H.pack_conv_weights_bf16x3(self.w)
         return H.conv3d_up2(x_lowres_ndhwc, self.wp_b3, self.scale, self.shift, res=res, neg_slope=self.neg_slope)
@@ -152,6 +170,7 @@ def lower_conv_block(blk) -> ConvLaunch:
     L.wp = H.pack_conv_weights(w)
     L.wp_b3 = None
     L.wp_c16 = None
+    L.wp_v32 = None
     L.scale = scale.contiguous()
     L.shift = shift.contiguous()
     L.stride = int(conv.stride[0])

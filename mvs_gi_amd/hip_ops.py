@@ -13,7 +13,7 @@ from . import _lib
 
 import os
 
-CONV_AUTO, CONV_DIRECT, CONV_MFMA, CONV_BF16X3, CONV_BF16X3_C16 = 0, 1, 2, 3, 4
+CONV_AUTO, CONV_DIRECT, CONV_MFMA, CONV_BF16X3, CONV_BF16X3_C16, CONV_BF16X3_V32 = 0, 1, 2, 3, 4, 5
 
 # Arithmetic of the conv layers: "f32" = exact fp32 MFMA (v_mfma_f32_16x16x4_f32),
 # "bf16x3" = split-bf16 MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate; ~2^-16 per product).
@@ -234,6 +234,25 @@ def pack_conv_weights_bf16x3(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
     wp = torch.empty(lib.mvsgi_conv3d_packed_weight_bytes_bf16x3(Cout, Cin), device=w.device, dtype=torch.uint8)
     _lib.check(lib.mvsgi_conv3d_pack_weights_bf16x3(w.data_ptr(), wp.data_ptr(), Cout, Cin, _stream_ptr(w)),
                "mvsgi_conv3d_pack_weights_bf16x3")
+    return wp
+
+
+def conv3d_v32_applies(B, Cin, Din, Hin, Win, Cout, stride=1) -> bool:
+    """Whether the 32x32x16-MFMA kernel (impl / w_layout CONV_BF16X3_V32) serves this problem
+    (for conv3d_up2 pass the upsampled input size)."""
+    return bool(_lib.load().mvsgi_conv3d_v32_applies(B, Cin, Din, Hin, Win, Cout, stride))
+
+
+def pack_conv_weights_bf16x3_v32(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
+    """[Cout % 32 == 0, Cin % 16 == 0, 3, 3, 3] -> 32x32x16-MFMA split-bf16 layout, or None when unsupported."""
+    lib = _lib.load()
+    w = _dev(w_oidhw, "conv weight")
+    Cout, Cin = w.shape[:2]
+    if tuple(w.shape[2:]) != (3, 3, 3) or Cin % 16 or Cout % 32:
+        return None
+    wp = torch.empty(lib.mvsgi_conv3d_packed_weight_bytes_bf16x3_v32(Cout, Cin), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.mvsgi_conv3d_pack_weights_bf16x3_v32(w.data_ptr(), wp.data_ptr(), Cout, Cin, _stream_ptr(w)),
+               "mvsgi_conv3d_pack_weights_bf16x3_v32")
     return wp
 
 
