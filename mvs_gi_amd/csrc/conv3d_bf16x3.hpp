@@ -20,10 +20,14 @@
 //     fragments only; the producers fetch the NEXT unit's halo brick (one 16-channel slice, fp32
 //     in HBM), split it and write it to the other half of a double-buffered LDS image
 //     [hi0-7 | hi8-15 | lo0-7 | lo8-15 | pad] = 80 B per voxel, while the consumers multiply the
-//     current one.  One __syncthreads() per unit hands the buffers over;
+//     current one.  One __syncthreads() per unit hands the buffers over.  The producers' requests run two
+//     units ahead (two register sets) and are issued item by item between the split / LDS writes of
+//     the previous unit (a burst would queue in front of the consumers' weight fragments);
 //   * weights arrive pre-split and lane-ordered straight from L2 (one coalesced 16-byte load per
-//     lane per fragment), requested 1-2 slots ahead of their MFMAs into rotating registers;
-//   * workgroups are persistent (one or two per CU) and walk (brick, cout-block) units with
+//     lane per fragment), requested 3 slots ahead of their MFMAs into rotating registers;
+//   * template flags select further schedules of the same arithmetic: UPS (trilinear x2 upsample evaluated
+//     in the producers), PLANE (Cout == 16), V32 (32x32x16 MFMA) -- described at the kernel;
+//   * workgroups are persistent (one per CU for the 4x4x16 bricks) and walk (brick, cout-block) units with
 //     stride gridDim.x; the unit index space is re-mapped so that each XCD (= each private L2)
 //     owns a contiguous run of bricks: neighbouring halos and the cout-blocks of a brick share L2.
 #pragma once

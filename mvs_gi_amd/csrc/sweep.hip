@@ -1,18 +1,22 @@
 // K1: fused spherical sweep for gfx950.
 //
-// One thread per output voxel (b, d, ho, wo).  It evaluates the reference's two
-// bilinear_grid_sample calls per candidate (dsta_mvs/model/backports/backports.py:34-86)
-// for all cameras, and the masked mean/variance of
-// cost_volume_builder/spherical_sweep_avg.py:92-125, without materialising any of the
-// ~115 intermediate tensors per candidate, and writes the C channels of the voxel as
-// contiguous 16-byte stores (channels-last volume, ready for the conv kernels).
+// Evaluates, per output voxel (b, d, ho, wo), the reference's two bilinear_grid_sample calls per
+// candidate (dsta_mvs/model/backports/backports.py:34-86) for all cameras and the masked
+// mean / variance of cost_volume_builder/spherical_sweep_avg.py:92-125 (or the concat of
+// spherical_sweep.py:38-68), without materialising any of the ~115 intermediate tensors per
+// candidate, and writes the voxel's C channels as 16-byte stores (channels-last volume, what the
+// conv kernels read).  Arithmetic follows the reference operation by operation with fp
+// contraction disabled, so the raw volume is bit-identical to the PyTorch CPU result.
 //
-// Neighbouring threads are neighbouring `wo`, whose sampling positions are neighbouring
-// texels for real (smooth) grids, so the per-channel-plane gathers of a wave fall into a
-// few cache lines; feats stay in the feature extractor's NCHW layout (no transpose pass).
-//
-// Arithmetic follows the reference operation by operation with fp contraction disabled,
-// so the raw volume is bit-identical to the PyTorch CPU result.
+// Kernels, slowest to fastest (all the same bits):
+//   sweep_std_kernel / sweep_cat_kernel      feats in the extractor's NCHW planes, one thread per voxel
+//                                            (any C, up to 6 cameras);
+//   sweep_std_nhwc_kernel / sweep_cat_nhwc_kernel   channels-last feats: 4 lanes share a voxel, one 64-byte
+//                                            texel per tap through buffer descriptors (zero padding = the
+//                                            hardware range check), XCD-contiguous block order;
+//   sweep_validity_kernel + sweep_std_nhwc_v_kernel   the default: the rig-constant mask half evaluated once
+//                                            per rig, the per-frame kernel walks the candidates of a row
+//                                            with the next candidate's grid point prefetched.
 #include "common.hpp"
 
 namespace {
