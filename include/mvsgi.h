@@ -200,6 +200,14 @@ int mvsgi_softargmin_div_f32(const float* costs, const float* inv_idx, float* in
 int mvsgi_ncv_to_nvc_f32(const float* x, float* y, int B, int C, long long V, mvsgi_stream_t stream);
 int mvsgi_nvc_to_ncv_f32(const float* x, float* y, int B, int C, long long V, mvsgi_stream_t stream);
 
+/* ResConvBlk2d.forward (common/common_modules.py:165-176) for 16 -> 16 channels, 3x3, stride 1 in ONE launch
+ * (the extractor's residual blocks are HBM-bound; fused, the intermediate never leaves the CU):
+ *   y = act( conv2( act( conv1(x) * scale1 + shift1 ) ) * scale2 + shift2 + x ),   x / y [N][H][W][16], x != y
+ * w_packed1 / w_packed2 from mvsgi_conv2d_pack_weights_bf16x3(Cout = Cin = 16); split-bf16 MFMA arithmetic. */
+int mvsgi_resblock2d_f32(const float* x, const void* w_packed1, const float* scale1, const float* shift1,
+                         const void* w_packed2, const float* scale2, const float* shift2, float* y,
+                         int N, int H, int W, float neg_slope, mvsgi_stream_t stream);
+
 /* ---- sampling-grid generator ---------------------------------------
  * The closed forms of dsta_mvs/support/dataset/torch_cuda_sweep.py, composed as
  * MultiViewCameraModelDataset.make_sweep_grid_cuda does (support/dataset/multi_view_camera_model_dataset.py:474-521):

@@ -18,6 +18,7 @@ namespace {
 
 #include "conv3d_bf16x3.hpp"
 #include "conv3d_f32mfma.hpp"
+#include "resblock2d_bf16x3.hpp"
 
 struct Conv2dArgs {
     const float* x;
@@ -255,4 +256,41 @@ extern "C" int mvsgi_conv2d_f32(const float* x, const float* w_oihw, const void*
         case D2_F32_S2: return launch_mfma<2, 1, 4, 1, 1, 4, 16, 2, 1>(a, st);
     }
     return mvsgi::fail("mvsgi_conv2d_f32: bad variant %d", v);
+}
+
+// ResConvBlk2d.forward (common/common_modules.py:165-176) for 16 -> 16 channels, 3x3, stride 1, in one launch:
+//   y = act( conv2(act(conv1(x) * scale1 + shift1)) * scale2 + shift2 + x )
+// x / y [N][H][W][16] channels-last; w_packed1 / w_packed2 from mvsgi_conv2d_pack_weights_bf16x3 (Cout = Cin = 16).
+extern "C" int mvsgi_resblock2d_f32(const float* x, const void* w_packed1, const float* scale1, const float* shift1,
+                                    const void* w_packed2, const float* scale2, const float* shift2, float* y, int N,
+                                    int H, int W, float neg_slope, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(x && w_packed1 && w_packed2 && scale1 && shift1 && scale2 && shift2 && y, "mvsgi_resblock2d_f32: null pointer");
+    MVSGI_REQUIRE(N > 0 && H > 0 && W > 0, "mvsgi_resblock2d_f32: non-positive dimension");
+    MVSGI_REQUIRE((long long)H * W * 16 < (1ll << 31), "mvsgi_resblock2d_f32: image too large for 32-bit element offsets");
+    MVSGI_REQUIRE(x != y, "mvsgi_resblock2d_f32: in-place operation is not supported (bricks read their neighbours' inputs)");
+    ResBlk2dArgs a{};
+    a.x = x; a.y = y;
+    a.wp1 = static_cast<const f32x4*>(w_packed1); a.wp2 = static_cast<const f32x4*>(w_packed2);
+    a.scale1 = scale1; a.shift1 = shift1; a.scale2 = scale2; a.shift2 = shift2;
+    a.N = N; a.H = H; a.W = W; a.neg_slope = neg_slope;
+    a.tiles_h = (int)mvsgi::cdiv(H, 14);
+    a.tiles_w = (int)mvsgi::cdiv(W, 30);
+    const long long nb = (long long)N * a.tiles_h * a.tiles_w;
+    MVSGI_REQUIRE(nb < (1ll << 31), "mvsgi_resblock2d_f32: too many bricks");
+    a.total_units = (int)nb;
+    constexpr size_t lds_bytes = (size_t)(2 * 18 * 34 + 18 * 34) * kVSB;     // input window x 2 + conv1 result
+    static int wgs_per_cu = 0;
+    if (!wgs_per_cu) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock2d_bf16x3_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return mvsgi::fail("mvsgi_resblock2d_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        int occ = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock2d_bf16x3_kernel, 512, lds_bytes);
+        if (e != hipSuccess || occ < 1) occ = 1;
+        wgs_per_cu = occ > 2 ? 2 : occ;
+    }
+    const long long resident = 256ll * wgs_per_cu;
+    hipLaunchKernelGGL(resblock2d_bf16x3_kernel, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(512), lds_bytes,
+                       mvsgi::as_stream(stream), a);
+    return mvsgi::check_launch("mvsgi_resblock2d_f32");
 }

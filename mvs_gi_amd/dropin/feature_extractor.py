@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import copy
 import math
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -135,11 +136,22 @@ class BaseConvBlk2d(nn.Module):
         return h + 2 * self.out_pad, w + 2 * self.out_pad
 
 
+_FUSE_RESBLOCK = os.environ.get("MVSGI_FUSE_RESBLOCK", "1") != "0"
+
+
 def res_block2d_nhwc(blk, x: Tensor) -> Tensor:
     if not _is_identity(blk.one_by_one) or getattr(blk, "out_pad", 0) != 0:
         raise NotImplementedError("ResConvBlk2d with projection / out_pad is not on the extractor path")
-    r = lower_conv2d_block(blk.blk1).run(x)
-    return lower_conv2d_block(blk.blk2).run(r, res=x)
+    L1, L2 = lower_conv2d_block(blk.blk1), lower_conv2d_block(blk.blk2)
+    if _FUSE_RESBLOCK and H.get_conv_mode() == "bf16x3" and L1.k == 3 and L2.k == 3 and L1.stride == 1 and L2.stride == 1 \
+            and (L1.cin, L1.cout, L2.cin, L2.cout) == (16, 16, 16, 16) and L1.neg_slope == L2.neg_slope:
+        # both convs in one launch, the intermediate stays in LDS (mvsgi_resblock2d_f32)
+        for L in (L1, L2):
+            if L.wp_b3 is None:
+                L.wp_b3 = H.pack_conv2d_weights_bf16x3(L.w)
+        return H.resblock2d(x, L1.wp_b3, L1.scale, L1.shift, L2.wp_b3, L2.scale, L2.shift, L1.neg_slope)
+    r = L1.run(x)
+    return L2.run(r, res=x)
 
 
 class ResConvBlk2d(nn.Module):

@@ -485,3 +485,17 @@ def deform_conv2d(x_nhwc, offset, w_packed, scale, shift, kernel_size, stride=(1
                                            padding[1], dilation[0], dilation[1], float(neg_slope), _stream_ptr(x)),
                "mvsgi_deform_conv2d_f32")
     return y
+
+
+def resblock2d(x_nhwc, wp1, scale1, shift1, wp2, scale2, shift2, neg_slope=0.01) -> torch.Tensor:
+    """Fused 16 -> 16 residual block (two 3x3 convs + BN + LeakyReLU + skip): x [N, H, W, 16] -> y, same shape."""
+    lib = _lib.load()
+    x = _dev(x_nhwc, "x")
+    N, Hh, W, C = x.shape
+    if C != 16 or scale1.numel() != 16 or scale2.numel() != 16:
+        raise AssertionError(f"resblock2d is the 16-channel block, got x {tuple(x.shape)}")
+    y = torch.empty_like(x)
+    _lib.check(lib.mvsgi_resblock2d_f32(x.data_ptr(), wp1.data_ptr(), scale1.data_ptr(), shift1.data_ptr(),
+                                        wp2.data_ptr(), scale2.data_ptr(), shift2.data_ptr(), y.data_ptr(), N, Hh, W,
+                                        float(neg_slope), _stream_ptr(x)), "mvsgi_resblock2d_f32")
+    return y

@@ -721,3 +721,38 @@ def test_sphere_feature_extractor_vs_oracle(conv_mode):
     p2 = {"fl." + k_[len("final_layer."):]: v for k_, v in p.items() if k_.startswith("final_layer.")}
     yref = O.sphere_block2d(x, p2, "fl", res=x).numpy()
     assert _rel(y.cpu().numpy(), yref) <= 2e-5
+
+
+# ------------------------------------------------------------------ fused residual block of the extractor
+@pytest.mark.parametrize("shape", [(2, 30, 45), (1, 14, 14), (3, 64, 256), (1, 9, 100), (5, 29, 15)])
+def test_fused_resblock2d_vs_two_convs(shape):
+    """mvsgi_resblock2d_f32 (both 3x3 convs of ResConvBlk2d in one launch, intermediate in LDS) vs the oracle's two
+    conv blocks and vs the two-launch HIP path; images smaller / larger than a 14x14 brick, ragged edges."""
+    N, Hh, W = shape
+    rng = np.random.default_rng(sum(shape))
+    p = {}
+    for name in ("blk1", "blk2"):
+        p[f"{name}.conv_layer.weight"] = (rng.standard_normal((16, 16, 3, 3)) / 12).astype(np.float32)
+        p[f"{name}.norm_layer.weight"] = rng.uniform(0.5, 1.5, 16).astype(np.float32)
+        p[f"{name}.norm_layer.bias"] = rng.normal(0, 0.3, 16).astype(np.float32)      # non-zero: conv1 of zero padding is not zero
+        p[f"{name}.norm_layer.running_mean"] = rng.normal(0, 0.1, 16).astype(np.float32)
+        p[f"{name}.norm_layer.running_var"] = rng.uniform(0.5, 1.5, 16).astype(np.float32)
+    x = rng.standard_normal((N, 16, Hh, W)).astype(np.float32)
+    pt = {k_: torch.from_numpy(v) for k_, v in p.items()}
+    xt = torch.from_numpy(x)
+    ref = O.conv_block2d(O.conv_block2d(xt, pt, "blk1"), pt, "blk2", res=xt).numpy()
+    blk = dropin.ResConvBlk2d(16, 16, 3, activation=torch.nn.LeakyReLU(), norm_layer=torch.nn.BatchNorm2d(16))
+    blk.load_state_dict(pt, strict=False)
+    blk = blk.eval().to(DEV)
+    old_mode = H.get_conv_mode()
+    try:
+        H.set_conv_mode("bf16x3")
+        with torch.no_grad():
+            y = blk(_g(x))
+            from mvs_gi_amd.dropin import feature_extractor as FE
+            xn = _g(x).permute(0, 2, 3, 1).contiguous()
+            two = FE.lower_conv2d_block(blk.blk2).run(FE.lower_conv2d_block(blk.blk1).run(xn), res=xn)
+    finally:
+        H.set_conv_mode(old_mode)
+    assert _rel(y.cpu().numpy(), ref) <= 1e-4
+    assert _rel(y.permute(0, 2, 3, 1).cpu().numpy(), two.cpu().numpy()) <= 2e-5
