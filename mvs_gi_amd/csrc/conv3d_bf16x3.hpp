@@ -246,6 +246,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
         if constexpr (UPS) {
             constexpr int CD = ITD / 2, CH = ITH / 2, CW = ITW / 2, NC = CD * CH * CW;
             constexpr int NITU = (NC * 4 + 255) / 256;         // cell items (cell, channel quad) per producer thread
+            // The last round is rarely full (324 items on 256 threads: 68 left).  When at most half of the threads
+            // would be busy, its items are split in two along D -- thread pairs share a cell item, each blends and
+            // writes the 4 upsampled voxels of one kd -- so the critical wave does 1 + 0.45 instead of 2 items.
+            constexpr int RF = NC * 4 / 256, REM = NC * 4 - RF * 256;
+            constexpr bool HALF = REM > 0 && 2 * REM <= 256;
+#define MVSGI_UPS_CQ(IT) ((HALF && (IT) == RF) ? RF * 256 + (ptid >> 1) : ptid + (IT) * 256)      /* cell-quad index */
+#define MVSGI_UPS_LIVE(IT) ((HALF && (IT) == RF) ? (ptid >> 1) < REM : ptid + (IT) * 256 < NC * 4)
             const int Dl = a.Din >> 1, Hl = a.Hin >> 1, Wl = a.Win >> 1;
             int lo_d[NITU], lo_h[NITU], lo_w[NITU];             // lower low-res corner of the cell (may be -1)
             unsigned inmask[NITU];                              // bit axis*2+k: upsampled voxel k of the cell is inside
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                 MVSGI_DECODE(UNIT, cb_, b_, od_, oh_, ow_)                                              \
                 (void)cb_;                                                                              \
                 _Pragma("unroll") for (int it = 0; it < NITU; ++it) {                                   \
-                    const int c = (ptid + it * 256) >> 2;                                               \
+                    const int c = MVSGI_UPS_CQ(it) >> 2;                                                \
                     const int cw = c % CW, ch = (c / CW) % CH, cd = c / (CW * CH);                      \
                     const int gd = od_ - 1 + 2 * cd, gh = oh_ - 1 + 2 * ch, gw = ow_ - 1 + 2 * cw;      \
                     lo_d[it] = (gd - 1) >> 1;                                                           \
@@ -276,9 +283,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
             if (cc2 == 0 && k2 > 0) { MVSGI_PLAN_UPS((int)blockIdx.x + k2 * G) }
 #define MVSGI_ISSUE_UPS1(CR, IM, IT)                                                                    \
             {                                                                                           \
-                const int e = ptid + (IT) * 256;                                                        \
-                const int q = e & 3;                                                                    \
-                const bool live = e < NC * 4;                                                           \
+                const int q = MVSGI_UPS_CQ(IT) & 3;                                                     \
+                const bool live = MVSGI_UPS_LIVE(IT);                                                   \
                 const int d0 = live ? MVSGI_CLAMP(lo_d[IT], Dl) : 0, d1 = live ? MVSGI_CLAMP(lo_d[IT] + 1, Dl) : 0; \
                 const int h0 = live ? MVSGI_CLAMP(lo_h[IT], Hl) : 0, h1 = live ? MVSGI_CLAMP(lo_h[IT] + 1, Hl) : 0; \
                 const int w0 = live ? MVSGI_CLAMP(lo_w[IT], Wl) : 0, w1 = live ? MVSGI_CLAMP(lo_w[IT] + 1, Wl) : 0; \
@@ -307,7 +313,34 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                 O1 = __builtin_elementwise_fma(d_, f32x4{0.75f, 0.75f, 0.75f, 0.75f}, (A));             \
             }
 #define MVSGI_PUT_UPS1(CR, IM, DST, IT)                                                                 \
-            {                                                                                           \
+            if (HALF && (IT) == RF) {                                                                   \
+                /* half item: this thread's kd = ptid & 1; blend along D first (one output plane), then H, then W */ \
+                if (MVSGI_UPS_LIVE(IT)) {                                                               \
+                    const int cq_ = MVSGI_UPS_CQ(IT), c = cq_ >> 2, q = cq_ & 3, kd = ptid & 1;         \
+                    const int cw = c % CW, ch = (c / CW) % CH, cd = c / (CW * CH);                      \
+                    const float f_ = kd ? 0.75f : 0.25f;                                                \
+                    const f32x4 f4_ = {f_, f_, f_, f_};                                                 \
+                    f32x4 xd[2][2], xh[2][2], xo[2][2];                                                 \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                     \
+                        const f32x4 d_ = __builtin_elementwise_fma(CR[IT][j], f32x4{-1.f, -1.f, -1.f, -1.f}, CR[IT][4 + j]); \
+                        xd[j >> 1][j & 1] = __builtin_elementwise_fma(d_, f4_, CR[IT][j]);              \
+                    }                                                                                   \
+                    _Pragma("unroll") for (int kw = 0; kw < 2; ++kw)                                    \
+                        MVSGI_LERP2(xd[0][kw], xd[1][kw], xh[0][kw], xh[1][kw])                         \
+                    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                    \
+                        MVSGI_LERP2(xh[kh][0], xh[kh][1], xo[kh][0], xo[kh][1])                         \
+                    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                    \
+                        _Pragma("unroll") for (int kw = 0; kw < 2; ++kw) {                              \
+                            const bool ok = ((IM[IT] >> kd) & (IM[IT] >> (2 + kh)) & (IM[IT] >> (4 + kw)) & 1u) != 0; \
+                            u32x2 hi, lo;                                                               \
+                            split_bf16x4(xo[kh][kw], hi, lo);                                           \
+                            if (!ok) hi = lo = u32x2{0u, 0u};                                           \
+                            const int vo_ = ((2 * cd + kd) * ITH + 2 * ch + kh) * ROWP + (2 * cw + kw) * kVSB; \
+                            *reinterpret_cast<u32x2*>((DST) + vo_ + q * 8) = hi;                        \
+                            *reinterpret_cast<u32x2*>((DST) + vo_ + 32 + q * 8) = lo;                   \
+                        }                                                                               \
+                }                                                                                       \
+            } else {                                                                                    \
                 const int e = ptid + (IT) * 256;                                                        \
                 if (e < NC * 4) {                                                                       \
                     const int c = e >> 2, q = e & 3;                                                    \
@@ -378,6 +411,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
 #undef MVSGI_STEP_UPS
 #undef MVSGI_PLAN_UPS
 #undef MVSGI_CLAMP
+#undef MVSGI_UPS_CQ
+#undef MVSGI_UPS_LIVE
         } else {
         int goff[NIT];
         unsigned okmask = 0, okA = 0, okB = 0;
@@ -736,7 +771,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
         // ---- plane schedule (Cout == 16): fragments of one in-plane tap pair at a time ----
         constexpr int NPP = 5;                              // in-plane tap pairs (9 taps)
         constexpr int PD = PLANE ? TD + 2 : 1;
-        bf16x8 pwh[2][PLANE ? 3 : 1], pwl[2][PLANE ? 3 : 1];             // [buffer][kd]
+        bf16x8 pwh[3][PLANE ? 3 : 1], pwl[3][PLANE ? 3 : 1];             // [buffer][kd]: weights run two pairs ahead
         bf16x8 pxh[2][PD], pxl[2][PD];                                   // [buffer][input plane]
         const int pbase = (wm * ITW + col) * kVSB + (kg >> 1) * 16;      // row wm, plane 0, tap (0, 0)
 #define MVSGI_PL_LOADW(BUFI, CC, P)                                                                    \
@@ -756,15 +791,16 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
             }                                                                                          \
         }
 // term-major, then kd, then plane: the three products of one accumulator are >= TD MFMAs apart
-#define MVSGI_PL_MFMAS(BUFI)                                                                           \
+#define MVSGI_PL_MFMAS(WBUFI, BUFI)                                                                         \
         _Pragma("unroll") for (int tr = 0; tr < 3; ++tr)                                               \
             _Pragma("unroll") for (int kd = 0; kd < 3; ++kd)                                           \
                 _Pragma("unroll") for (int i = 0; i < TD; ++i)                                         \
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr == 0 ? pwl[BUFI][kd] : pwh[BUFI][kd], \
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr == 0 ? pwl[WBUFI][kd] : pwh[WBUFI][kd], \
                                                                          tr == 1 ? pxl[BUFI][i + kd] : pxh[BUFI][i + kd], acc[i][0], 0, 0, 0);
         if constexpr (PLANE) {
             unsigned l16 = lane16;
             MVSGI_PL_LOADW(0, 0, 0)
+            MVSGI_PL_LOADW(1, 0, 1)
         } else {
             unsigned l16 = lane16;
 #pragma unroll
@@ -806,36 +842,41 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
             }
             if constexpr (PLANE) {
                 MVSGI_PL_READX(0, 0)
+                // 6 slots = 5 pairs + 1 rotation-only slot, so that pair q of every unit sits in weight buffer q % 3.
+                // Weight fragments are requested two slots (72 MFMAs, ~1.2 k cycles) ahead: one pair ahead is less than
+                // an L2 round trip under load.
 #pragma unroll
-                for (int p_ = 0; p_ < NPP; ++p_) {
+                for (int p_ = 0; p_ < NPP + 1; ++p_) {
                     const int cur = p_ & 1, nxt = cur ^ 1;
                     unsigned l16 = lane16;
                     asm volatile("" : "+v"(l16));
-                    if (p_ + 1 < NPP) {
-                        MVSGI_PL_LOADW(nxt, cc, p_ + 1)
-                        MVSGI_PL_READX(nxt, p_ + 1)
-                    } else if (last && a.res) {
-                        // residual planes of this row: behind the unit's last weight requests
-                        const float* rb = a.res + (long long)b_ * frame_elems;
-#pragma unroll
-                        for (int i = 0; i < MW; ++i)
-                            rres[i][0] = *reinterpret_cast<const f32x4*>(rb + (eoff[i] >= 0 ? eoff[i] : 0));
+                    if (p_ + 2 < NPP) {
+                        MVSGI_PL_LOADW((p_ + 2) % 3, cc, p_ + 2)
+                    } else if (p_ + 2 > NPP && more) {
+                        MVSGI_PL_LOADW(p_ + 2 - (NPP + 1), ncc, p_ + 2 - (NPP + 1))     // pairs 0, 1 of the next unit
                     }
-                    MVSGI_PL_MFMAS(cur)
-                    if (p_ + 1 < NPP) {
-                        // 18 fragment requests spread over the 36 MFMAs of the pair
+                    if (p_ < NPP) {
+                        if (p_ + 1 < NPP) {
+                            MVSGI_PL_READX(nxt, p_ + 1)
+                        } else if (last && a.res) {
+                            // residual planes of this row: behind the unit's last weight requests
+                            const float* rb = a.res + (long long)b_ * frame_elems;
 #pragma unroll
-                        for (int q_ = 0; q_ < 6 + 2 * PD; ++q_) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 36 / (6 + 2 * PD) > 0 ? 36 / (6 + 2 * PD) : 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);
+                            for (int i = 0; i < MW; ++i)
+                                rres[i][0] = *reinterpret_cast<const f32x4*>(rb + (eoff[i] >= 0 ? eoff[i] : 0));
                         }
-                        __builtin_amdgcn_sched_group_barrier(0x008, 36, 0);
+                        MVSGI_PL_MFMAS(p_ % 3, cur)
+                        if (p_ + 1 < NPP) {
+                            // the fragment requests of the slot spread over its 36 MFMAs
+#pragma unroll
+                            for (int q_ = 0; q_ < 6 + 2 * PD; ++q_) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 36 / (6 + 2 * PD) > 0 ? 36 / (6 + 2 * PD) : 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);
+                            }
+                            __builtin_amdgcn_sched_group_barrier(0x008, 36, 0);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                }
-                if (more) {                                  // first pair of the next unit (hidden by the epilogue / barrier)
-                    unsigned l16 = lane16;
-                    MVSGI_PL_LOADW(0, ncc, 0)
                 }
             } else {
             MVSGI_READX(0, 0, 0, MW)
