@@ -94,13 +94,18 @@ class InferencePipeline:
     float / 255 conversion is folded into the extractor's stem kernel and the division by bf into the
     soft-argmin kernel, so the only host traffic is the image upload and the result download."""
 
-    def __init__(self, cfg: PathConfig, weights, consts, device="cuda"):
+    def __init__(self, cfg: PathConfig, weights, consts, device="cuda", extractor: str = "simple"):
+        """extractor: 'simple' = SimpleFeatExtraction (G16V, config29), 'sphere' = SphereEquirectFeatExtraction with the
+        sphere-convolution final layer (G16VV, config103; configs/feature_extractor/sphereconv_featext.yaml)."""
         self.cfg = cfg
         self.hot = HotPath(cfg, weights, consts, device)
         Hi, Wi = cfg.feat_hw
-        fe = dropin.SimpleFeatExtraction(in_size=(4 * Hi, 4 * Wi), in_chs=3, chs=cfg.feat_chs, k_sz=3, layers=[5, 10])
-        fe.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in weights["feature_extractor"].items()},
-                           strict=True)
+        Extractor = {"simple": dropin.SimpleFeatExtraction, "sphere": dropin.SphereEquirectFeatExtraction}[extractor]
+        fe = Extractor(in_size=(4 * Hi, 4 * Wi), in_chs=3, chs=cfg.feat_chs, k_sz=3, layers=[5, 10])
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in weights["feature_extractor"].items()}
+        if extractor == "sphere":          # the offset field is a constructor-made buffer unless the checkpoint brings one
+            sd.setdefault("final_layer.blk.0.offset", fe.final_layer.blk[0].offset)
+        fe.load_state_dict(sd, strict=True)
         self.feature_extractor = fe.eval().to(self.hot.device)
         self.hot.dist_regressor.post_div = float(cfg.bf)          # inference_class.py:111-114
         self.hot.dist_regressor.return_norm_costs = False         # discarded by inference callers

@@ -598,6 +598,33 @@ def test_inference_pipeline_uint8_in_metric_out(golden_dir, conv_mode):
     assert err <= 1e-3
 
 
+def test_inference_pipeline_with_sphere_extractor(conv_mode):
+    """The G16VV front end (sphere-conv final layer) through the same facade: uint8 images in, inv_dist / bf out,
+    against the oracle chain (sphere extractor -> hot path); deform_conv2d itself is restated, see oracle header."""
+    from mvs_gi_amd.configs import CONFIGS, DIST_8L
+    from mvs_gi_amd.pipeline import InferencePipeline
+    cfg = CONFIGS["G16V"].scaled(feat_hw=(16, 64), mask_hw=(64, 256), cv_hw=(8, 32), dist_cands=DIST_8L)
+    seed = 9
+    w = synth.make_weights(cfg, seed=seed)
+    w["feature_extractor"] = _sphere_weights(seed)
+    inp = synth.make_inputs(cfg, seed=seed, batch=1)
+    pipe = InferencePipeline(cfg, w, inp, device=DEV, extractor="sphere")
+    rng = np.random.default_rng(seed)
+    imgs_u8 = rng.integers(0, 256, (cfg.num_cams, 64, 256, 3), dtype=np.uint8)
+    out = pipe({"imgs": [im for im in imgs_u8]})
+    t = O.to_torch(inp)
+    p = {k_: torch.from_numpy(v) for k_, v in w["feature_extractor"].items()}
+    p["final_layer.blk.0.offset"] = pipe.feature_extractor.final_layer.blk[0].offset.cpu()
+    with torch.no_grad():
+        x = torch.from_numpy(imgs_u8).permute(0, 3, 1, 2).float() / 255.0              # inference_class.py:104-107
+        f = O.sphere_feature_extractor(x, p)
+        ref = O.hot_path(f.unsqueeze(0), t["grids"], t["grid_masks"], t["masks"], O.to_torch(w), cfg.builder,
+                         cfg.dist_cands, cfg.bf, cfg.interp_scale_factor, cfg.pre_interp)
+    ref = (ref / cfg.bf).squeeze().numpy()
+    assert out.shape == ref.shape == (16, 64)
+    assert _rel(out, ref) <= 1e-3
+
+
 # ------------------------------------------------------------------ sampling-grid generator (SURVEY 8(f) rank 2)
 def test_sweep_grid_generator_vs_reference_goldens(golden_dir):
     """HIP closed forms (dropin/sweep_grids.py, reference class names) vs the reference's own outputs.
