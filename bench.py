@@ -233,6 +233,16 @@ def main(argv=None):
     cpu_res = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_res = cpu_baseline_subprocess(args)      # before any GPU initialisation
+    if not os.path.isfile(os.path.join(ROOT, "mvs_gi_amd", "libmvsgi_hip.so")):
+        # the library normally travels with the tree (built by __graft_entry__.build()); build it rather than fail
+        if local_rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            for _ in range(600):
+                if os.path.isfile(os.path.join(ROOT, "mvs_gi_amd", "libmvsgi_hip.so")):
+                    break
+                time.sleep(0.5)
     import numpy as np
     import torch
     import torch.distributed as dist
