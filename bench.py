@@ -10,14 +10,23 @@ barrier and the max-over-ranks of the elapsed time) -> "scaling": "weak".
 Prints ONE JSON line (rank 0) with the driver's contract plus
   "roofline":     the dominant kernel's achieved TFLOP/s (algorithmic conv FLOPs of its
                   launches / their HIP-event durations measured in the timed region)
-                  against the gfx950 fp32-MFMA peak;
+                  against the gfx950 bf16-MFMA (or fp32-MFMA) peak;
   "cpu_baseline": the CPU oracle (torch-CPU restatement of the reference path) timed on this
-                  host's cores on a bounded sample (rank 0, N == 1 only).
+                  host's cores on a bounded sample (rank 0, N == 1 only), whole path + per stage;
+  "parity":       inverse-distance error of the benchmarked weights against that oracle (B=1,
+                  outside the timed region);
+and, at N == 1 (outside the headline's timed region, skipped with --no-extras):
+  "extras":       the same path with the rig-constant cache off, as a hipGraph replay, at B=1
+                  (latency), with the HIP feature extractor in front (images -> inverse distance)
+                  and fed from pinned host memory (uint8 frames, double-buffered H2D);
+  "configs":      the other BASELINE.json configurations (G16VV, E8, 4cam-32), each with
+                  frames/s, ms/step, dominant kernel and roofline fraction.
 """
 import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,27 +36,30 @@ if ROOT not in sys.path:
 PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0}   # MI355X_MICROARCH.md: dense fp32-MFMA / bf16-MFMA peaks
 DTYPE = {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA operands, f32 accumulate/activations)"}
 PEAK_HBM_GBS = 8000.0
+EXTRA_CONFIGS = (("G16VV", 8), ("E8", 8), ("4cam-32", 8))      # (tag, frames per step)
+LIB = os.path.join(ROOT, "mvs_gi_amd", "libmvsgi_hip.so")
 
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="G16V")
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
     ap.add_argument("--mode", default="bf16x3", choices=["bf16x3", "f32"],
                     help="conv arithmetic: split-bf16 MFMA (3 bf16 MFMAs per product, fp32 accumulate) or exact fp32 MFMA")
-    ap.add_argument("--graph", action="store_true",
-                    help="also time hipGraph replays of the same step (reported as graph_replay_*; the headline "
-                         "value and the per-kernel events always come from the eager launches)")
-    ap.add_argument("--end-to-end", action="store_true",
-                    help="also time imgs -> inv_dist with the HIP feature extractor in front (SURVEY 8(f) rank 1); "
-                         "reported as end_to_end_*; the headline metric stays the plane-sweep hot path")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extras / configs blocks (rig cache off, hipGraph, B=1 latency, images -> inverse "
+                         "distance, host feed, other BASELINE configs); they never touch the headline's timed region")
+    ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of each extras / configs measurement")
+    ap.add_argument("--graph", action="store_true", help=argparse.SUPPRESS)         # kept: now part of extras
+    ap.add_argument("--end-to-end", action="store_true", help=argparse.SUPPRESS)    # kept: now part of extras
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl=RCCL)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-dump", default=None, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
 
@@ -66,9 +78,11 @@ def frame_shard(total_frames: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def timed_steps(step_fn, sync_fn, steps: int, warmup: int, world: int, backend_ready: bool, device=None):
+def timed_steps(step_fn, sync_fn, steps: int, warmup: int, world: int, backend_ready: bool, device=None,
+                per_rank=None):
     """W warmup steps, barrier+sync, exactly K timed steps, sync+barrier; returns the MAX
-    elapsed seconds over ranks."""
+    elapsed seconds over ranks.  `per_rank` (a list) receives every rank's own elapsed seconds
+    (rank order) so that a straggler is visible."""
     import torch
     import torch.distributed as dist
     for _ in range(warmup):
@@ -81,14 +95,23 @@ def timed_steps(step_fn, sync_fn, steps: int, warmup: int, world: int, backend_r
     for _ in range(steps):
         step_fn()
     sync_fn()
+    own = time.perf_counter() - t0
     if backend_ready:
         dist.barrier()
     el = time.perf_counter() - t0
     if backend_ready:
         on_cpu = device is None or dist.get_backend() == "gloo"
-        t = torch.tensor([el], dtype=torch.float64, device="cpu" if on_cpu else device)
+        dv = "cpu" if on_cpu else device
+        t = torch.tensor([el], dtype=torch.float64, device=dv)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+        if per_rank is not None:
+            mine = torch.tensor([own], dtype=torch.float64, device=dv)
+            allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(allr, mine)
+            per_rank[:] = [float(x.item()) for x in allr]
+    elif per_rank is not None:
+        per_rank[:] = [own]
     return el
 
 
@@ -96,7 +119,7 @@ def timed_steps(step_fn, sync_fn, steps: int, warmup: int, world: int, backend_r
 # per-kernel attribution: HIP events around every conv launch of the timed region
 # ------------------------------------------------------------------------------------------
 class ConvProbe:
-    """Wraps hip_ops.conv3d: records a HIP event pair (on the launch stream) around each
+    """Wraps hip_ops.conv3d / conv3d_up2: records a HIP event pair (on the launch stream) around each
     call and the algorithmic FLOPs and kernel name of the launch."""
 
     def __init__(self, H):
@@ -156,14 +179,18 @@ class ConvProbe:
 
 
 def read_pmc_traffic(kernel_name: str):
-    """HBM bytes per launch of `kernel_name` from a committed rocprofv3 --pmc summary
-    (profiles/pmc_traffic.json, written by tools/summarize_rocprof.py), or None."""
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc summary
+    (profiles/pmc_traffic.json, written by tools/summarize_rocprof.py from separate --pmc passes of this same
+    command): (bytes | None, source string).  The counters cannot be read from inside the process, so the line
+    says where the number comes from instead of presenting it as measured in this run."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         d = json.load(open(p))
-        return d.get(kernel_name, {}).get("hbm_bytes_per_launch")
+        v = d.get(kernel_name, {}).get("hbm_bytes_per_launch")
+        return v, (f"profiles/pmc_traffic.json ({d.get('_source', 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE')})"
+                   if v is not None else None)
     except Exception:
-        return None
+        return None, None
 
 
 # ------------------------------------------------------------------------------------------
@@ -181,14 +208,15 @@ def effective_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline_subprocess(args):
+def cpu_baseline_subprocess(args, dump_path):
     """Run the CPU baseline in a child process, before this process touches the GPU, with a
-    hard timeout so a slow host can never stall the benchmark."""
+    hard timeout so a slow host can never stall the benchmark.  The child also writes the oracle's
+    inv_dist of the seed-0 frame to `dump_path` (.npy) for the parity block."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", args.config,
-           "--cpu-seconds", str(args.cpu_seconds)]
+           "--cpu-seconds", str(args.cpu_seconds), "--cpu-dump", dump_path]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_seconds * 6 + 90)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_seconds * 6 + 120)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:   # report, never fail the GPU measurement
@@ -196,9 +224,11 @@ def cpu_baseline_subprocess(args):
                 "sample": f"CPU baseline did not finish: {type(e).__name__}"}
 
 
-def cpu_baseline(cfg, seconds: float):
+def cpu_baseline(cfg, seconds: float, dump_path=None):
     """The oracle (CPU restatement of the reference's PyTorch path) on this host's cores:
-    B=1 frames of the same workload until ~`seconds` have elapsed (at least 3 frames)."""
+    B=1 frames of the same workload until ~`seconds` have elapsed (at least 3 frames), then the three
+    stages on their own (min / median of 3)."""
+    import numpy as np
     import torch
     from mvs_gi_amd import synth
     from oracle import mvsgi_oracle as O
@@ -210,17 +240,106 @@ def cpu_baseline(cfg, seconds: float):
     def one():
         return O.hot_path(inp["feats"], inp["grids"], inp["grid_masks"], inp["masks"], w, cfg.builder,
                           cfg.dist_cands, cfg.bf, cfg.interp_scale_factor, cfg.pre_interp)
-    one()
-    n, t0 = 0, time.perf_counter()
+    ref = one()
+    if dump_path:
+        np.save(dump_path, ref.numpy())
+    n, t0, per = 0, time.perf_counter(), []
     while True:
+        t1 = time.perf_counter()
         one()
+        per.append(time.perf_counter() - t1)
         n += 1
         el = time.perf_counter() - t0
         if (el >= seconds and n >= 3) or n >= 200:
             break
+    stages = {}
+    with torch.no_grad():
+        def timed(fn, reps=3):
+            ts, out = [], None
+            for _ in range(reps):
+                t1 = time.perf_counter()
+                out = fn()
+                ts.append((time.perf_counter() - t1) * 1e3)
+            return out, {"min_ms": round(min(ts), 2), "median_ms": round(sorted(ts)[len(ts) // 2], 2)}
+        sweep = (lambda: O.sweep_std_masked(inp["feats"], inp["grids"], inp["grid_masks"], inp["masks"])) \
+            if cfg.builder == "std" else (lambda: O.sweep_concat(inp["feats"], inp["grids"]))
+        vol_raw, stages["cv_builder.sweep"] = timed(sweep)
+        vol, stages["cv_builder.post_vol"] = timed(lambda: O.post_vol(vol_raw, w["cv_builder"]))
+        costs, stages["cv_regulator"] = timed(lambda: O.regulator_forward(vol, w["cv_regulator"]))
+        _, stages["dist_regressor"] = timed(lambda: O.soft_argmin(costs, cfg.dist_cands, cfg.bf, cfg.interp_scale_factor,
+                                                                  cfg.pre_interp))
+    per.sort()
     return {"value": round(n / el, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "frame_ms_min": round(per[0] * 1e3, 1), "frame_ms_median": round(per[len(per) // 2] * 1e3, 1),
+            "stages": stages,
             "sample": f"{n} single-frame (B=1) {cfg.tag} passes of oracle/mvsgi_oracle.py (torch {torch.__version__} "
-                      f"CPU, fp32) in {el:.1f} s after 1 warm-up"}
+                      f"CPU, fp32) in {el:.1f} s after 1 warm-up; stages: min / median of 3"}
+
+
+# ------------------------------------------------------------------------------------------
+def ensure_library(local_rank: int):
+    """The library normally travels with the tree (built by __graft_entry__.build()).  When it is missing or
+    stale, local rank 0 builds it (to a temporary path, renamed into place -- never a half-written file) and the
+    other ranks wait until the finished file loads and passes the ABI check; a failed or overdue build exits
+    non-zero on every rank."""
+    from mvs_gi_amd import _lib
+
+    def loadable():
+        try:
+            _lib.load()
+            return True
+        except Exception:
+            return False
+    if os.path.isfile(LIB) and loadable():
+        return
+    if local_rank == 0:
+        import __graft_entry__
+        __graft_entry__.build()
+        return
+    deadline = time.time() + 900
+    while time.time() < deadline:
+        if os.path.isfile(LIB) and loadable():
+            return
+        time.sleep(1.0)
+    raise SystemExit("bench.py: libmvsgi_hip.so did not appear (build by local rank 0 failed or timed out)")
+
+
+def measure_path(cfg, B, mode, steps, warmup, dev, H, HotPath, synth, torch, np, rng, graph=False):
+    """frames/s, ms/step and per-conv-kernel attribution of one configuration at one batch size (single process,
+    outside the headline's timed region)."""
+    from mvs_gi_amd.configs import path_gflop
+    H.set_conv_mode(mode)
+    inp = synth.make_inputs(cfg, seed=0, batch=1)
+    hp = HotPath(cfg, synth.make_weights(cfg, seed=0), inp, device=dev)
+    feats = torch.from_numpy(rng.standard_normal((B, *inp["feats"].shape[1:]), dtype=np.float32)).to(dev)
+
+    def step():
+        hp(feats)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+    with ConvProbe(H) as probe:
+        for _ in range(warmup):
+            step()
+        sync()
+        probe.enabled = True
+        el = timed_steps(step, sync, steps, 0, 1, False, dev)
+        probe.enabled = False
+        agg = probe.summary()
+    dname, (dn, dflops, dms) = max(agg.items(), key=lambda kv: kv[1][2])
+    ach = dflops / (dms * 1e-3) / 1e12
+    res = {"frames_per_step": B, "frames_per_s": round(B * steps / el, 2), "ms_per_step": round(el / steps * 1e3, 4),
+           "path_tflops": round(B * steps / el * path_gflop(cfg) / 1e3, 2),
+           "dominant_kernel": dname, "dominant_avg_us": round(dms / dn * 1e3, 2),
+           "dominant_tflops": round(ach, 2), "frac": round(ach / PEAK_TFLOPS[mode], 4)}
+    if graph:
+        hp.capture(feats)
+        gel = timed_steps(lambda: hp.replay(), sync, steps, warmup, 1, False, dev)
+        res["graph_replay_frames_per_s"] = round(B * steps / gel, 2)
+        res["graph_replay_ms_per_step"] = round(gel / steps * 1e3, 4)
+    del hp, feats
+    torch.cuda.empty_cache()
+    return res
 
 
 def main(argv=None):
@@ -228,21 +347,18 @@ def main(argv=None):
     rank, local_rank, world = dist_env()
     if args.cpu_baseline_only:
         from mvs_gi_amd.configs import CONFIGS as _C
-        print(json.dumps(cpu_baseline(_C[args.config], args.cpu_seconds)), flush=True)
+        print(json.dumps(cpu_baseline(_C[args.config], args.cpu_seconds, args.cpu_dump)), flush=True)
         return
-    cpu_res = None
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
+                             f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    cpu_res, ref_dump = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_res = cpu_baseline_subprocess(args)      # before any GPU initialisation
-    if not os.path.isfile(os.path.join(ROOT, "mvs_gi_amd", "libmvsgi_hip.so")):
-        # the library normally travels with the tree (built by __graft_entry__.build()); build it rather than fail
-        if local_rank == 0:
-            import __graft_entry__
-            __graft_entry__.build()
-        else:
-            for _ in range(600):
-                if os.path.isfile(os.path.join(ROOT, "mvs_gi_amd", "libmvsgi_hip.so")):
-                    break
-                time.sleep(0.5)
+        ref_dump = os.path.join(tempfile.mkdtemp(prefix="mvsgi_bench_"), "oracle_inv_dist.npy")
+        cpu_res = cpu_baseline_subprocess(args, ref_dump)      # before any GPU initialisation
+    ensure_library(local_rank)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -250,10 +366,6 @@ def main(argv=None):
     from mvs_gi_amd.configs import CONFIGS, path_gflop
     from mvs_gi_amd.pipeline import HotPath
 
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
-                             f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     if os.environ.get("MVSGI_BENCH_SHARE_GPU"):      # test hook: N ranks on one device (use --backend gloo)
         local_rank = 0
@@ -273,7 +385,8 @@ def main(argv=None):
     H.set_conv_mode(args.mode)
     peak = PEAK_TFLOPS[args.mode]
     inp = synth.make_inputs(cfg, seed=0, batch=1)
-    hp = HotPath(cfg, synth.make_weights(cfg, seed=0), inp, device=dev)
+    weights = synth.make_weights(cfg, seed=0)
+    hp = HotPath(cfg, weights, inp, device=dev)
     rng = np.random.default_rng(1000 + rank)     # every rank owns different frames
     feats = torch.from_numpy(rng.standard_normal((B, *inp["feats"].shape[1:]), dtype=np.float32)).to(dev)
     out = {}
@@ -284,49 +397,18 @@ def main(argv=None):
     def sync():
         torch.cuda.synchronize(dev)
 
+    per_rank = []
     with ConvProbe(H) as probe:
         for _ in range(args.warmup):
             step()
         sync()
         probe.enabled = True
-        el = timed_steps(step, sync, args.steps, 0, world, backend_ready, dev)
+        el = timed_steps(step, sync, args.steps, 0, world, backend_ready, dev, per_rank)
         probe.enabled = False
         sync()
         agg = probe.summary()
 
     assert torch.isfinite(out["inv"]).all()
-    graph_res = None
-    if args.graph:
-        hp.capture(feats)
-
-        def gstep():
-            hp.replay()
-        gel = timed_steps(gstep, sync, args.steps, args.warmup, world, backend_ready, dev)
-        graph_res = {"graph_replay_frames_per_s": round(B * world * args.steps / gel, 2),
-                     "graph_replay_ms_per_step": round(gel / args.steps * 1e3, 4)}
-    e2e_res = None
-    if args.end_to_end:
-        from mvs_gi_amd import dropin
-        Hi, Wi = cfg.feat_hw
-        fe = dropin.SimpleFeatExtraction(in_size=(4 * Hi, 4 * Wi), in_chs=3, chs=cfg.feat_chs, k_sz=3, layers=[5, 10])
-        fe.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_extractor_weights(0).items()}, strict=True)
-        fe = fe.eval().to(dev)
-        imgs = torch.from_numpy(rng.random((B * cfg.num_cams, 3, 4 * Hi, 4 * Wi), dtype=np.float32)).to(dev)
-
-        def estep():
-            with torch.no_grad():
-                f = fe(imgs)
-            out["inv"], out["pr"] = hp(f.reshape(B, cfg.num_cams, *f.shape[1:]))
-
-        def fstep():
-            with torch.no_grad():
-                out["f"] = fe(imgs)
-        eel = timed_steps(estep, sync, args.steps, args.warmup, world, backend_ready, dev)
-        fel = timed_steps(fstep, sync, args.steps, args.warmup, world, backend_ready, dev)
-        e2e_res = {"end_to_end_frames_per_s": round(B * world * args.steps / eel, 2),
-                   "end_to_end_ms_per_step": round(eel / args.steps * 1e3, 4),
-                   "feature_extractor_ms_per_step": round(fel / args.steps * 1e3, 4),
-                   "feature_extractor_tflops": round(B * 58.06 / (fel / args.steps) / 1e3, 2)}
     frames = B * world * args.steps
     value = frames / el
     # dominant kernel = largest total time among the conv variants
@@ -334,8 +416,9 @@ def main(argv=None):
     dname, (dn, dflops, dms) = dom
     achieved = dflops / (dms * 1e-3) / 1e12
     conv_ms = sum(v[2] for v in agg.values())
+    traffic, traffic_src = read_pmc_traffic(dname)
     res = {
-        "metric": "stereo frames/sec/GPU (G16V, 3-cam, D=16) + inv-dist L1 vs reference",
+        "metric": f"stereo frames/sec/GPU ({cfg.tag}, {cfg.num_cams}-cam, D={cfg.num_cands}) + inv-dist L1 vs reference",
         "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPE[args.mode], "data": "synthetic",
@@ -343,25 +426,45 @@ def main(argv=None):
                                f"regulator=({cfg.reg_in_chs},{cfg.reg_f_int_chs}), feats {cfg.feat_hw}, cv {cfg.cv_hw}",
                    "frames_per_gpu_per_step": B, "parallelism": f"frame-sharded x{world} (no collective)",
                    "rig_constants": "grids / grid_masks / masks resident in HBM; validity byte and packed weights lowered "
-                                    "once during warm-up (DESIGN.md section 1)",
+                                    "once during warm-up (DESIGN.md section 1); extras.rig_cache_off re-samples them every step",
                    "path_gflop_per_frame": round(path_gflop(cfg), 2)},
         "frames_per_sec_per_gpu": round(value / world, 2),
+        "per_rank_frames_per_s": {"min": round(B * args.steps / max(per_rank), 2), "max": round(B * args.steps / min(per_rank), 2)}
+        if per_rank else None,
         "path_tflops": round(value * path_gflop(cfg) / 1e3, 2),
         "roofline": {"bound": "mfma", "kernel": dname, "achieved": round(achieved, 2), "peak": peak,
                      "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "note": ("achieved = ALGORITHMIC conv FLOPs / kernel time; the split-bf16 kernel issues 3 bf16 "
                               "MFMA FLOPs per algorithmic FLOP, so frac tops out at 1/3" if args.mode == "bf16x3"
                               else "exact fp32 MFMA"),
-                     "traffic": read_pmc_traffic(dname), "launches": dn,
+                     "traffic": traffic, "traffic_source": traffic_src, "launches": dn,
                      "avg_launch_us": round(dms / dn * 1e3, 2), "gflop_per_launch": round(dflops / dn / 1e9, 3),
                      "conv_time_frac_of_step": round(conv_ms / (el * 1e3), 3)},
         "kernels": {k: {"launches": v[0], "avg_us": round(v[2] / v[0] * 1e3, 2),
                         "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2)} for k, v in sorted(agg.items())},
     }
-    if graph_res is not None:
-        res.update(graph_res)
-    if e2e_res is not None:
-        res.update(e2e_res)
+    # ---- parity of the benchmarked weights: the seed-0 frame (B=1) against the CPU oracle's inverse distance
+    if ref_dump is not None and os.path.isfile(ref_dump):
+        ref = np.load(ref_dump)
+        got = hp(torch.from_numpy(inp["feats"]).to(dev))[0].cpu().numpy()
+        res["parity"] = {"max_rel": float(np.abs(got - ref).max() / np.abs(ref).max()),
+                         "mean_l1_rel": float(np.abs(got - ref).mean() / np.abs(ref).mean()),
+                         "bar": 1e-3, "ref": "oracle/mvsgi_oracle.py (CPU fp32 restatement pinned to the reference goldens)",
+                         "frames": 1, "mode": args.mode}
+    # ---- extras: single GPU only, outside the timed region above
+    if world == 1 and rank == 0 and not args.no_extras:
+        res["extras"] = run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, value)
+        del hp, feats
+        torch.cuda.empty_cache()
+        cfgs = {}
+        for tag, b in EXTRA_CONFIGS:
+            if tag == cfg.tag:
+                continue
+            try:
+                cfgs[tag] = measure_path(CONFIGS[tag], b, args.mode, args.extra_steps, 3, dev, H, HotPath, synth, torch, np, rng)
+            except Exception as e:       # never lose the headline to an extra
+                cfgs[tag] = {"error": f"{type(e).__name__}: {e}"}
+        res["configs"] = cfgs
     if cpu_res is not None:
         res["cpu_baseline"] = cpu_res
     if backend_ready:
@@ -369,6 +472,124 @@ def main(argv=None):
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(res), flush=True)
+
+
+def run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, headline_fps):
+    """Measurements beside the headline (same process, same device, after the timed region)."""
+    from mvs_gi_amd import dropin
+    from mvs_gi_amd.pipeline import HotPath
+    ex = {}
+    K, W = args.extra_steps, 3
+
+    def sync():
+        torch.cuda.synchronize(dev)
+
+    def guarded(name, fn):
+        try:
+            ex[name] = fn()
+        except Exception as e:
+            ex[name] = {"error": f"{type(e).__name__}: {e}"}
+
+    def rig_off():
+        hp.cv_builder.cache_rig_constants = False
+        try:
+            el = timed_steps(lambda: hp(feats), sync, K, W, 1, False, dev)
+        finally:
+            hp.cv_builder.cache_rig_constants = True
+        return {"frames_per_s": round(B * K / el, 2), "ms_per_step": round(el / K * 1e3, 4),
+                "note": "grid_masks / masks re-sampled inside every step (MVSGI_RIG_CACHE=0 behaviour)"}
+    guarded("rig_cache_off", rig_off)
+
+    def graph():
+        hp.capture(feats)
+        el = timed_steps(lambda: hp.replay(), sync, K, W, 1, False, dev)
+        return {"frames_per_s": round(B * K / el, 2), "ms_per_step": round(el / K * 1e3, 4)}
+    guarded("graph_replay", graph)
+
+    def b1():
+        r = measure_path(cfg, 1, args.mode, 200, 20, dev, H, HotPath, synth, torch, np, rng, graph=True)
+        return {"eager_ms": r["ms_per_step"], "graph_replay_ms": r["graph_replay_ms_per_step"],
+                "eager_frames_per_s": r["frames_per_s"], "graph_replay_frames_per_s": r["graph_replay_frames_per_s"],
+                "dominant_kernel": r["dominant_kernel"], "frac": r["frac"]}
+    guarded("latency_b1", b1)
+
+    # ---- images -> inverse distance (HIP feature extractor in front), HBM-resident and host-fed
+    Hi, Wi = cfg.feat_hw
+    N = cfg.num_cams
+
+    def make_extractor():
+        fe = dropin.SimpleFeatExtraction(in_size=(4 * Hi, 4 * Wi), in_chs=3, chs=cfg.feat_chs, k_sz=3, layers=[5, 10])
+        fe.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_extractor_weights(0).items()}, strict=True)
+        return fe.eval().to(dev)
+
+    def e2e():
+        fe = make_extractor()
+        imgs = torch.from_numpy(rng.integers(0, 256, (B * N, 4 * Hi, 4 * Wi, 3), dtype=np.uint8)).to(dev)
+
+        def estep():
+            with torch.no_grad():
+                f = fe(imgs)
+            hp(f.reshape(B, N, *f.shape[1:]))
+
+        def fstep():
+            with torch.no_grad():
+                fe(imgs)
+        eel = timed_steps(estep, sync, K, W, 1, False, dev)
+        fel = timed_steps(fstep, sync, K, W, 1, False, dev)
+        r = {"frames_per_s": round(B * K / eel, 2), "ms_per_step": round(eel / K * 1e3, 4),
+             "feature_extractor_ms_per_step": round(fel / K * 1e3, 4),
+             "feature_extractor_tflops": round(B * 58.06 / (fel / K) / 1e3, 2), "input": "uint8 HWC images resident in HBM"}
+        # B = 1 latency of the whole chain
+        img1 = imgs[:N].contiguous()
+
+        def e1():
+            with torch.no_grad():
+                f = fe(img1)
+            hp(f.reshape(1, N, *f.shape[1:]))
+        e1l = timed_steps(e1, sync, 100, 10, 1, False, dev)
+        r["b1_ms"] = round(e1l / 100 * 1e3, 4)
+        # host feed: uint8 frames in pinned memory, double-buffered H2D on a side stream overlapped with compute
+        nbuf = 3
+        host = [torch.from_numpy(rng.integers(0, 256, (B * N, 4 * Hi, 4 * Wi, 3), dtype=np.uint8)).pin_memory()
+                for _ in range(nbuf)]
+        devb = [torch.empty_like(imgs) for _ in range(2)]
+        copy_s = torch.cuda.Stream(device=dev)
+        ready = [torch.cuda.Event() for _ in range(2)]
+        freed = [torch.cuda.Event() for _ in range(2)]
+        main_s = torch.cuda.current_stream(dev)
+        state = {"i": 0}
+
+        def upload(slot, k):
+            with torch.cuda.stream(copy_s):
+                copy_s.wait_event(freed[slot])
+                devb[slot].copy_(host[k % nbuf], non_blocking=True)
+                ready[slot].record(copy_s)
+
+        for s_ in range(2):
+            freed[s_].record(main_s)
+        upload(0, 0)
+
+        def hstep():
+            i = state["i"]
+            slot = i & 1
+            upload(slot ^ 1, i + 1)                  # next batch crosses PCIe while this one is computed
+            main_s.wait_event(ready[slot])
+            with torch.no_grad():
+                f = fe(devb[slot])
+            hp(f.reshape(B, N, *f.shape[1:]))
+            freed[slot].record(main_s)
+            state["i"] = i + 1
+        hel = timed_steps(hstep, sync, K, W, 1, False, dev)
+        bytes_per_frame = N * 4 * Hi * 4 * Wi * 3
+        r["host_feed"] = {"frames_per_s": round(B * K / hel, 2), "ms_per_step": round(hel / K * 1e3, 4),
+                          "vs_resident": round((B * K / hel) / (B * K / eel), 4),
+                          "bytes_per_frame": bytes_per_frame,
+                          "h2d_GBps": round(B * K * bytes_per_frame / hel / 1e9, 2),
+                          "how": "uint8 HWC frames in pinned host memory, two device buffers, copies on a side stream "
+                                 "overlapped with the previous batch's compute"}
+        return r
+    guarded("images_to_inverse_distance", e2e)
+    return ex
 
 
 if __name__ == "__main__":

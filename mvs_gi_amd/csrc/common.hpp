@@ -37,4 +37,38 @@ inline hipStream_t as_stream(mvsgi_stream_t s) { return reinterpret_cast<hipStre
 
 inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
+// Per-(kernel, device) launch set-up of the persistent kernels: the dynamic-LDS limit is a per-device function
+// attribute and the persistent grid is sized from THAT device's CU count and residency (a process may drive several
+// devices, or a partitioned / smaller one).  Each launcher keeps one `static PersistentGeom[kMaxDevices]`.
+constexpr int kMaxDevices = 32;
+struct PersistentGeom {
+    int wgs_per_cu;   // 0 = not set up on this device yet
+    int cus;
+};
+template <class K>
+inline int persistent_geometry(K kern, int threads, size_t lds_bytes, int max_wgs_per_cu,
+                               PersistentGeom (&cache)[kMaxDevices], const char* what, PersistentGeom& out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail("%s: hipGetDevice: %s", what, hipGetErrorString(e));
+    if (dev < 0 || dev >= kMaxDevices) return fail("%s: device ordinal %d not supported (max %d)", what, dev, kMaxDevices);
+    PersistentGeom g = cache[dev];           // benign race: the set-up is idempotent
+    if (!g.wgs_per_cu) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes);
+        if (e != hipSuccess) return fail("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+        int occ = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, lds_bytes);
+        if (e != hipSuccess || occ < 1) occ = 1;
+        int cus = 0;
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess || cus < 1) return fail("%s: cannot read the device's CU count", what);
+        g.wgs_per_cu = occ > max_wgs_per_cu ? max_wgs_per_cu : occ;
+        g.cus = cus;
+        cache[dev] = g;
+    }
+    out = g;
+    return 0;
+}
+
 }  // namespace mvsgi

@@ -279,17 +279,10 @@ extern "C" int mvsgi_resblock2d_f32(const float* x, const void* w_packed1, const
     MVSGI_REQUIRE(nb < (1ll << 31), "mvsgi_resblock2d_f32: too many bricks");
     a.total_units = (int)nb;
     constexpr size_t lds_bytes = (size_t)(2 * 18 * 34 + 18 * 34) * kVSB;     // input window x 2 + conv1 result
-    static int wgs_per_cu = 0;
-    if (!wgs_per_cu) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock2d_bf16x3_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return mvsgi::fail("mvsgi_resblock2d_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        int occ = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock2d_bf16x3_kernel, 512, lds_bytes);
-        if (e != hipSuccess || occ < 1) occ = 1;
-        wgs_per_cu = occ > 2 ? 2 : occ;
-    }
-    const long long resident = 256ll * wgs_per_cu;
+    static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
+    mvsgi::PersistentGeom geo;
+    if (mvsgi::persistent_geometry(resblock2d_bf16x3_kernel, 512, lds_bytes, 2, geo_cache, "mvsgi_resblock2d_f32", geo)) return 1;
+    const long long resident = ((long long)geo.cus * geo.wgs_per_cu) / 8 * 8 > 0 ? ((long long)geo.cus * geo.wgs_per_cu) / 8 * 8 : 8;
     hipLaunchKernelGGL(resblock2d_bf16x3_kernel, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(512), lds_bytes,
                        mvsgi::as_stream(stream), a);
     return mvsgi::check_launch("mvsgi_resblock2d_f32");

@@ -991,16 +991,9 @@ int launch_bf16x3(ConvArgs a, hipStream_t st) {
     constexpr size_t lds_bytes = (size_t)2 * ITD * ITH * ROWP;             // double-buffered image
     static_assert(lds_bytes <= 160 * 1024, "LDS images too large");
     auto kern = conv3d_bf16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32>;
-    static int wgs_per_cu = 0;       // benign race: idempotent
-    if (!wgs_per_cu) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return mvsgi::fail("conv3d: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        int occ = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 512, lds_bytes);
-        if (e != hipSuccess || occ < 1) occ = 1;
-        wgs_per_cu = occ > 2 ? 2 : occ;
-    }
+    static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
+    mvsgi::PersistentGeom geo;
+    if (mvsgi::persistent_geometry(kern, 512, lds_bytes, 2, geo_cache, "conv3d(bf16x3)", geo)) return 1;
     a.tiles_d = (int)mvsgi::cdiv(a.Do, TD);
     a.tiles_h = (int)mvsgi::cdiv(a.Ho, TH);
     a.tiles_w = (int)mvsgi::cdiv(a.Wo, TW);
@@ -1031,7 +1024,8 @@ int launch_bf16x3(ConvArgs a, hipStream_t st) {
 #endif
     // persistent grid (a multiple of 8 unless it covers every unit once): each workgroup walks the
     // units blockIdx.x + k*gridDim.x, which stay on its XCD's contiguous run of the index space
-    const long long resident = 256ll * wgs_per_cu;
+    // (the unit walk needs gridDim.x % 8 == 0 or gridDim.x == total: CU counts of whole-XCD devices are multiples of 8)
+    const long long resident = ((long long)geo.cus * geo.wgs_per_cu) / 8 * 8 > 0 ? ((long long)geo.cus * geo.wgs_per_cu) / 8 * 8 : 8;
     const unsigned grid = (unsigned)(nb <= resident ? nb : resident);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds_bytes, st, a);
     return mvsgi::check_launch("mvsgi_conv3d_f32(bf16x3)");

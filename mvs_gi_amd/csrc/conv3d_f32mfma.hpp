@@ -146,13 +146,9 @@ int launch_mfma(ConvArgs a, hipStream_t st) {
     constexpr size_t lds_bytes = (size_t)ITD * ITH * ITW * kVS * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS tile too large");
     auto kern = conv3d_mfma_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD>;
-    static bool attr_done = false;   // benign race: idempotent
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return mvsgi::fail("conv3d: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
-    }
+    static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};      // per device: the LDS limit is a per-device attribute
+    mvsgi::PersistentGeom geo;
+    if (mvsgi::persistent_geometry(kern, 256, lds_bytes, 8, geo_cache, "conv3d(f32 mfma)", geo)) return 1;
     a.tiles_d = (int)mvsgi::cdiv(a.Do, TD);
     a.tiles_h = (int)mvsgi::cdiv(a.Ho, TH);
     a.tiles_w = (int)mvsgi::cdiv(a.Wo, TW);

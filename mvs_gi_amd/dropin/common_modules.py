@@ -101,15 +101,22 @@ def _is_identity(m) -> bool:
 
 
 def _fingerprint(blk) -> tuple:
+    """Everything the lowered launch record depends on: parameter identity and in-place version (pointer and
+    version as SEPARATE entries), the norm layer's mode / eps, the activation and the stride.  `training` is part
+    of the key, so a later `model.train()` re-lowers and raises instead of silently reusing eval statistics."""
     conv = blk.conv_layer
-    parts = [conv.weight.data_ptr(), conv.weight._version]
+    parts = [conv.weight.data_ptr(), conv.weight._version, tuple(conv.stride)]
     if conv.bias is not None:
         parts += [conv.bias.data_ptr(), conv.bias._version]
     norm = blk.norm_layer
-    if isinstance(norm, nn.BatchNorm3d):
+    parts.append(type(norm).__name__)
+    if isinstance(norm, (nn.BatchNorm3d, nn.BatchNorm2d)):
+        parts += [bool(norm.training), float(norm.eps)]
         for t in (norm.weight, norm.bias, norm.running_mean, norm.running_var):
             if t is not None:
                 parts += [t.data_ptr(), t._version]
+    act = blk.activation
+    parts += [type(act).__name__, float(getattr(act, "negative_slope", 0.0))]
     return tuple(parts)
 
 

@@ -20,7 +20,7 @@ from . import common_modules as cm
 from .common_modules import NORM3D_TYPE, RELU_TYPE
 
 
-_RIG_VALIDITY = weakref.WeakKeyDictionary()      # module -> (key, vmask)
+_RIG_VALIDITY = weakref.WeakKeyDictionary()      # module -> ((grids, grid_masks, masks), versions, vmask)
 _RIG_CACHE_ENV = os.environ.get("MVSGI_RIG_CACHE", "1") != "0"
 
 
@@ -39,8 +39,13 @@ class _SweepBase(nn.Module):
                                          activation=self.relu_type(), norm_layer=self.norm_type(feat_chs))
 
 
-def _rig_key(*tensors):
-    return tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device) for t in tensors)
+def _rig_hit(entry, tensors) -> bool:
+    """A cache entry holds STRONG references to the three rig tensors it was computed from and their in-place
+    version counters: identity (`is`) + version decide a hit.  Holding the references also keeps the caching
+    allocator from handing the same addresses to another rig's tensors (a key built from data_ptr() alone would
+    then match a freed-and-reallocated rig and silently reuse the wrong validity byte)."""
+    return entry is not None and all(a is b for a, b in zip(entry[0], tensors)) \
+        and entry[1] == tuple(t._version for t in tensors)
 
 
 def std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=None) -> Tensor:
@@ -54,12 +59,12 @@ def std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=None) -> Tensor:
         and H.nhwc_sweep_ok(feats) and grids.is_cuda
     if not use_cache:
         return H.sweep_std(feats, grids, grid_masks, masks)
-    key = _rig_key(grids, grid_masks, masks)
+    tensors = (grids, grid_masks, masks)
     cached = _RIG_VALIDITY.get(owner)
-    if cached is None or cached[0] != key:
-        cached = (key, H.sweep_validity(grids, grid_masks, masks))
-        _RIG_VALIDITY[owner] = cached            # weak: dies with the module, never pickled with it
-    return H.sweep_std_valid(feats, grids, cached[1])
+    if not _rig_hit(cached, tensors):
+        cached = (tensors, tuple(t._version for t in tensors), H.sweep_validity(grids, grid_masks, masks))
+        _RIG_VALIDITY[owner] = cached            # weak on the module: dies with it, never pickled with it
+    return H.sweep_std_valid(feats, grids, cached[2])
 
 
 def cat_sweep_ndhwc(feats, grids) -> Tensor:

@@ -17,6 +17,7 @@ import torch
 from torch import nn, Tensor
 
 from .. import hip_ops as H
+from . import common_modules as cm
 from .common_modules import NoOp, NORM2D_TYPE, RELU_TYPE, _is_identity
 
 
@@ -39,12 +40,7 @@ class Conv2dLaunch:
 
 def lower_conv2d_block(blk) -> Conv2dLaunch:
     conv: nn.Conv2d = blk.conv_layer
-    parts = [conv.weight.data_ptr(), conv.weight._version]
-    norm = blk.norm_layer
-    if isinstance(norm, nn.BatchNorm2d):
-        parts += [t.data_ptr() + t._version for t in (norm.weight, norm.bias, norm.running_mean, norm.running_var)
-                  if t is not None]
-    key = tuple(parts)
+    key = cm._fingerprint(blk)        # pointer and version as separate entries, bias, norm mode / eps, activation, stride
     cached = blk.__dict__.get("_mvsgi_launch")
     if cached is not None and cached.key == key:
         return cached
@@ -307,10 +303,15 @@ class SphereConvEquirect2d(nn.Module):
 
 def _lower_sphere(conv, norm=None, act=None):
     """Launch record of a SphereConvEquirect2d (+ optional eval BatchNorm2d / activation), cached on the module."""
-    parts = [conv.weight.data_ptr(), conv.weight._version, id(norm), id(act)]
+    parts = [conv.weight.data_ptr(), conv.weight._version, id(norm), id(act), type(act).__name__,
+             float(getattr(act, "negative_slope", 0.0))]
+    if conv.bias is not None:
+        parts += [conv.bias.data_ptr(), conv.bias._version]
     if isinstance(norm, nn.BatchNorm2d):
-        parts += [t.data_ptr() + t._version for t in (norm.weight, norm.bias, norm.running_mean, norm.running_var)
-                  if t is not None]
+        parts += [bool(norm.training), float(norm.eps)]
+        for t in (norm.weight, norm.bias, norm.running_mean, norm.running_var):
+            if t is not None:
+                parts += [t.data_ptr(), t._version]
     key = tuple(parts)
     cached = conv.__dict__.get("_mvsgi_launch")
     if cached is not None and cached[0] == key:

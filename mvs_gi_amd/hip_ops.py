@@ -15,9 +15,12 @@ import os
 
 CONV_AUTO, CONV_DIRECT, CONV_MFMA, CONV_BF16X3, CONV_BF16X3_C16, CONV_BF16X3_V32 = 0, 1, 2, 3, 4, 5
 
-# Arithmetic of the conv layers: "f32" = exact fp32 MFMA (v_mfma_f32_16x16x4_f32),
-# "bf16x3" = split-bf16 MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate; ~2^-16 per product).
-_CONV_MODE = os.environ.get("MVSGI_CONV_MODE", "f32")
+# Arithmetic of the conv layers: "bf16x3" (default) = split-bf16 MFMA (hi*hi + hi*lo + lo*hi, fp32
+# accumulate; ~2^-16 per product; inverse distance within 3e-4 of the reference on every golden case),
+# "f32" = exact fp32 MFMA (v_mfma_f32_16x16x4_f32; bit-for-bit an fp32 fmaf chain, ~3x slower).
+_CONV_MODE = os.environ.get("MVSGI_CONV_MODE", "bf16x3")
+if _CONV_MODE not in ("f32", "bf16x3"):
+    raise ValueError(f"MVSGI_CONV_MODE={_CONV_MODE!r} not in ('f32', 'bf16x3')")
 
 
 def set_conv_mode(mode: str) -> None:

@@ -30,3 +30,20 @@ def _hip_library_built():
         if g._needs_rebuild():
             g.build()
     yield
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """One line per whole-path parity case x conv mode: the measured inverse-distance errors and the
+    reference they were measured against (golden = output of the reference's own modules committed under
+    tests/golden; oracle = CPU restatement, pinned to those goldens by tests/test_oracle_golden.py)."""
+    import parity_log
+    if not parity_log.ROWS:
+        return
+    tr = terminalreporter
+    tr.write_sep("=", "inverse-distance parity (bar: max_rel <= 1e-3)")
+    tr.write_line(f"{'case':28s} {'mode':7s} {'gain':>6s} {'max_rel':>10s} {'mean_l1_rel':>12s}  ref")
+    for case, mode, gain, mx, l1, ref in parity_log.ROWS:
+        tr.write_line(f"{case:28s} {mode:7s} {gain:6.2f} {mx:10.3e} {l1:12.3e}  ref={ref}")
+    worst = max(r[3] for r in parity_log.ROWS)
+    n_or = sum(1 for r in parity_log.ROWS if r[5] != "golden")
+    tr.write_line(f"worst max_rel {worst:.3e} over {len(parity_log.ROWS)} rows; {n_or} row(s) not against reference goldens")
