@@ -75,6 +75,10 @@ def load() -> ctypes.CDLL:
         raise MvsgiLibraryMissing(
             f"{LIB_PATH} not found: build the HIP library first (__graft_entry__.build()). "
             "mvs_gi_amd has no CPU fallback.")
+    # torch first: libmvsgi_hip.so links libamdhip64 by SONAME and must bind to the HIP runtime torch has
+    # loaded (its own copy); loaded the other way round the process ends up with two runtimes and every launch of
+    # this library fails with "no ROCm-capable device is detected"
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

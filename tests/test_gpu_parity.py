@@ -114,7 +114,7 @@ def test_rig_constant_cache_follows_the_tensors():
         assert np.array_equal(cvb.sweep(f, g, gm, m2).cpu().numpy(), v_cached.cpu().numpy())
         # free-then-reallocate: a second rig's same-shaped tensors that the caching allocator may place at the
         # first rig's addresses (version 0 again) must not hit the first rig's entry
-        inp_b = synth.make_inputs(cfg, seed=6, batch=2)
+        inp_b = synth.make_inputs(cfg, seed=6, batch=2, grid_kind="random", grid_mask_dtype="bool")   # another rig
         ref_b = cvb.sweep(f, *(_g(inp_b[k]) for k in ("grids", "grid_masks", "masks"))).clone()
         cvb.cache_rig_constants = False
         ref_a = cvb.sweep(f, _g(inp["grids"]), _g(inp["grid_masks"]), _g(inp["masks"])).clone()
