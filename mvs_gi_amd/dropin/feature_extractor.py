@@ -40,6 +40,7 @@ class Conv2dLaunch:
 
 def lower_conv2d_block(blk) -> Conv2dLaunch:
     conv: nn.Conv2d = blk.conv_layer
+    norm = blk.norm_layer
     key = cm._fingerprint(blk)        # pointer and version as separate entries, bias, norm mode / eps, activation, stride
     cached = blk.__dict__.get("_mvsgi_launch")
     if cached is not None and cached.key == key:
