@@ -239,6 +239,28 @@ int mvsgi_deform_conv2d_f32(const float* x, const float* offset, int offset_per_
                             int N, int Cin, int H, int W, int Cout, int Kh, int Kw, int stride_h, int stride_w,
                             int pad_h, int pad_w, int dil_h, int dil_w, float neg_slope, mvsgi_stream_t stream);
 
+/* ---- split-padded activations and the register-stationary conv (csrc/conv3d_rs.hip) ----------------------
+ * Split-padded format of a channels-last activation tensor:  [B][D+2][H+2][W+2][C/16][4][8] bf16, where a voxel's
+ * 16-channel slice is [hi(c 0-7) | hi(c 8-15) | lo(c 0-7) | lo(c 8-15)], x = hi + lo (hi = bf16(x), lo = bf16(x - hi));
+ * the one-voxel border is zero (Conv3d's padding=1, common_modules.py:97-101) and is never written by any kernel:
+ * allocate the buffer zero-filled once.  Same 4 bytes per element as fp32.
+ *   mvsgi_act_split_bytes      size of such a buffer
+ *   mvsgi_act_f32_to_split     fp32 [B][D][H][W][C] -> interior of a split-padded buffer
+ *   mvsgi_act_split_to_f32     the inverse (hi + lo)
+ *   mvsgi_conv3d_rs_split      BaseConvBlk3d.forward (common_modules.py:107-115) for Cin = Cout = 32, stride 1, on
+ *                              split-padded x / res / y with the layer's weights resident in registers
+ *                              (w_packed from mvsgi_conv3d_rs_pack_weights); same arithmetic as MVSGI_CONV_BF16X3;
+ *                              neg_slope in [0, 1]
+ */
+size_t mvsgi_conv3d_rs_packed_weight_bytes(int Cout, int Cin);
+int mvsgi_conv3d_rs_pack_weights(const float* w_oidhw, void* w_packed, int Cout, int Cin, mvsgi_stream_t stream);
+size_t mvsgi_act_split_bytes(int B, int C, int D, int H, int W);
+int mvsgi_act_f32_to_split(const float* x, void* y_split, int B, int C, int D, int H, int W, mvsgi_stream_t stream);
+int mvsgi_act_split_to_f32(const void* x_split, float* y, int B, int C, int D, int H, int W, mvsgi_stream_t stream);
+int mvsgi_conv3d_rs_split(const void* x_split, const void* w_packed_rs, const float* scale, const float* shift,
+                          const void* res_split, void* y_split, int B, int Cin, int D, int H, int W, int Cout,
+                          float neg_slope, mvsgi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,478 @@
+// K2e: "register-stationary" split-bf16 3x3x3 convolution for the narrow layers of the regulator
+// (Cin, Cout <= 32: BaseConvBlk3d.forward, dsta_mvs/model/common/common_modules.py:107-115, as used by
+// ResConvBlk3d :231-244 at UNet level 0), and the activation format it works on.
+//
+// Why a second schedule.  conv3d_bf16x3_kernel streams the pre-split weight fragments from L2 once per
+// (brick, slice) and wave -- ~42 B/clk/CU of vector-memory traffic that shares the CU's memory queue with the
+// staging loads -- and gives half of the workgroup's waves to splitting fp32 activations into hi|lo bf16 for
+// LDS.  For the 32 -> 32 layers ALL weights are 110 KB = 432 registers x 64 lanes, which fits the register
+// files of two waves (gfx950: 512 registers per lane at one wave per SIMD).  So here
+//   * a workgroup is 4 waves, one per SIMD, each holding its half of the layer's weights in registers for the
+//     whole launch (wave (pl, s): the 16-channel slice s, both cout tiles, all 14 tap pairs = 224 registers);
+//     the main loop has no weight traffic at all;
+//   * activations live in HBM ALREADY SPLIT ("split-padded" format below): the split is done once, in the
+//     producing layer's epilogue, instead of once per staged halo voxel; staging is a pure copy and runs on the
+//     LDS-DMA path (buffer_load ... lds: no VGPR round trip, no VALU, no producer waves);
+//   * tensors carry a one-voxel zero border, so a halo brick is a fixed pattern of offsets from the brick's
+//     origin: no bounds arithmetic per staged voxel (the per-lane DMA offsets are computed once per launch);
+//   * the two slice-waves of a voxel set exchange half of their accumulators through LDS (32 KB per brick of
+//     128 voxels against 860 KB of fragment reads) and each finishes half of the tiles: scale / shift,
+//     residual, LeakyReLU, split, 16-byte stores;
+//   * one s_barrier per brick, placed between tap pairs 12 and 13: the last pair's MFMAs cover the first LDS
+//     reads of the next brick, the epilogue of brick u runs under the MFMAs of brick u + 1.
+//
+// Split-padded activation format:  [B][D+2][H+2][W+2][C/16][4][8] bf16
+//   voxel record = C/16 slices x 64 B, slice = [hi(c 0-7) | hi(c 8-15) | lo(c 0-7) | lo(c 8-15)],
+//   x = hi + lo, hi = bf16(x) (RNE), lo = bf16(x - hi): 16-17 significant bits, the same 4 B per element as fp32;
+//   the border voxels are zero and never written (the convolution's padding).
+#include "common.hpp"
+#ifdef MVSGI_RS_STAMPS
+#include <cstdio>
+#include <cstdlib>
+#endif
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// x = hi + lo for four fp32 values, packed two bf16 per dword (same arithmetic as conv3d_bf16x3.hpp)
+__device__ __forceinline__ void split4(const f32x4 x, u32x2& hi, u32x2& lo) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const f32x2v v = {x[2 * p], x[2 * p + 1]};
+        const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+        const f32x2v hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        hi[p] = hb;
+        lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, bf16x2));
+    }
+}
+__device__ __forceinline__ f32x4 join4(const u32x2 hi, const u32x2 lo) {
+    f32x4 r;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        r[2 * p] = __builtin_bit_cast(float, hi[p] << 16) + __builtin_bit_cast(float, lo[p] << 16);
+        r[2 * p + 1] = __builtin_bit_cast(float, hi[p] & 0xffff0000u) + __builtin_bit_cast(float, lo[p] & 0xffff0000u);
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// format conversion (module boundaries, tests): fp32 NDHWC <-> split-padded.  One thread per (voxel, 8 channels).
+// ---------------------------------------------------------------------------------------------
+__global__ void f32_to_split_kernel(const float* __restrict__ x, unsigned char* __restrict__ y, int B, int C, int D, int H,
+                                    int W) {
+    const long long n = (long long)B * D * H * W * (C / 8);
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int g = (int)(idx % (C / 8));          // 8-channel group
+    long long v = idx / (C / 8);
+    const int w = (int)(v % W);
+    v /= W;
+    const int h = (int)(v % H);
+    v /= H;
+    const int d = (int)(v % D);
+    const int b = (int)(v / D);
+    const float* src = x + ((((long long)b * D + d) * H + h) * W + w) * C + g * 8;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+    u32x2 h0, l0, h1, l1;
+    split4(a0, h0, l0);
+    split4(a1, h1, l1);
+    unsigned char* dst = y + ((((long long)b * (D + 2) + d + 1) * (H + 2) + h + 1) * (W + 2) + w + 1) * (C * 4) +
+                         (g >> 1) * 64 + (g & 1) * 16;
+    *reinterpret_cast<u32x4*>(dst) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+    *reinterpret_cast<u32x4*>(dst + 32) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+}
+
+__global__ void split_to_f32_kernel(const unsigned char* __restrict__ x, float* __restrict__ y, int B, int C, int D, int H,
+                                    int W) {
+    const long long n = (long long)B * D * H * W * (C / 8);
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int g = (int)(idx % (C / 8));
+    long long v = idx / (C / 8);
+    const int w = (int)(v % W);
+    v /= W;
+    const int h = (int)(v % H);
+    v /= H;
+    const int d = (int)(v % D);
+    const int b = (int)(v / D);
+    const unsigned char* src = x + ((((long long)b * (D + 2) + d + 1) * (H + 2) + h + 1) * (W + 2) + w + 1) * (C * 4) +
+                               (g >> 1) * 64 + (g & 1) * 16;
+    const u32x4 hi = *reinterpret_cast<const u32x4*>(src), lo = *reinterpret_cast<const u32x4*>(src + 32);
+    float* dst = y + ((((long long)b * D + d) * H + h) * W + w) * C + g * 8;
+    *reinterpret_cast<f32x4*>(dst) = join4(u32x2{hi[0], hi[1]}, u32x2{lo[0], lo[1]});
+    *reinterpret_cast<f32x4*>(dst + 4) = join4(u32x2{hi[2], hi[3]}, u32x2{lo[2], lo[3]});
+}
+
+// ---------------------------------------------------------------------------------------------
+// the 32 -> 32 kernel
+// ---------------------------------------------------------------------------------------------
+struct RsArgs {
+    const unsigned char* x;    // split-padded [B][D+2][H+2][W+2][32]
+    unsigned char* y;          // split-padded, same geometry (stride 1)
+    const unsigned char* res;  // split-padded residual or nullptr
+    const bf16x8* wp;          // mvsgi_conv3d_rs_pack_weights layout: [slice][cout tile][14 pairs][hi|lo][64 lanes]
+    const float* scale;
+    const float* shift;
+    int B, D, H, W;
+    float neg_slope;           // in [0, 1]: act(v) = max(v, v * neg_slope)
+    int tiles_d, tiles_h, tiles_w, total_units;
+    unsigned long long* dbg;   // MVSGI_RS_STAMPS diagnostic build only
+};
+
+__device__ __forceinline__ int rs_xcd_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+namespace rs {
+constexpr int TD = 2, TH = 4, TW = 16;        // brick: 128 output voxels = 2 planes x 4 rows x 16
+constexpr int ITH = TH + 2, ITW = TW + 2;     // halo: 4 planes x 6 rows x 18
+// LDS image of a halo brick: voxel v = d * PL + h * ROW + w in a HI region (64 B per voxel: the hi halves of the two
+// 16-channel slices, 4 chunks of 16 B) followed by a LO region.  Chunk c of voxel (d, h, w) sits in slot c ^ ((w >> 2) & 3):
+// the 16 voxels a ds_read_b128 lane group touches -- 8 lanes on one tap, 8 on its pair partner -- then cover the 16
+// 16-byte units of a 256-B bank row exactly once when (a) both taps are in one row and differ by one voxel (in-row pairs
+// kw = 0 | 1) or (b) both have kw = 2 and their rows start at the same voxel index mod 4 (ROW, PL multiples of 4).
+// Because the slot depends on w only, a tap's row / plane offset and a tile's row are plain immediates of the read.
+constexpr int ROW = 20, PL = ITH * ROW;       // 2 padding voxels per row
+constexpr int NV = 4 * PL;                    // 480 voxels = 30 DMA pieces per region
+constexpr int REGION = NV * 64;               // 30,720
+constexpr int IMG = 2 * REGION;               // 61,440
+constexpr int BUF1 = 65536;                   // the second image sits one address bit away
+constexpr int SCR = 2 * BUF1;                 // exchange scratch: 2 x (4 waves x 4 KB), the two halves one address bit (16384) apart
+constexpr int LDS_BYTES = SCR + 2 * 16384;    // 163,840 = all of the CU's LDS
+static_assert((SCR & 16384) == 0 && BUF1 + IMG <= SCR, "scratch halves toggle by XOR 16384");
+constexpr int NDMA = IMG / 1024;              // 60 pieces per image
+constexpr int DPW = NDMA / 4;                 // 15 per wave
+constexpr int kPairs = 14;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(ROW % 4 == 0 && PL % 4 == 0 && NV % 16 == 0, "image geometry");
+// pair p -> its two taps as (k = kd * 3 + kh, kw); second tap of pair 13: none (-1)
+__host__ __device__ constexpr int pair_k(int p, int which) { return p < 9 ? p : (2 * (p - 9) + which < 9 ? 2 * (p - 9) + which : -1); }
+__host__ __device__ constexpr int pair_kw(int p, int which) { return p < 9 ? which : 2; }
+}  // namespace rs
+
+// [Cout 32][Cin 32][27] -> [slice 2][cout tile 2][14 pairs][hi|lo][64 lanes][8 bf16]
+//   lane = (kg << 4) | i holds W[cout = ct*16 + i][cin = slice*16 + (kg>>1)*8 + j][tap of pair p selected by kg & 1]
+__global__ void rs_pack_weights_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 2 * 2 * rs::kPairs * 64) return;
+    const int lane = idx & 63;
+    int r = idx >> 6;
+    const int p = r % rs::kPairs;
+    r /= rs::kPairs;
+    const int ct = r & 1, sl = r >> 1;
+    const int kg = lane >> 4, co = ct * 16 + (lane & 15), ci = sl * 16 + (kg >> 1) * 8;
+    const int k = rs::pair_k(p, kg & 1), kw = rs::pair_kw(p, kg & 1);
+    bf16x8 hi, lo;
+    for (int j = 0; j < 8; ++j) {
+        const float v = k >= 0 ? w[((long long)co * 32 + ci + j) * 27 + k * 3 + kw] : 0.f;
+        const __bf16 h = (__bf16)v;
+        hi[j] = h;
+        lo[j] = (__bf16)(v - (float)h);
+    }
+    const int o = (((sl * 2 + ct) * rs::kPairs + p) * 2) * 64 + lane;
+    wp[o] = hi;
+    wp[o + 64] = lo;
+}
+
+struct RsUnit {      // coordinates of a brick (wave-uniform)
+    int b, od, oh, ow;
+};
+
+__global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
+    using namespace rs;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = wave & 1, s = wave >> 1;            // plane of the brick, channel slice
+    const int col = lane & 15, kg = lane >> 4;
+    const bool second = kg & 1;
+    const int half = kg >> 1;
+    const int Hp = a.H + 2, Wp = a.W + 2;
+    const long long frame_bytes = (long long)(a.D + 2) * Hp * Wp * 128;
+
+    // ---- weights: resident in the accumulator half of the register file for the whole launch ----
+    bf16x8 wh[kPairs][2], wl[kPairs][2];
+#pragma unroll
+    for (int p = 0; p < kPairs; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bf16x8* q = a.wp + ((long long)((s * 2 + j) * kPairs + p) * 2) * 64 + lane;
+            wh[p][j] = q[0];
+            wl[p][j] = q[64];
+        }
+#pragma unroll
+    for (int p = 0; p < kPairs; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : "+a"(wh[p][j]), "+a"(wl[p][j]));
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- fragment read bases (image 0, HI region); group 0 = own tiles (rows 2s, 2s+1), group 1 = the partner's ----
+    const int chunk = 2 * s + half;
+    int rbin[2], rb2[2][5];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int row0 = g == 0 ? 2 * s : 2 - 2 * s;
+        const int w_in = col + (second ? 1 : 0), w_2 = col + 2;
+        rbin[g] = (pl * PL + row0 * ROW + w_in) * 64 + ((chunk ^ ((w_in >> 2) & 3)) << 4);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int kA = 2 * q, kB = 2 * q + 1 < 9 ? 2 * q + 1 : 2 * q;
+            const int k = second ? kB : kA;
+            rb2[g][q] = (pl * PL + row0 * ROW + w_2 + (k / 3) * PL + (k % 3) * ROW) * 64 + ((chunk ^ ((w_2 >> 2) & 3)) << 4);
+        }
+    }
+    // ---- DMA plan: piece i = wave + 4 m fills LDS bytes [i * 1024, +1024) of an image: 16 voxels x 4 chunks ----
+    unsigned voff[DPW];
+#pragma unroll
+    for (int m = 0; m < DPW; ++m) {
+        const int i = wave + 4 * m;
+        const int region = i >= NDMA / 2 ? 1 : 0, jj = i - region * (NDMA / 2);
+        const int v = 16 * jj + (lane >> 2), slot = lane & 3;
+        const int d = v / PL, r = v - d * PL;
+        const int h = r / ROW, w = r - h * ROW;
+        const int c = slot ^ ((w >> 2) & 3);
+        voff[m] = w < ITW ? (unsigned)(((d * Hp + h) * Wp + w) * 128 + (c >> 1) * 64 + region * 32 + (c & 1) * 16)
+                          : 0xffffff00u;     // row padding: beyond num_records, zero-filled
+    }
+    // ---- output side: this lane's 16-byte piece of the own tiles' voxel records ----
+    const f32x4 esc[2] = {*reinterpret_cast<const f32x4*>(a.scale + kg * 4), *reinterpret_cast<const f32x4*>(a.scale + 16 + kg * 4)};
+    const f32x4 esh[2] = {*reinterpret_cast<const f32x4*>(a.shift + kg * 4), *reinterpret_cast<const f32x4*>(a.shift + 16 + kg * 4)};
+    unsigned voy0[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        voy0[i] = (unsigned)((((pl + 1) * Hp + 2 * s + i + 1) * Wp + col + 1) * 128 + (kg & 1) * 32 + (kg >> 1) * 16);
+    int sp_rd = SCR + (wave ^ 2) * 4096 + lane * 16, sp_wr = SCR + 16384 + wave * 4096 + lane * 16;
+
+    const int total = a.total_units, G = gridDim.x;
+    const int n = (total - (int)blockIdx.x + G - 1) / G;       // bricks of this workgroup (the same for its 4 waves)
+    // The walk: logical ids id0 + k * step (XCD-contiguous remap, cdna_hip_programming.md T1; G % 8 == 0 or G == total)
+    const int id0 = rs_xcd_remap((int)blockIdx.x, total);
+    const int step = G == total ? 0 : G >> 3;
+    const int sw = step % a.tiles_w;
+    int tq = step / a.tiles_w;
+    const int sh_ = tq % a.tiles_h;
+    tq /= a.tiles_h;
+    const int sd = tq % a.tiles_d, sb = tq / a.tiles_d;
+    RsUnit c2{0, 0, 0, 0}, c1{0, 0, 0, 0}, c0, nx;
+    {
+        int t_ = id0;
+        c0.ow = t_ % a.tiles_w;
+        t_ /= a.tiles_w;
+        c0.oh = t_ % a.tiles_h;
+        t_ /= a.tiles_h;
+        c0.od = t_ % a.tiles_d;
+        c0.b = t_ / a.tiles_d;
+    }
+// tile coordinates of the next brick of the walk: mixed-radix add, no division
+#define RS_STEP(DST, SRC)                                                      \
+    {                                                                          \
+        int w_ = SRC.ow + sw, c_ = w_ >= a.tiles_w;                            \
+        DST.ow = w_ - (c_ ? a.tiles_w : 0);                                    \
+        int h_ = SRC.oh + sh_ + c_;                                            \
+        c_ = h_ >= a.tiles_h;                                                  \
+        DST.oh = h_ - (c_ ? a.tiles_h : 0);                                    \
+        int d_ = SRC.od + sd + c_;                                             \
+        c_ = d_ >= a.tiles_d;                                                  \
+        DST.od = d_ - (c_ ? a.tiles_d : 0);                                    \
+        DST.b = SRC.b + sb + c_;                                               \
+    }
+    RS_STEP(nx, c0)
+// buffer descriptor whose base is the brick's origin inside PTR (a split-padded tensor of this geometry); VALID = false
+// gives zero records: every access through it is dropped (loads return 0)
+#define RS_DESC(PTR, U, VALID)                                                                                   \
+    ({                                                                                                           \
+        const long long in_frame_ = ((long long)((U).od * TD * Hp + (U).oh * TH) * Wp + (U).ow * TW) * 128;      \
+        long long left_ = frame_bytes * (a.B - (U).b) - in_frame_;                                               \
+        if (left_ > 0x7fffff00ll) left_ = 0x7fffff00ll;                                                          \
+        if (!(VALID) || left_ < 0) left_ = 0;                                                                    \
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(PTR) + ((VALID) ? (long long)(U).b * frame_bytes + in_frame_ : 0), \
+                                          0, (int)left_, 0x00020000);                                            \
+    })
+#define RS_DMA(M)                                                                                                \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(dsc_x, (__attribute__((address_space(3))) void*)(lds + nxt_img + (wave + 4 * (M)) * 1024), \
+                                             16, voff[M], 0, 0, 0);
+// The MFMAs are inline asm so that the weight operands can be pinned to the accumulator half of the register file
+// ("a"): hipcc keeps A/B operands of the builtin form in VGPRs and would shuttle the 224 weight registers through
+// v_accvgpr_read every brick.  hipcc pads no hazards around asm: the schedule keeps >= 3 MFMAs between an accumulator's
+// last MFMA and its first read, and nothing else reads or writes MFMA operands.
+#define RS_MF(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "a"(WREG), "v"(XREG));
+#define RS_MF0(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(ACC) : "a"(WREG), "v"(XREG));
+
+#ifdef MVSGI_RS_STAMPS   // diagnostic build (tools/rs_stamps.py): s_memtime stamps of workgroup 8, every wave
+    int nst = 0;
+#define STAMP()                                                                                     \
+    if (a.dbg && blockIdx.x == 8 && nst < 250) {                                                    \
+        unsigned long long t_;                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        if (lane == 0) a.dbg[wave * 256 + nst] = t_;                                                \
+        nst++;                                                                                      \
+    }
+#else
+#define STAMP()
+#endif
+
+    // prologue: image 0 <- brick 0
+    {
+        const auto dsc_x = RS_DESC(a.x, c0, true);
+        const int nxt_img = 0;
+#pragma unroll
+        for (int m = 0; m < DPW; ++m) RS_DMA(m)
+    }
+    f32x4 acc[8], keepA[4], keepB[4], snd[4];
+    bf16x8 xh[2][4], xl[2][4];
+    u32x4 rres[4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        keepA[k] = keepB[k] = snd[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rres[k] = u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xh[1][i] = xl[1][i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 pt0, pt1, pt2, pt3, t0, t1_, t2, t3;
+    u32x2 sa0, sb0, sa1, sb1, sa2, sb2, sa3, sb3, hb0, hb1, hb2, hb3, lb0, lb1, lb2, lb3;
+    f32x2v hf0, hf1, hf2, hf3;
+    float rh0, rl0, u0, rh1, rl1, u1, rh2, rl2, u2, rh3, rl3, u3;
+#define t1 t1_
+    // phases: ph = 0 .. n + 1.  Phase ph = [pair 13 of brick ph - 1, accumulators handed over] [pairs 0 .. 12 of brick ph]
+    // with, between the MFMAs: the staging of brick ph + 1, the epilogue of brick ph - 2, the residual request of brick
+    // ph - 1.  The last two phases (no brick left to multiply) run the same stream without the pairs.
+    for (int ph = 0; ph < n + 2; ++ph) {
+        const int nxt_img = (ph & 1) ? 0 : BUF1;
+        const auto dsc_x = RS_DESC(a.x, nx, ph + 1 < n);
+        const auto dsc_r = RS_DESC(a.res, c1, a.res != nullptr && ph >= 1 && ph - 1 < n);
+        const auto dsc_y = RS_DESC(a.y, c2, ph >= 2);
+        unsigned voy[2];
+        {
+            // the brick two phases back: stores of voxels outside the volume (ragged sizes) are sent out of range
+            const bool dok = c2.od * TD + pl < a.D;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                voy[i] = (dok && c2.oh * TH + 2 * s + i < a.H && c2.ow * TW + col < a.W) ? voy0[i] : 0xffffff00u;
+        }
+        STAMP()
+        if (ph < n) {
+#include "conv3d_rs_phase_main.inc"
+        } else {
+#include "conv3d_rs_phase_drain.inc"
+        }
+        STAMP()
+        c2 = c1;
+        c1 = c0;
+        c0 = nx;
+        RS_STEP(nx, c0)
+        // all but the 4 youngest vector-memory operations (the residual requests): the next image has landed
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        STAMP()
+        __builtin_amdgcn_s_barrier();
+    }
+#undef t1
+#undef STAMP
+#undef RS_MF
+#undef RS_MF0
+#undef RS_DMA
+#undef RS_DESC
+#undef RS_STEP
+}
+
+}  // namespace
+
+extern "C" size_t mvsgi_act_split_bytes(int B, int C, int D, int H, int W) {
+    return (size_t)B * (D + 2) * (H + 2) * (W + 2) * (size_t)C * 4;
+}
+
+extern "C" int mvsgi_act_f32_to_split(const float* x, void* y, int B, int C, int D, int H, int W, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(x && y, "mvsgi_act_f32_to_split: null pointer");
+    MVSGI_REQUIRE(B > 0 && C > 0 && C % 16 == 0 && D > 0 && H > 0 && W > 0, "mvsgi_act_f32_to_split: bad dims (C %% 16 == 0)");
+    const long long n = (long long)B * D * H * W * (C / 8);
+    MVSGI_REQUIRE(mvsgi::cdiv(n, 256) < (1ll << 31), "mvsgi_act_f32_to_split: tensor too large");
+    hipLaunchKernelGGL(f32_to_split_kernel, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, mvsgi::as_stream(stream), x,
+                       static_cast<unsigned char*>(y), B, C, D, H, W);
+    return mvsgi::check_launch("mvsgi_act_f32_to_split");
+}
+
+extern "C" int mvsgi_act_split_to_f32(const void* x, float* y, int B, int C, int D, int H, int W, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(x && y, "mvsgi_act_split_to_f32: null pointer");
+    MVSGI_REQUIRE(B > 0 && C > 0 && C % 16 == 0 && D > 0 && H > 0 && W > 0, "mvsgi_act_split_to_f32: bad dims (C %% 16 == 0)");
+    const long long n = (long long)B * D * H * W * (C / 8);
+    MVSGI_REQUIRE(mvsgi::cdiv(n, 256) < (1ll << 31), "mvsgi_act_split_to_f32: tensor too large");
+    hipLaunchKernelGGL(split_to_f32_kernel, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, mvsgi::as_stream(stream),
+                       static_cast<const unsigned char*>(x), y, B, C, D, H, W);
+    return mvsgi::check_launch("mvsgi_act_split_to_f32");
+}
+
+extern "C" size_t mvsgi_conv3d_rs_packed_weight_bytes(int Cout, int Cin) {
+    return Cout == 32 && Cin == 32 ? (size_t)2 * 2 * rs::kPairs * 2 * 64 * 16 : 0;
+}
+
+extern "C" int mvsgi_conv3d_rs_pack_weights(const float* w_oidhw, void* w_packed, int Cout, int Cin, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(w_oidhw && w_packed, "mvsgi_conv3d_rs_pack_weights: null pointer");
+    MVSGI_REQUIRE(Cout == 32 && Cin == 32, "mvsgi_conv3d_rs_pack_weights: only 32 -> 32 channels (got %d -> %d)", Cin, Cout);
+    hipLaunchKernelGGL(rs_pack_weights_kernel, dim3((2 * 2 * rs::kPairs * 64 + 255) / 256), dim3(256), 0, mvsgi::as_stream(stream),
+                       w_oidhw, static_cast<bf16x8*>(w_packed));
+    return mvsgi::check_launch("mvsgi_conv3d_rs_pack_weights");
+}
+
+extern "C" int mvsgi_conv3d_rs_split(const void* x, const void* w_packed_rs, const float* scale, const float* shift,
+                                     const void* res, void* y, int B, int Cin, int D, int H, int W, int Cout,
+                                     float neg_slope, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(x && y && w_packed_rs && scale && shift, "mvsgi_conv3d_rs_split: null pointer");
+    MVSGI_REQUIRE(Cin == 32 && Cout == 32, "mvsgi_conv3d_rs_split: only 32 -> 32 channels (got %d -> %d)", Cin, Cout);
+    MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_conv3d_rs_split: bad dims");
+    MVSGI_REQUIRE(x != y, "mvsgi_conv3d_rs_split: in-place operation is not supported");
+    MVSGI_REQUIRE(neg_slope >= 0.f && neg_slope <= 1.f, "mvsgi_conv3d_rs_split: neg_slope %g not in [0, 1]", (double)neg_slope);
+    MVSGI_REQUIRE((long long)(D + 2) * (H + 2) * (W + 2) * 128 < (1ll << 31), "mvsgi_conv3d_rs_split: frame too large for 32-bit offsets");
+    RsArgs a{};
+    a.x = static_cast<const unsigned char*>(x);
+    a.y = static_cast<unsigned char*>(y);
+    a.res = static_cast<const unsigned char*>(res);
+    a.wp = static_cast<const bf16x8*>(w_packed_rs);
+    a.scale = scale;
+    a.shift = shift;
+    a.B = B; a.D = D; a.H = H; a.W = W;
+    a.neg_slope = neg_slope;
+    a.tiles_d = (int)mvsgi::cdiv(D, rs::TD);
+    a.tiles_h = (int)mvsgi::cdiv(H, rs::TH);
+    a.tiles_w = (int)mvsgi::cdiv(W, rs::TW);
+    const long long nb = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
+    MVSGI_REQUIRE(nb < (1ll << 31), "mvsgi_conv3d_rs_split: too many units");
+    a.total_units = (int)nb;
+#ifdef MVSGI_RS_STAMPS
+    {   // MVSGI_STAMP=1: record; =2: print the stamps of the previous launch
+        static unsigned long long* dbgbuf = nullptr;
+        const char* e_ = getenv("MVSGI_STAMP");
+        if (e_ && !dbgbuf) { (void)hipMalloc(&dbgbuf, 4 * 256 * 8); (void)hipMemset(dbgbuf, 0, 4 * 256 * 8); }
+        a.dbg = e_ ? dbgbuf : nullptr;
+        if (e_ && atoi(e_) == 2 && dbgbuf) {
+            static unsigned long long h[4 * 256];
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(h, dbgbuf, sizeof(h), hipMemcpyDeviceToHost);
+            for (int w = 0; w < 4; ++w) {
+                fprintf(stderr, "wave %d:", w);
+                for (int i = 0; i < 250; ++i) fprintf(stderr, " %lld", (long long)(h[w * 256 + i] - h[0]));
+                fprintf(stderr, "\n");
+            }
+        }
+    }
+#endif
+    static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
+    mvsgi::PersistentGeom geo;
+    if (mvsgi::persistent_geometry(conv3d_rs32_kernel, 256, rs::LDS_BYTES, 1, geo_cache, "mvsgi_conv3d_rs_split", geo)) return 1;
+    const long long resident = (long long)geo.cus / 8 * 8 > 0 ? (long long)geo.cus / 8 * 8 : 8;
+    hipLaunchKernelGGL(conv3d_rs32_kernel, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), rs::LDS_BYTES,
+                       mvsgi::as_stream(stream), a);
+    return mvsgi::check_launch("mvsgi_conv3d_rs_split");
+}

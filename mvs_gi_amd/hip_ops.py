@@ -327,6 +327,72 @@ def conv3d_variant(B, Cin, Din, Hin, Win, Cout, stride=1, impl=CONV_AUTO) -> str
     return name.decode()
 
 
+# --------------------------------------------------------------------------------------
+# split-padded activations (csrc/conv3d_rs.hip): [B, D+2, H+2, W+2, C] int32 words, each word = (hi | lo) bf16 pieces laid
+# out per 16-channel slice as [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15]; zero border
+# --------------------------------------------------------------------------------------
+class SplitAct:
+    """A split-padded activation buffer plus its logical geometry (B, D, H, W, C)."""
+    __slots__ = ("buf", "B", "D", "H", "W", "C")
+
+    def __init__(self, B, D, H, W, C, device, buf=None):
+        self.B, self.D, self.H, self.W, self.C = int(B), int(D), int(H), int(W), int(C)
+        if buf is None:
+            buf = torch.zeros((self.B, self.D + 2, self.H + 2, self.W + 2, self.C), device=device, dtype=torch.int32)
+        self.buf = buf
+
+    @property
+    def shape(self):
+        return (self.B, self.D, self.H, self.W, self.C)
+
+
+def act_to_split(x_ndhwc: torch.Tensor, out: Optional[SplitAct] = None) -> SplitAct:
+    lib = _lib.load()
+    x = _dev(x_ndhwc, "x")
+    B, D, Hh, W, C = x.shape
+    y = out if out is not None else SplitAct(B, D, Hh, W, C, x.device)
+    if y.shape != (B, D, Hh, W, C):
+        raise AssertionError(f"split buffer {y.shape} does not match {tuple(x.shape)}")
+    _lib.check(lib.mvsgi_act_f32_to_split(x.data_ptr(), y.buf.data_ptr(), B, C, D, Hh, W, _stream_ptr(x)), "mvsgi_act_f32_to_split")
+    return y
+
+
+def act_from_split(x: SplitAct, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    y = out if out is not None else torch.empty(x.shape, device=x.buf.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_act_split_to_f32(x.buf.data_ptr(), y.data_ptr(), x.B, x.C, x.D, x.H, x.W, _stream_ptr(x.buf)),
+               "mvsgi_act_split_to_f32")
+    return y
+
+
+def pack_conv_weights_rs(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
+    """[32, 32, 3, 3, 3] -> register-stationary layout (tap pairs in the kernel's own order), or None when unsupported."""
+    lib = _lib.load()
+    w = _dev(w_oidhw, "conv weight")
+    Cout, Cin = w.shape[:2]
+    nbytes = lib.mvsgi_conv3d_rs_packed_weight_bytes(Cout, Cin) if tuple(w.shape[2:]) == (3, 3, 3) else 0
+    if not nbytes:
+        return None
+    wp = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+    _lib.check(lib.mvsgi_conv3d_rs_pack_weights(w.data_ptr(), wp.data_ptr(), Cout, Cin, _stream_ptr(w)),
+               "mvsgi_conv3d_rs_pack_weights")
+    return wp
+
+
+def conv3d_rs(x: SplitAct, w_packed_b3, scale, shift, res: Optional[SplitAct] = None, neg_slope=0.01,
+              out: Optional[SplitAct] = None) -> SplitAct:
+    """Register-stationary split-bf16 conv (Cin = Cout = 32, stride 1) on split-padded activations."""
+    lib = _lib.load()
+    Cout = scale.numel()
+    y = out if out is not None else SplitAct(x.B, x.D, x.H, x.W, Cout, x.buf.device)
+    if res is not None and res.shape != y.shape:
+        raise AssertionError(f"residual {res.shape} does not match output {y.shape}")
+    _lib.check(lib.mvsgi_conv3d_rs_split(x.buf.data_ptr(), w_packed_b3.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                         None if res is None else res.buf.data_ptr(), y.buf.data_ptr(), x.B, x.C, x.D, x.H,
+                                         x.W, Cout, float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_rs_split")
+    return y
+
+
 def pack_conv2d_weights_bf16x3(w_oihw: torch.Tensor) -> Optional[torch.Tensor]:
     """[Cout, Cin, 3, 3] -> split-bf16 MFMA layout, or None when unsupported."""
     lib = _lib.load()
