@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     const int half = kg >> 1;
     const int Hp = a.H + 2, Wp = a.W + 2;
     const long long frame_bytes = (long long)(a.D + 2) * Hp * Wp * 128;
+    const long long total_bytes = frame_bytes * a.B;
 
     // ---- weights: resident in the accumulator half of the register file for the whole launch ----
     bf16x8 wh[kPairs][2], wl[kPairs][2];
@@ -285,15 +286,17 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     }
     RS_STEP(nx, c0)
 // buffer descriptor whose base is the brick's origin inside PTR (a split-padded tensor of this geometry); VALID = false
-// gives zero records: every access through it is dropped (loads return 0)
+// gives zero records: every access through it is dropped (loads return 0).  Straight-line scalar code on purpose: a
+// branch inside the phase body splits it into basic blocks, and hipcc then permutes the accumulators between registers at
+// the block boundaries (v_accvgpr_mov right in front of an asm MFMA it cannot see: an unpadded hazard, wrong sums).
 #define RS_DESC(PTR, U, VALID)                                                                                   \
     ({                                                                                                           \
-        const long long in_frame_ = ((long long)((U).od * TD * Hp + (U).oh * TH) * Wp + (U).ow * TW) * 128;      \
-        long long left_ = frame_bytes * (a.B - (U).b) - in_frame_;                                               \
-        if (left_ > 0x7fffff00ll) left_ = 0x7fffff00ll;                                                          \
-        if (!(VALID) || left_ < 0) left_ = 0;                                                                    \
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(PTR) + ((VALID) ? (long long)(U).b * frame_bytes + in_frame_ : 0), \
-                                          0, (int)left_, 0x00020000);                                            \
+        const long long off_ = (long long)(U).b * frame_bytes +                                                  \
+                               ((long long)((U).od * TD * Hp + (U).oh * TH) * Wp + (U).ow * TW) * 128;           \
+        const long long left_ = total_bytes - off_;                                                              \
+        const int rec_ = left_ > 0x7fffff00ll ? 0x7fffff00 : (int)left_;                                         \
+        const int ok_ = (int)(VALID) & (int)(left_ > 0);                                                         \
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(PTR) + off_, 0, ok_ ? rec_ : 0, 0x00020000); \
     })
 #define RS_DMA(M)                                                                                                \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(dsc_x, (__attribute__((address_space(3))) void*)(lds + nxt_img + (wave + 4 * (M)) * 1024), \
@@ -305,6 +308,25 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 #define RS_MF(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "a"(WREG), "v"(XREG));
 #define RS_MF0(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(ACC) : "a"(WREG), "v"(XREG));
 
+// diagnostic builds only: MVSGI_RS_ABL bit 1 drops the fragment reads, 2 the epilogue, 4 the LDS-DMA (results are wrong)
+#ifndef MVSGI_RS_ABL
+#define MVSGI_RS_ABL 0
+#endif
+#if MVSGI_RS_ABL & 1
+#define RS_F_READ(...)
+#else
+#define RS_F_READ(...) __VA_ARGS__
+#endif
+#if MVSGI_RS_ABL & 2
+#define RS_F_EPI(...)
+#else
+#define RS_F_EPI(...) __VA_ARGS__
+#endif
+#if MVSGI_RS_ABL & 4
+#define RS_F_DMA(...)
+#else
+#define RS_F_DMA(...) __VA_ARGS__
+#endif
 #ifdef MVSGI_RS_STAMPS   // diagnostic build (tools/rs_stamps.py): s_memtime stamps of workgroup 8, every wave
     int nst = 0;
 #define STAMP()                                                                                     \
@@ -350,35 +372,38 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     // phases: ph = 0 .. n + 1.  Phase ph = [pair 13 of brick ph - 1, accumulators handed over] [pairs 0 .. 12 of brick ph]
     // with, between the MFMAs: the staging of brick ph + 1, the epilogue of brick ph - 2, the residual request of brick
     // ph - 1.  The last two phases (no brick left to multiply) run the same stream without the pairs.
-    for (int ph = 0; ph < n + 2; ++ph) {
+    __amdgpu_buffer_rsrc_t dsc_x, dsc_r, dsc_y;
+    unsigned voy[2] = {0xffffff00u, 0xffffff00u};
+    dsc_x = dsc_r = dsc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.x), 0, 0, 0x00020000);
+// stores of the brick two phases back: voxels outside the volume (ragged sizes) are sent out of range
+#define RS_VOY()                                                                                     \
+    {                                                                                                \
+        const int dok_ = c2.od * TD + pl < a.D;                                                      \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                \
+            voy[i] = (dok_ & (int)(c2.oh * TH + 2 * s + i < a.H) & (int)(c2.ow * TW + col < a.W)) ? voy0[i] : 0xffffff00u; \
+    }
+    // One code path per loop (a main / drain diamond inside one loop made hipcc park the accumulators in VGPRs at the
+    // loop header: 64 v_accvgpr moves per phase).
+    int ph = 0;
+    for (; ph < n; ++ph) {
         const int nxt_img = (ph & 1) ? 0 : BUF1;
-        const auto dsc_x = RS_DESC(a.x, nx, ph + 1 < n);
-        const auto dsc_r = RS_DESC(a.res, c1, a.res != nullptr && ph >= 1 && ph - 1 < n);
-        const auto dsc_y = RS_DESC(a.y, c2, ph >= 2);
-        unsigned voy[2];
-        {
-            // the brick two phases back: stores of voxels outside the volume (ragged sizes) are sent out of range
-            const bool dok = c2.od * TD + pl < a.D;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                voy[i] = (dok && c2.oh * TH + 2 * s + i < a.H && c2.ow * TW + col < a.W) ? voy0[i] : 0xffffff00u;
-        }
         STAMP()
-        if (ph < n) {
 #include "conv3d_rs_phase_main.inc"
-        } else {
-#include "conv3d_rs_phase_drain.inc"
-        }
         STAMP()
-        c2 = c1;
-        c1 = c0;
-        c0 = nx;
-        RS_STEP(nx, c0)
         // all but the 4 youngest vector-memory operations (the residual requests): the next image has landed
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         STAMP()
         __builtin_amdgcn_s_barrier();
     }
+    for (; ph < n + 2; ++ph) {
+        STAMP()
+#include "conv3d_rs_phase_drain.inc"
+        STAMP()
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        STAMP()
+        __builtin_amdgcn_s_barrier();
+    }
+#undef RS_VOY
 #undef t1
 #undef STAMP
 #undef RS_MF

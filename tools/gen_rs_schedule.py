@@ -2,13 +2,16 @@
 """Generates the instruction schedule of one phase of the register-stationary conv kernel
 (mvs_gi_amd/csrc/conv3d_rs.hip): a stream of 336 MFMAs (pair 13 of the previous brick, then pairs 0..12 of the
 current one) with every other instruction of the phase -- LDS fragment reads, LDS-DMA staging of the next brick,
-accumulator hand-over, the epilogue of the brick two phases back, residual requests, address toggles -- placed BY
-HAND between individual MFMAs and pinned there with sched_barrier(0).
+accumulator hand-over, the epilogue of the brick two phases back, residual requests, descriptor / address upkeep --
+placed BY HAND between individual MFMAs and pinned there with sched_barrier(0).
 
 Why a generator: the MFMAs are inline asm (weights pinned to the accumulator register file), which the compiler's
-scheduler treats as opaque; and an in-order wave only hides a VALU / LDS / VMEM instruction behind an MFMA when it sits
-directly behind it in program order (an MFMA holds the issue port for 8 of its 16 cycles: two single-issue
-instructions fit per MFMA).  Output: csrc/conv3d_rs_phase_main.inc and csrc/conv3d_rs_phase_drain.inc (committed).
+scheduler treats as opaque; and an in-order wave only hides an instruction behind an MFMA when it sits directly behind
+it in program order.  Measured on MI355X (tools/ubench/mfma_filler.hip, one wave per SIMD, cycles per
+v_mfma_f32_16x16x32_bf16): bare 16.4; + 1 VALU 16.6; + 2 VALU 17.0; + 3 VALU 21.0; + a ds_read_b128 every third MFMA
+16.4, with 1 VALU 16.7, with 2 VALU 20.9; + a permlane16_swap 28.9.  So a slot carries two single-issue
+instructions (a ds_read_b128 counts as one), and a result is never consumed in the slot after its LDS request.
+Output: csrc/conv3d_rs_phase_main.inc and csrc/conv3d_rs_phase_drain.inc (committed).
 """
 import os
 
@@ -16,14 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "mvs_gi_amd", "csrc")
 PL, ROW = 120, 20
 NSLOT = 14 * 24
-
-
-def pair_taps(p):
-    """pair p -> (k0, kw0), (k1, kw1) with k = kd*3+kh; in-row pairs first (kw 0|1), then the kw = 2 taps two by two"""
-    if p < 9:
-        return (p, 0), (p, 1)
-    q = p - 9
-    return (2 * q, 2), ((2 * q + 1, 2) if 2 * q + 1 < 9 else None)
+CAP = 2.0
 
 
 def read_stmt(qn, T, lo):
@@ -39,12 +35,32 @@ def read_stmt(qn, T, lo):
     if lo:
         imm += 30720
     dst = ("xl" if lo else "xh") + f"[{qn & 1}][{T}]"
-    return f"{dst} = *reinterpret_cast<const bf16x8*>(lds + {base} + {imm});"
+    return f"RS_F_READ({dst} = *reinterpret_cast<const bf16x8*>(lds + {base} + {imm});)"
+
+
+OLD_ORDER = os.environ.get("RS_OLD_ORDER") == "1"
+OLD_FIN = True      # element-wise reads of an asm "+a" vector gave stale values (hipcc 7.2): read the accumulator whole
+
+
+def mfma_order(pair):
+    """(term, accumulator) order of a pair's 24 MFMAs.  Term-major keeps the three products of an accumulator 8 MFMAs apart.
+    Pair 13 finishes the own accumulators (0..3) early and pair 0 starts the partner's (4..7) late, so that every
+    accumulator rests >= 6 MFMAs between its last MFMA and the VALU reads that take it out of the accumulator file (an
+    MFMA result is not interlocked against VALU reads; 2 MFMAs of distance were measured NOT to be enough)."""
+    if OLD_ORDER:
+        return [(t, a) for t in range(3) for a in range(8)]
+    if pair == 13:
+        return [(0, a) for a in range(8)] + [(1, a) for a in range(4)] + [(2, a) for a in range(4)] + \
+               [(1, a) for a in range(4, 8)] + [(2, a) for a in range(4, 8)]
+    if pair == 0:
+        return [(0, a) for a in range(4)] + [(1, a) for a in range(4)] + [(0, a) for a in range(4, 8)] + \
+               [(1, a) for a in range(4, 8)] + [(2, a) for a in range(8)]
+    return [(t, a) for t in range(3) for a in range(8)]
 
 
 def mfma_stmt(pair, idx, first_unit_pair):
-    """idx 0..23 inside a pair: term-major (wl*xh, wh*xl, wh*xh), then tile, then cout tile"""
-    term, a = idx // 8, idx % 8
+    """idx 0..23 inside a pair; terms: wl*xh, wh*xl, wh*xh"""
+    term, a = mfma_order(pair)[idx]
     T, j = a // 2, a % 2
     w = ("wl" if term == 0 else "wh") + f"[{pair}][{j}]"
     x = ("xl" if term == 1 else "xh") + f"[{pair & 1}][{T}]"
@@ -53,118 +69,154 @@ def mfma_stmt(pair, idx, first_unit_pair):
     return f"RS_MF(acc[{a}], {w}, {x})"
 
 
-def epilogue_stmts(k):
-    """own accumulator k (tile i' = k >> 1, cout tile j = k & 1) of the brick two phases back"""
+def epilogue_items(k):
+    """(cost, statement) list for own accumulator k (tile i' = k >> 1, cout tile j = k & 1) of the brick two phases
+    back; pt{k} (the partner's half) was requested from the exchange scratch in block 1"""
     T, j = k >> 1, k & 1
     s = []
-    s.append(f"pt{k} = *reinterpret_cast<const f32x4*>(lds + sp_rd + {k * 1024});")
     for e in range(4):
-        s.append(f"t{k}[{e}] = keepB[{k}][{e}] + pt{k}[{e}];")
+        s.append((1, f"t{k}[{e}] = keepB[{k}][{e}] + pt{k}[{e}];"))
     for e in range(4):
-        s.append(f"t{k}[{e}] = __builtin_fmaf(t{k}[{e}], esc[{j}][{e}], esh[{j}][{e}]);")
-    s.append(f"sa{k} = __builtin_amdgcn_permlane16_swap(rres[{k}][0], rres[{k}][2], false, false);")
-    s.append(f"sb{k} = __builtin_amdgcn_permlane16_swap(rres[{k}][1], rres[{k}][3], false, false);")
-    # (own hi, own lo) words: sa = channels 0,1 ; sb = channels 2,3
+        s.append((1, f"t{k}[{e}] = __builtin_fmaf(t{k}[{e}], esc[{j}][{e}], esh[{j}][{e}]);"))
+    s.append((2.0, f"sa{k} = __builtin_amdgcn_permlane16_swap(rres[{k}][0], rres[{k}][2], false, false);"))
+    s.append((2.0, f"sb{k} = __builtin_amdgcn_permlane16_swap(rres[{k}][1], rres[{k}][3], false, false);"))
     for e, (src, sh) in enumerate((("sa", True), ("sa", False), ("sb", True), ("sb", False))):
         hi = f"{src}{k}[0] << 16" if sh else f"{src}{k}[0] & 0xffff0000u"
         lo = f"{src}{k}[1] << 16" if sh else f"{src}{k}[1] & 0xffff0000u"
-        s.append(f"rh{k} = __builtin_bit_cast(float, {hi});")
-        s.append(f"rl{k} = __builtin_bit_cast(float, {lo});")
-        s.append(f"rh{k} = rh{k} + rl{k};")
-        s.append(f"t{k}[{e}] = t{k}[{e}] + rh{k};")
+        s.append((1, f"rh{k} = __builtin_bit_cast(float, {hi});"))
+        s.append((1, f"rl{k} = __builtin_bit_cast(float, {lo});"))
+        s.append((1, f"rh{k} = rh{k} + rl{k};"))
+        s.append((1, f"t{k}[{e}] = t{k}[{e}] + rh{k};"))
     for e in range(4):
-        s.append(f"u{k} = t{k}[{e}] * a.neg_slope;")
-        s.append(f"t{k}[{e}] = __builtin_fmaxf(t{k}[{e}], u{k});")
+        s.append((1, f"u{k} = t{k}[{e}] * a.neg_slope;"))
+        s.append((1, f"t{k}[{e}] = __builtin_fmaxf(t{k}[{e}], u{k});"))
     for p in range(2):
-        s.append(f"hb{k}[{p}] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{{t{k}[{2 * p}], t{k}[{2 * p + 1}]}}, bf16x2));")
-        s.append(f"hf{k}[0] = __builtin_bit_cast(float, hb{k}[{p}] << 16);")
-        s.append(f"hf{k}[1] = __builtin_bit_cast(float, hb{k}[{p}] & 0xffff0000u);")
-        s.append(f"hf{k}[0] = t{k}[{2 * p}] - hf{k}[0];")
-        s.append(f"hf{k}[1] = t{k}[{2 * p + 1}] - hf{k}[1];")
-        s.append(f"lb{k}[{p}] = __builtin_bit_cast(unsigned, __builtin_convertvector(hf{k}, bf16x2));")
-    s.append(f"sa{k} = __builtin_amdgcn_permlane16_swap(hb{k}[0], lb{k}[0], false, false);")
-    s.append(f"sb{k} = __builtin_amdgcn_permlane16_swap(hb{k}[1], lb{k}[1], false, false);")
-    s.append(f"__builtin_amdgcn_raw_buffer_store_b128(u32x4{{sa{k}[0], sb{k}[0], sa{k}[1], sb{k}[1]}}, dsc_y, voy[{T}] + {j * 64}, 0, 0);")
-    return s
+        s.append((1, f"hb{k}[{p}] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{{t{k}[{2 * p}], t{k}[{2 * p + 1}]}}, bf16x2));"))
+        s.append((1, f"hf{k}[0] = __builtin_bit_cast(float, hb{k}[{p}] << 16);"))
+        s.append((1, f"hf{k}[1] = __builtin_bit_cast(float, hb{k}[{p}] & 0xffff0000u);"))
+        s.append((1, f"hf{k}[0] = t{k}[{2 * p}] - hf{k}[0];"))
+        s.append((1, f"hf{k}[1] = t{k}[{2 * p + 1}] - hf{k}[1];"))
+        s.append((1, f"lb{k}[{p}] = __builtin_bit_cast(unsigned, __builtin_convertvector(hf{k}, bf16x2));"))
+    s.append((2.0, f"sa{k} = __builtin_amdgcn_permlane16_swap(hb{k}[0], lb{k}[0], false, false);"))
+    s.append((2.0, f"sb{k} = __builtin_amdgcn_permlane16_swap(hb{k}[1], lb{k}[1], false, false);"))
+    s.append((2.0, f"__builtin_amdgcn_raw_buffer_store_b128(u32x4{{sa{k}[0], sb{k}[0], sa{k}[1], sb{k}[1]}}, dsc_y, voy[{T}] + {j * 64}, 0, 0);"))
+    return [(c, f"RS_F_EPI({st})") for c, st in s]
+
+
+class Sched:
+    def __init__(self):
+        self.slots = [[] for _ in range(NSLOT)]
+        self.load = [0.0] * NSLOT
+
+    def put(self, slot, cost, stmt):
+        self.slots[slot].append(stmt)
+        self.load[slot] += cost
+
+    def place(self, start, cost, stmt, end=NSLOT, cap=CAP):
+        """first slot >= start with room; returns the slot"""
+        s = start
+        while s < end and self.load[s] + cost > cap + 1e-9:
+            s += 1
+        assert s < end, (stmt, start)
+        self.put(s, cost, stmt)
+        return s
 
 
 def build(with_pairs: bool):
-    slots = [[] for _ in range(NSLOT)]
-    # A. MFMAs and fragment reads
+    S = Sched()
+    mf = [[] for _ in range(NSLOT)]
+    # A. MFMAs (fixed) and fragment reads (fixed: one per three MFMAs, a pair ahead)
     for b in range(14):
         pair = 13 if b == 0 else b - 1
         qn = 0 if b == 0 else b
         if not with_pairs and b >= 1:
             continue
         for pos in range(24):
-            slots[b * 24 + pos].append(mfma_stmt(pair, pos, first_unit_pair=(pair == 0)))
-        if qn <= 13 and (with_pairs or b == 0):
-            if b == 0 and not with_pairs:
-                continue           # drain: no next brick to read
+            mf[b * 24 + pos].append(mfma_stmt(pair, pos, first_unit_pair=(pair == 0)))
+        if with_pairs:
             r = 0
             for T in range(4):
                 for lo in (0, 1):
-                    slots[b * 24 + 3 * r].append(read_stmt(qn, T, lo))
+                    S.put(b * 24 + 3 * r, 1, read_stmt(qn, T, lo))
                     r += 1
-    # B. keepB <- keepA while pair 13 runs, then the accumulators leave the accumulator file
+    # B. descriptors / masks of this phase (scalar work + a few VALU), early in block 0
+    S.put(1, 0.5, "dsc_y = RS_DESC(a.y, c2, ph >= 2);")
+    S.put(2, 2.0, "RS_VOY()")
+    S.put(4, 0.5, "dsc_x = RS_DESC(a.x, nx, ph + 1 < n);")
+    # C. keepB <- keepA while pair 13 runs
     for k in range(4):
         for e in range(4):
-            slots[k * 4 + e].append(f"keepB[{k}][{e}] = keepA[{k}][{e}];")
+            S.place(5, 1, f"keepB[{k}][{e}] = keepA[{k}][{e}];", end=19)
+    # D. the accumulators leave the accumulator file (see mfma_order): own accumulators 0..3 rest from slot 12 + a on and
+    #    are overwritten at slot 24 + a; the partner's 4..7 rest from slot 16 + a on and are overwritten at slot 28 + a
     for a in range(8):
         dst = f"keepA[{a}]" if a < 4 else f"snd[{a - 4}]"
-        slots[19 + a].append(f"{dst} = acc[{a}]; asm volatile(\"\" : \"+v\"({dst}));")
-    # C. the partner's half goes to the exchange scratch
+        lo, hi = (12 + a + 6, 24 + a) if a < 4 else (16 + a + 6, 28 + a)
+        if OLD_ORDER:
+            lo, hi = 19 + a, 24 + a
+        if OLD_FIN:
+            S.put(lo, 4, f"{dst} = acc[{a}]; asm volatile(\"\" : \"+v\"({dst}));")
+            continue
+        for e in range(4):
+            S.place(lo, 1, f"{dst}[{e}] = acc[{a}][{e}]; asm volatile(\"\" : \"+v\"({dst}[{e}]));", end=hi + 1, cap=3.0)
+    # E. the partner's half goes to the exchange scratch; the partner's half of the brick two phases back is requested
     for a in range(4):
-        slots[27 + a].append(f"*reinterpret_cast<f32x4*>(lds + sp_wr + {a * 1024}) = snd[{a}];")
-    # D. LDS-DMA of the next brick: pieces m = 0..14 in pairs 0..7
+        S.place(28 + a + 2, 2.0, f"*reinterpret_cast<f32x4*>(lds + sp_wr + {a * 1024}) = snd[{a}];")
+    for k in range(4):
+        S.place(38, 1, f"RS_F_EPI(pt{k} = *reinterpret_cast<const f32x4*>(lds + sp_rd + {k * 1024});)")
+    # F. LDS-DMA of the next brick: pieces m = 0..14 in pairs 0..7 (a slot each)
     if with_pairs:
         m = 0
         for b in range(1, 9):
             for pos in (10, 22):
                 if m < 15:
-                    slots[b * 24 + pos].append(f"RS_DMA({m})")
+                    S.place(b * 24 + pos, 2.0, f"RS_F_DMA(RS_DMA({m}))")
                     m += 1
-    dma_slots = {b * 24 + pos for b in range(1, 9) for pos in (10, 22)}
-    # E. epilogue of the brick two phases back: one statement per slot, pairs 1..8
-    ep = [st for k in range(4) for st in epilogue_stmts(k)]
+    # G. epilogue of the brick two phases back: in program order, wherever a slot has room, from pair 1 on
     s = 2 * 24
-    for st in ep:
-        while s in dma_slots:
-            s += 1
-        slots[s].append(st)
-        s += 1
-    assert s <= 12 * 24, s
-    # F. residual of the previous brick (consumed by the next phase's epilogue): the youngest VMEM operations of the phase
-    for k, pos in enumerate((1, 7, 13, 19)):
-        slots[12 * 24 + pos].append(f"rres[{k}] = __builtin_amdgcn_raw_buffer_load_b128(dsc_r, voy0[{k >> 1}] + {(k & 1) * 64}, 0, 0);")
-    # G. the read bases move to the other image once their last reads of this phase are out
-    tg = [(10 * 24 + 2, "rbin[0] ^= BUF1;"), (10 * 24 + 5, "rbin[1] ^= BUF1;")]
+    last = s
+    for k in range(4):
+        for cost, st in epilogue_items(k):
+            s = S.place(s, cost, st, end=12 * 24)
+            if cost >= 2.0:
+                s += 1                      # nothing behind a swap / store in its own slot
+            last = s
+    # H. residual of the previous brick (consumed by the next phase's epilogue): the youngest VMEM operations of the phase
+    S.put(11 * 24 + 20, 0.5, "dsc_r = RS_DESC(a.res, c1, (int)(a.res != nullptr) & (int)(ph >= 1) & (int)(ph - 1 < n));")
+    s = max(12 * 24, last + 1)
+    for k in range(4):
+        s = S.place(s, 2.0, f"rres[{k}] = __builtin_amdgcn_raw_buffer_load_b128(dsc_r, voy0[{k >> 1}] + {(k & 1) * 64}, 0, 0);") + 2
+    # I. the read bases move to the other image once their last reads of this phase are out; scratch halves swap
+    tg = [(10 * 24 + 1, "rbin[0] ^= BUF1;"), (10 * 24 + 2, "rbin[1] ^= BUF1;")]
     for q in range(4):
-        tg += [((10 + q) * 24 + 8, f"rb2[0][{q}] ^= BUF1;"), ((10 + q) * 24 + 11, f"rb2[1][{q}] ^= BUF1;")]
+        tg += [((10 + q) * 24 + 4, f"rb2[0][{q}] ^= BUF1;"), ((10 + q) * 24 + 5, f"rb2[1][{q}] ^= BUF1;")]
     tg += [(13 * 24 + 22, "rb2[0][4] ^= BUF1;"), (13 * 24 + 23, "rb2[1][4] ^= BUF1;")]
-    tg += [(11 * 24 + 14, "sp_rd ^= 16384;"), (11 * 24 + 17, "sp_wr ^= 16384;")]
-    if with_pairs:
-        for sl, st in tg:
-            slots[sl].append(st)
-    else:
-        slots[11 * 24 + 14].append("sp_rd ^= 16384;")
-        slots[11 * 24 + 17].append("sp_wr ^= 16384;")
+    if not with_pairs:
+        tg = []
+    tg += [(11 * 24 + 13, "sp_rd ^= 16384;"), (11 * 24 + 14, "sp_wr ^= 16384;")]
+    for sl, st in tg:
+        S.place(sl, 1, st)
+    # J. the walk moves on (scalar)
+    S.put(13 * 24 + 10, 0.5, "c2 = c1; c1 = c0; c0 = nx;")
+    S.put(13 * 24 + 13, 0.5, "RS_STEP(nx, c0)")
     out = []
-    for i, sl in enumerate(slots):
-        if not sl:
+    for i in range(NSLOT):
+        if not mf[i] and not S.slots[i]:
             continue
-        out.append(f"    // slot {i} (block {i // 24}, pos {i % 24})")
-        for st in sl:
+        out.append(f"    // slot {i} (block {i // 24}, pos {i % 24}; filler load {S.load[i]:g})")
+        for st in mf[i] + S.slots[i]:
             out.append("    " + st)
         out.append("    __builtin_amdgcn_sched_barrier(0);")
-    return "\n".join(out) + "\n"
+    over = sum(1 for l in S.load if l > CAP)
+    return "\n".join(out) + "\n", max(S.load), over, last
 
 
 def main():
     hdr = "// GENERATED by tools/gen_rs_schedule.py -- do not edit; edit the generator and re-run it.\n"
-    open(os.path.join(OUT, "conv3d_rs_phase_main.inc"), "w").write(hdr + build(True))
-    open(os.path.join(OUT, "conv3d_rs_phase_drain.inc"), "w").write(hdr + build(False))
-    print("wrote conv3d_rs_phase_{main,drain}.inc")
+    for name, wp in (("main", True), ("drain", False)):
+        txt, mx, over, last = build(wp)
+        open(os.path.join(OUT, f"conv3d_rs_phase_{name}.inc"), "w").write(hdr + txt)
+        print(f"{name}: max slot load {mx:g}, {over} overloaded slots, epilogue ends at slot {last} (block {last // 24})")
 
 
 if __name__ == "__main__":

@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 if "MVSGI_LIB" not in os.environ:
     import __graft_entry__ as g
-    lib = g.build_stamps(0)
+    abl = int(os.environ.get("RS_ABL", "0"))
+    lib = g.build_stamps(abl)
     env = dict(os.environ, MVSGI_LIB=lib, MVSGI_STAMP="2")
     r = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, capture_output=True, text=True)
     rows = [l for l in r.stderr.splitlines() if l.startswith("wave ")]
@@ -15,20 +16,19 @@ if "MVSGI_LIB" not in os.environ:
         print(r.stdout[-2000:], r.stderr[-4000:])
         sys.exit(1)
     import statistics
-    names = ["barrier->start", "pair 13 (+ first reads)", "epilogue of unit u-2", "exchange + residual request",
-             "pairs 0..12 (+ DMA issue)", "wait vmcnt/lgkmcnt"]
+    names = ["barrier -> phase start", "phase body (336 MFMAs + fillers)", "wait vmcnt / lgkmcnt"]
     for l in rows[-4:]:
         t = [int(v) for v in l.split(":")[1].split()]
-        t = [v for v in t if v > 0 or v == t[0]]
-        ph = [t[i:i + 6] for i in range(0, len(t) - 6, 6)]
-        segs = [[] for _ in range(6)]
+        t = [v for i, v in enumerate(t) if v > 0 or i == 0]
+        ph = [t[i:i + 3] for i in range(0, len(t) - 3, 3)]
+        segs = [[] for _ in range(3)]
         for k in range(3, len(ph) - 3):          # steady-state phases only
-            for sidx in range(5):
-                segs[sidx + 1].append(ph[k][sidx + 1] - ph[k][sidx])
-            segs[0].append(ph[k][0] - ph[k - 1][5])
+            segs[0].append(ph[k][0] - ph[k - 1][2])
+            segs[1].append(ph[k][1] - ph[k][0])
+            segs[2].append(ph[k][2] - ph[k][1])
         tot = sum(statistics.median(sg) for sg in segs if sg)
-        print(l.split(":")[0], " ".join(f"{nm}: {statistics.median(sg):.0f}" for nm, sg in zip(names, segs) if sg),
-              f"| phase {tot:.0f} ticks ({len(ph)} phases)")
+        print(l.split(":")[0], " | ".join(f"{nm}: {statistics.median(sg):.0f}" for nm, sg in zip(names, segs) if sg),
+              f"| phase {tot:.0f} ticks = {tot / 336:.2f} per MFMA ({len(ph)} phases)")
     sys.exit(0)
 import numpy as np
 import torch
