@@ -127,6 +127,8 @@ class ConvProbe:
         self.H, self.torch = H, torch
         self.orig = H.conv3d
         self.orig_up2 = H.conv3d_up2
+        self.orig_rs = H.conv3d_rs
+        self.orig_os = H.conv3d_out_split
         self.records = []
         self.enabled = False
 
@@ -159,13 +161,41 @@ class ConvProbe:
             self.records.append((H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, w_layout), 2.0 * 27 * Cin * Cout * vox, s, e))
             return y
 
+        def probed_rs(x, w_packed_rs, scale, shift, res=None, neg_slope=0.01, out=None, out_f32=False):
+            if not self.enabled:
+                return self.orig_rs(x, w_packed_rs, scale, shift, res, neg_slope, out, out_f32)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = self.orig_rs(x, w_packed_rs, scale, shift, res, neg_slope, out, out_f32)
+            e.record()
+            self.records.append(("conv3d_rs32_kernel<%s>" % ("true" if out_f32 else "false"),
+                                 2.0 * 27 * x.C * scale.numel() * x.B * x.D * x.H * x.W, s, e))
+            return y
+
+        def probed_os(x, w_packed_b3, scale, shift, out, res=None, stride=1, neg_slope=0.01):
+            if not self.enabled:
+                return self.orig_os(x, w_packed_b3, scale, shift, out, res, stride, neg_slope)
+            B, D, Hh, W, Cin = x.shape
+            Cout = scale.numel()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = self.orig_os(x, w_packed_b3, scale, shift, out, res, stride, neg_slope)
+            e.record()
+            self.records.append((H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3) + " [split-padded out]",
+                                 2.0 * 27 * Cin * Cout * out.B * out.D * out.H * out.W, s, e))
+            return y
+
         H.conv3d = probed
         H.conv3d_up2 = probed_up2
+        H.conv3d_rs = probed_rs
+        H.conv3d_out_split = probed_os
         return self
 
     def __exit__(self, *a):
         self.H.conv3d = self.orig
         self.H.conv3d_up2 = self.orig_up2
+        self.H.conv3d_rs = self.orig_rs
+        self.H.conv3d_out_split = self.orig_os
 
     def summary(self):
         agg = {}

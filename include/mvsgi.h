@@ -250,15 +250,19 @@ int mvsgi_deform_conv2d_f32(const float* x, const float* offset, int offset_per_
  *   mvsgi_conv3d_rs_split      BaseConvBlk3d.forward (common_modules.py:107-115) for Cin = Cout = 32, stride 1, on
  *                              split-padded x / res / y with the layer's weights resident in registers
  *                              (w_packed from mvsgi_conv3d_rs_pack_weights); same arithmetic as MVSGI_CONV_BF16X3;
- *                              neg_slope in [0, 1]
+ *                              neg_slope in [0, 1]; y_is_f32 != 0: y is a plain fp32 [B][D][H][W][32] tensor (the
+ *                              hand-over to a kernel that reads fp32), otherwise split-padded
  */
+int mvsgi_conv3d_f32_out_split(const float* x, const float* w_packed_b3, const float* scale, const float* shift,
+                               const float* res, void* y_split, int B, int Cin, int Din, int Hin, int Win, int Cout,
+                               int stride, float neg_slope, mvsgi_stream_t stream);   /* mvsgi_conv3d_f32 (MVSGI_CONV_BF16X3) writing a split-padded y */
 size_t mvsgi_conv3d_rs_packed_weight_bytes(int Cout, int Cin);
 int mvsgi_conv3d_rs_pack_weights(const float* w_oidhw, void* w_packed, int Cout, int Cin, mvsgi_stream_t stream);
 size_t mvsgi_act_split_bytes(int B, int C, int D, int H, int W);
 int mvsgi_act_f32_to_split(const float* x, void* y_split, int B, int C, int D, int H, int W, mvsgi_stream_t stream);
 int mvsgi_act_split_to_f32(const void* x_split, float* y, int B, int C, int D, int H, int W, mvsgi_stream_t stream);
 int mvsgi_conv3d_rs_split(const void* x_split, const void* w_packed_rs, const float* scale, const float* shift,
-                          const void* res_split, void* y_split, int B, int Cin, int D, int H, int W, int Cout,
+                          const void* res_split, void* y, int y_is_f32, int B, int Cin, int D, int H, int W, int Cout,
                           float neg_slope, mvsgi_stream_t stream);
 
 #ifdef __cplusplus

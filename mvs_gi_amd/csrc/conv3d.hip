@@ -543,6 +543,23 @@ extern "C" int mvsgi_conv3d_f32(const float* x, const float* w_oidhw, const floa
     return launch_variant(v, a, mvsgi::as_stream(stream));
 }
 
+// the same block with the output in the split-padded format of conv3d_rs.hip (y_split zero-bordered, interior written):
+// the hand-over from a streaming split-bf16 layer to the register-stationary layers
+extern "C" int mvsgi_conv3d_f32_out_split(const float* x, const float* w_packed_b3, const float* scale, const float* shift,
+                                          const float* res, void* y_split, int B, int Cin, int Din, int Hin, int Win, int Cout,
+                                          int stride, float neg_slope, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(x && y_split && scale && shift && w_packed_b3, "mvsgi_conv3d_f32_out_split: null pointer");
+    MVSGI_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0, "mvsgi_conv3d_f32_out_split: Cin, Cout must be multiples of 16");
+    ConvArgs a{};
+    if (fill_args(a, x, nullptr, w_packed_b3, scale, shift, res, reinterpret_cast<float*>(y_split), B, Cin, Din, Hin, Win, Cout,
+                  stride, neg_slope))
+        return 1;
+    a.y_split = static_cast<unsigned char*>(y_split);
+    const int v = select_variant(a, MVSGI_CONV_BF16X3);
+    if (v == V_COUNT) return 1;
+    return launch_variant(v, a, mvsgi::as_stream(stream));
+}
+
 extern "C" const char* mvsgi_conv3d_variant_f32(int B, int Cin, int Din, int Hin, int Win, int Cout, int stride,
                                                 int impl) {
     ConvArgs a{};

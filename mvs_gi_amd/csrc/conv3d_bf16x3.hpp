@@ -827,6 +827,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
             // multiplied so the epilogue does not wait for them one tile at a time
             f32x4 esc[NW], esh[NW], rres[RPRE ? MW : 1][RPRE ? NW : 1];
             int eoff[MW];                  // in-frame element offset of (voxel, cout 4*kg) or -1 outside the volume
+            int soff[MW];                  // split-padded output (a.y_split): in-frame byte offset of the voxel's record
             if (last) {
 #pragma unroll
                 for (int j = 0; j < NW; ++j) {
@@ -838,6 +839,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                     const int od = od0 + tdv[i], oh = oh0 + thv[i], ow = ow0 + twv[i];
                     const bool inside = od < a.Do && oh < a.Ho && ow < a.Wo;
                     eoff[i] = inside ? ((od * a.Ho + oh) * a.Wo + ow) * a.Cout + kg * 4 : -1;
+                    soff[i] = ((((od + 1) * (a.Ho + 2) + oh + 1) * (a.Wo + 2) + ow + 1) * a.Cout) * 4 + (kg >> 1) * 16 + (kg & 1) * 8;
                 }
             }
             if constexpr (PLANE) {
@@ -957,7 +959,17 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                         if (a.res) r += RPRE ? rres[RPRE ? i : 0][RPRE ? j : 0] : rl[RPRE ? 0 : i][RPRE ? 0 : j];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : r[e] * a.neg_slope;
-                        if (eoff[i] >= 0 && ct0 + j < CT) *reinterpret_cast<f32x4*>(yb + eoff[i] + (ct0 + j) * 16) = r;
+                        if (a.y_split) {
+                            // split-padded output: slice (ct0 + j) of the voxel record, this lane's 4 couts = 8 B of hi and 8 B of lo
+                            u32x2 hi, lo;
+                            split_bf16x4(r, hi, lo);
+                            if (eoff[i] >= 0 && ct0 + j < CT) {
+                                unsigned char* q = a.y_split + (long long)b_ * ((long long)(a.Do + 2) * (a.Ho + 2) * (a.Wo + 2) * a.Cout * 4) +
+                                                   soff[i] + (ct0 + j) * 64;
+                                *reinterpret_cast<u32x2*>(q) = hi;
+                                *reinterpret_cast<u32x2*>(q + 32) = lo;
+                            }
+                        } else if (eoff[i] >= 0 && ct0 + j < CT) *reinterpret_cast<f32x4*>(yb + eoff[i] + (ct0 + j) * 16) = r;
                         acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
@@ -1003,6 +1015,8 @@ int launch_bf16x3(ConvArgs a, hipStream_t st) {
     MVSGI_REQUIRE((long long)a.Din * a.Hin * a.Win * a.Cin < (1ll << 29), "conv3d: volume too large for 32-bit byte offsets");
     MVSGI_REQUIRE(!UPS || (a.Din % 2 == 0 && a.Hin % 2 == 0 && a.Win % 2 == 0), "conv3d: fused upsample needs even sizes");
     MVSGI_REQUIRE((long long)a.Do * a.Ho * a.Wo * a.Cout < (1ll << 31), "conv3d: output frame too large for 32-bit element offsets");
+    MVSGI_REQUIRE(!a.y_split || (!V32 && (long long)(a.Do + 2) * (a.Ho + 2) * (a.Wo + 2) * a.Cout * 4 < (1ll << 31)),
+                  "conv3d: split-padded output not available for this kernel / size");
     a.total_units = (int)nb;
 #ifdef MVSGI_STAMPS
     {   // stamps of the PREVIOUS launch are printed when MVSGI_STAMP=2

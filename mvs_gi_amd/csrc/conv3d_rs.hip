@@ -185,6 +185,8 @@ struct RsUnit {      // coordinates of a brick (wave-uniform)
     int b, od, oh, ow;
 };
 
+// OUTF32: the output goes to a plain fp32 channels-last tensor [B][D][H][W][32] (the hand-over to a kernel that stages fp32)
+template <bool OUTF32>
 __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     using namespace rs;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -249,6 +251,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
         voy0[i] = (unsigned)((((pl + 1) * Hp + 2 * s + i + 1) * Wp + col + 1) * 128 + (kg & 1) * 32 + (kg >> 1) * 16);
+    unsigned voyo[2];     // the same for the OUTPUT tensor (fp32: unpadded, couts 4 kg .. 4 kg + 3 of the tile are 16 contiguous bytes)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        voyo[i] = OUTF32 ? (unsigned)(((pl * a.H + 2 * s + i) * a.W + col) * 128 + kg * 16) : voy0[i];
     int sp_rd = SCR + (wave ^ 2) * 4096 + lane * 16, sp_wr = SCR + 16384 + wave * 4096 + lane * 16;
 
     const int total = a.total_units, G = gridDim.x;
@@ -298,6 +304,17 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
         const int ok_ = (int)(VALID) & (int)(left_ > 0);                                                         \
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(PTR) + off_, 0, ok_ ? rec_ : 0, 0x00020000); \
     })
+#define RS_DESC_OUT(U, VALID)                                                                                   \
+    ({                                                                                                           \
+        const long long off_ = (long long)(U).b * ((long long)a.D * a.H * a.W * 128) +                           \
+                               ((long long)((U).od * TD * a.H + (U).oh * TH) * a.W + (U).ow * TW) * 128;         \
+        const long long left_ = (long long)a.B * a.D * a.H * a.W * 128 - off_;                                   \
+        const int rec_ = left_ > 0x7fffff00ll ? 0x7fffff00 : (int)left_;                                         \
+        const int ok_ = (int)(VALID) & (int)(left_ > 0);                                                         \
+        __builtin_amdgcn_make_buffer_rsrc(a.y + off_, 0, ok_ ? rec_ : 0, 0x00020000);                            \
+    })
+#define RS_F_SPL(...) if constexpr (!OUTF32) { __VA_ARGS__ }
+#define RS_F_F32(...) if constexpr (OUTF32) { __VA_ARGS__ }
 #define RS_DMA(M)                                                                                                \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(dsc_x, (__attribute__((address_space(3))) void*)(lds + nxt_img + (wave + 4 * (M)) * 1024), \
                                              16, voff[M], 0, 0, 0);
@@ -327,6 +344,16 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 #else
 #define RS_F_DMA(...) __VA_ARGS__
 #endif
+#if MVSGI_RS_ABL & 8      // no output stores (the value is kept alive)
+#define RS_F_STORE(V, D, O) { u32x4 v_ = V; asm volatile("" ::"v"(v_)); }
+#else
+#define RS_F_STORE(V, D, O) __builtin_amdgcn_raw_buffer_store_b128(V, D, O, 0, 0);
+#endif
+#if MVSGI_RS_ABL & 16     // no residual requests
+#define RS_F_RES(R, D, O)
+#else
+#define RS_F_RES(R, D, O) R = __builtin_amdgcn_raw_buffer_load_b128(D, O, 0, 0);
+#endif
 #ifdef MVSGI_RS_STAMPS   // diagnostic build (tools/rs_stamps.py): s_memtime stamps of workgroup 8, every wave
     int nst = 0;
 #define STAMP()                                                                                     \
@@ -351,13 +378,13 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     }
     f32x4 acc[8], keepA[4], keepB[4], snd[4];
     bf16x8 xh[2][4], xl[2][4];
-    u32x4 rres[4];
+    u32x4 rres[4], rresB[4], outp[4];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         keepA[k] = keepB[k] = snd[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        rres[k] = u32x4{0u, 0u, 0u, 0u};
+        rres[k] = rresB[k] = outp[k] = u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) xh[1][i] = xl[1][i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -380,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     {                                                                                                \
         const int dok_ = c2.od * TD + pl < a.D;                                                      \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                \
-            voy[i] = (dok_ & (int)(c2.oh * TH + 2 * s + i < a.H) & (int)(c2.ow * TW + col < a.W)) ? voy0[i] : 0xffffff00u; \
+            voy[i] = (dok_ & (int)(c2.oh * TH + 2 * s + i < a.H) & (int)(c2.ow * TW + col < a.W)) ? voyo[i] : 0xffffff00u; \
     }
     // One code path per loop (a main / drain diamond inside one loop made hipcc park the accumulators in VGPRs at the
     // loop header: 64 v_accvgpr moves per phase).
@@ -410,6 +437,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 #undef RS_MF0
 #undef RS_DMA
 #undef RS_DESC
+#undef RS_DESC_OUT
+#undef RS_F_SPL
+#undef RS_F_F32
 #undef RS_STEP
 }
 
@@ -452,7 +482,7 @@ extern "C" int mvsgi_conv3d_rs_pack_weights(const float* w_oidhw, void* w_packed
 }
 
 extern "C" int mvsgi_conv3d_rs_split(const void* x, const void* w_packed_rs, const float* scale, const float* shift,
-                                     const void* res, void* y, int B, int Cin, int D, int H, int W, int Cout,
+                                     const void* res, void* y, int y_is_f32, int B, int Cin, int D, int H, int W, int Cout,
                                      float neg_slope, mvsgi_stream_t stream) {
     MVSGI_REQUIRE(x && y && w_packed_rs && scale && shift, "mvsgi_conv3d_rs_split: null pointer");
     MVSGI_REQUIRE(Cin == 32 && Cout == 32, "mvsgi_conv3d_rs_split: only 32 -> 32 channels (got %d -> %d)", Cin, Cout);
@@ -493,11 +523,12 @@ extern "C" int mvsgi_conv3d_rs_split(const void* x, const void* w_packed_rs, con
         }
     }
 #endif
-    static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
+    static mvsgi::PersistentGeom geo_cache[2][mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
-    if (mvsgi::persistent_geometry(conv3d_rs32_kernel, 256, rs::LDS_BYTES, 1, geo_cache, "mvsgi_conv3d_rs_split", geo)) return 1;
+    auto kern = y_is_f32 ? conv3d_rs32_kernel<true> : conv3d_rs32_kernel<false>;
+    if (mvsgi::persistent_geometry(kern, 256, rs::LDS_BYTES, 1, geo_cache[y_is_f32 ? 1 : 0], "mvsgi_conv3d_rs_split", geo)) return 1;
     const long long resident = (long long)geo.cus / 8 * 8 > 0 ? (long long)geo.cus / 8 * 8 : 8;
-    hipLaunchKernelGGL(conv3d_rs32_kernel, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), rs::LDS_BYTES,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), rs::LDS_BYTES,
                        mvsgi::as_stream(stream), a);
     return mvsgi::check_launch("mvsgi_conv3d_rs_split");
 }

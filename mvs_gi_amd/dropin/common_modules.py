@@ -42,7 +42,7 @@ _USE_V32 = os.environ.get("MVSGI_V32", "0") != "0"
 class ConvLaunch:
     """Device-resident launch arguments of one BaseConvBlk3d: PyTorch-layout weight, packed
     MFMA weight (or None), per-channel scale/shift (eval BatchNorm3d or bias), stride, slope."""
-    __slots__ = ("w", "wp", "wp_b3", "wp_c16", "wp_v32", "scale", "shift", "stride", "neg_slope", "cin", "cout", "key")
+    __slots__ = ("w", "wp", "wp_b3", "wp_c16", "wp_v32", "wp_rs", "scale", "shift", "stride", "neg_slope", "cin", "cout", "key")
 
     def run(self, x_ndhwc: Tensor, res: Optional[Tensor] = None, impl: Optional[int] = None) -> Tensor:
         wp = self.wp
@@ -73,6 +73,20 @@ class ConvLaunch:
         if getattr(self, "wp_c16", None) is None:
             self.wp_c16 = H.pack_conv_weights_bf16x3_c16(self.w)
         return self.wp_c16
+
+    def _wp_b3(self):
+        if self.wp_b3 is None:
+            self.wp_b3 = H.pack_conv_weights_bf16x3(self.w)
+        return self.wp_b3
+
+    def rs_ok(self) -> bool:
+        """The register-stationary kernel (csrc/conv3d_rs.hip) serves this layer."""
+        return H.conv3d_rs_applies(self.cin, self.cout, self.stride, self.neg_slope)
+
+    def _wp_rs(self):
+        if self.wp_rs is None:
+            self.wp_rs = H.pack_conv_weights_rs(self.w)
+        return self.wp_rs
 
     def _wp_v32(self):
         if self.wp_v32 is None:
@@ -178,6 +192,7 @@ def lower_conv_block(blk) -> ConvLaunch:
     L.wp_b3 = None
     L.wp_c16 = None
     L.wp_v32 = None
+    L.wp_rs = None
     L.scale = scale.contiguous()
     L.shift = shift.contiguous()
     L.stride = int(conv.stride[0])

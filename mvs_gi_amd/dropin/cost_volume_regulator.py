@@ -7,6 +7,7 @@ mvsgi_conv3d_f32 / mvsgi_resize_trilinear_f32 launch on the current stream.
 from __future__ import annotations
 
 import copy
+import os
 from typing import Sequence
 
 from torch import nn, Tensor
@@ -31,7 +32,63 @@ class UNetDownBlk(nn.Module):
         return cm._to_ncdhw_view(down_block_ndhwc(self, H.as_ndhwc(x)))
 
 
+# MVSGI_RS=0 keeps every layer on the streaming kernels.  The register-stationary kernel walks >= MVSGI_RS_MIN_UNITS
+# 128-voxel bricks per launch (one workgroup per CU, each with a prologue and two drain phases: small launches lose)
+_USE_RS = os.environ.get("MVSGI_RS", "1") != "0"
+_RS_MIN_UNITS = int(os.environ.get("MVSGI_RS_MIN_UNITS", "2048"))
+
+
+def _rs_chain(blk, x: Tensor):
+    """The residual convs of a UNetDownBlk as launch records if ALL of them can run register-stationary on split-padded
+    activations (32 -> 32 channels: UNet level 0 of the (16, 32) regulator), else None."""
+    if not (_USE_RS and H.get_conv_mode() == "bf16x3" and len(blk.blks) > 0):
+        return None
+    L0 = cm.lower_conv_block(blk.first)
+    if L0.cin % 16 or L0.cout != 32:
+        return None
+    B, D, Hh, W, _ = x.shape
+    s = L0.stride
+    Do, Ho, Wo = (D - 1) // s + 1, (Hh - 1) // s + 1, (W - 1) // s + 1
+    if B * ((Do + 1) // 2) * ((Ho + 3) // 4) * ((Wo + 15) // 16) < _RS_MIN_UNITS:
+        return None
+    chain = []
+    for rb in blk.blks:
+        if not cm._is_identity(rb.one_by_one) or getattr(rb, "out_pad", 0) != 0:
+            return None
+        L1, L2 = cm.lower_conv_block(rb.blk1), cm.lower_conv_block(rb.blk2)
+        if not (L1.rs_ok() and L2.rs_ok()):
+            return None
+        chain.append((L1, L2))
+    return L0, chain, (B, Do, Ho, Wo)
+
+
+def _down_block_rs(blk, x: Tensor, L0, chain, dims) -> Tensor:
+    """first conv (streaming kernel, output written split-padded) -> residual blocks on the register-stationary kernel, three
+    rotating split-padded buffers owned by the module (zero borders, allocated once) -> last conv writes plain fp32."""
+    B, Do, Ho, Wo = dims
+    key = (B, Do, Ho, Wo, x.device)
+    bufs = blk.__dict__.get("_mvsgi_rs_bufs")
+    if bufs is None or bufs[0] != key:
+        bufs = (key, [H.SplitAct(B, Do, Ho, Wo, 32, x.device) for _ in range(3)])
+        blk.__dict__["_mvsgi_rs_bufs"] = bufs
+    b = bufs[1]
+    H.conv3d_out_split(x, L0._wp_b3(), L0.scale, L0.shift, out=b[0], stride=L0.stride, neg_slope=L0.neg_slope)
+    cur, out = 0, None
+    for i, (L1, L2) in enumerate(chain):
+        r, y = (cur + 1) % 3, (cur + 2) % 3
+        H.conv3d_rs(b[cur], L1._wp_rs(), L1.scale, L1.shift, neg_slope=L1.neg_slope, out=b[r])
+        if i == len(chain) - 1:
+            out = H.conv3d_rs(b[r], L2._wp_rs(), L2.scale, L2.shift, res=b[cur], neg_slope=L2.neg_slope, out_f32=True)
+        else:
+            H.conv3d_rs(b[r], L2._wp_rs(), L2.scale, L2.shift, res=b[cur], neg_slope=L2.neg_slope, out=b[y])
+            cur = y
+    return out
+
+
 def down_block_ndhwc(blk, x: Tensor) -> Tensor:
+    rs = _rs_chain(blk, x)
+    if rs is not None:
+        return _down_block_rs(blk, x, *rs)
     x = cm.lower_conv_block(blk.first).run(x)
     for rb in blk.blks:
         x = cm.res_block_ndhwc(rb, x)

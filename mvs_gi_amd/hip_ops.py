@@ -379,18 +379,49 @@ def pack_conv_weights_rs(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
     return wp
 
 
-def conv3d_rs(x: SplitAct, w_packed_b3, scale, shift, res: Optional[SplitAct] = None, neg_slope=0.01,
-              out: Optional[SplitAct] = None) -> SplitAct:
-    """Register-stationary split-bf16 conv (Cin = Cout = 32, stride 1) on split-padded activations."""
+def conv3d_rs(x: SplitAct, w_packed_rs, scale, shift, res: Optional[SplitAct] = None, neg_slope=0.01,
+              out=None, out_f32: bool = False):
+    """Register-stationary split-bf16 conv (Cin = Cout = 32, stride 1) on split-padded activations.  `out_f32`: the
+    result is a plain fp32 [B, D, H, W, 32] tensor instead of a SplitAct (hand-over to an fp32-reading kernel)."""
     lib = _lib.load()
     Cout = scale.numel()
-    y = out if out is not None else SplitAct(x.B, x.D, x.H, x.W, Cout, x.buf.device)
-    if res is not None and res.shape != y.shape:
-        raise AssertionError(f"residual {res.shape} does not match output {y.shape}")
-    _lib.check(lib.mvsgi_conv3d_rs_split(x.buf.data_ptr(), w_packed_b3.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                         None if res is None else res.buf.data_ptr(), y.buf.data_ptr(), x.B, x.C, x.D, x.H,
+    if out_f32:
+        y = out if out is not None else torch.empty((x.B, x.D, x.H, x.W, Cout), device=x.buf.device, dtype=torch.float32)
+        yp = y.data_ptr()
+        if tuple(y.shape) != (x.B, x.D, x.H, x.W, Cout) or not y.is_contiguous():
+            raise AssertionError(f"fp32 output {tuple(y.shape)} does not match {(x.B, x.D, x.H, x.W, Cout)}")
+    else:
+        y = out if out is not None else SplitAct(x.B, x.D, x.H, x.W, Cout, x.buf.device)
+        yp = y.buf.data_ptr()
+        if y.shape != (x.B, x.D, x.H, x.W, Cout):
+            raise AssertionError(f"split output {y.shape} does not match {(x.B, x.D, x.H, x.W, Cout)}")
+    if res is not None and res.shape != (x.B, x.D, x.H, x.W, Cout):
+        raise AssertionError(f"residual {res.shape} does not match the output")
+    _lib.check(lib.mvsgi_conv3d_rs_split(x.buf.data_ptr(), w_packed_rs.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                         None if res is None else res.buf.data_ptr(), yp, int(out_f32), x.B, x.C, x.D, x.H,
                                          x.W, Cout, float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_rs_split")
     return y
+
+
+def conv3d_out_split(x, w_packed_b3, scale, shift, out: "SplitAct", res=None, stride=1, neg_slope=0.01) -> "SplitAct":
+    """mvsgi_conv3d_f32 (split-bf16 streaming kernel) with the output written split-padded into `out`."""
+    lib = _lib.load()
+    x = _dev(x, "x")
+    B, Din, Hin, Win, Cin = x.shape
+    Cout = scale.numel()
+    Do, Ho, Wo = (Din - 1) // stride + 1, (Hin - 1) // stride + 1, (Win - 1) // stride + 1
+    if out.shape != (B, Do, Ho, Wo, Cout):
+        raise AssertionError(f"split output {out.shape} does not match {(B, Do, Ho, Wo, Cout)}")
+    if res is not None:
+        res = _dev(res, "res")
+    _lib.check(lib.mvsgi_conv3d_f32_out_split(x.data_ptr(), w_packed_b3.data_ptr(), scale.data_ptr(), shift.data_ptr(), _ptr(res),
+                                              out.buf.data_ptr(), B, Cin, Din, Hin, Win, Cout, stride, float(neg_slope),
+                                              _stream_ptr(x)), "mvsgi_conv3d_f32_out_split")
+    return out
+
+
+def conv3d_rs_applies(cin: int, cout: int, stride: int, neg_slope: float) -> bool:
+    return cin == 32 and cout == 32 and stride == 1 and 0.0 <= neg_slope <= 1.0
 
 
 def pack_conv2d_weights_bf16x3(w_oihw: torch.Tensor) -> Optional[torch.Tensor]:

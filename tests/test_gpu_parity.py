@@ -845,3 +845,119 @@ def test_fused_resblock2d_vs_two_convs(shape):
         H.set_conv_mode(old_mode)
     assert _rel(y.cpu().numpy(), ref) <= 1e-4
     assert _rel(y.permute(0, 2, 3, 1).cpu().numpy(), two.cpu().numpy()) <= 2e-5
+
+
+# ------------------------------------------------------------------------------ register-stationary conv (csrc/conv3d_rs.hip)
+def test_split_padded_format_round_trip_and_border():
+    rng = np.random.default_rng(3)
+    x = _g(rng.standard_normal((2, 3, 5, 7, 32), dtype=np.float32) * 10)
+    s = H.act_to_split(x)
+    assert tuple(s.buf.shape) == (2, 5, 7, 9, 32) and s.buf.dtype == torch.int32
+    back = H.act_from_split(s)
+    # hi + lo keeps 16-17 significant bits
+    assert float(((back - x).abs() / x.abs().clamp_min(1e-30)).max()) <= 2.0 ** -16
+    again = H.act_from_split(H.act_to_split(back))
+    assert torch.equal(again, back)                                   # the representable set is closed under the conversion
+    for sl in (s.buf[:, 0], s.buf[:, -1], s.buf[:, :, 0], s.buf[:, :, -1], s.buf[:, :, :, 0], s.buf[:, :, :, -1]):
+        assert int(sl.abs().max()) == 0                               # the border is never written
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 4, 16), (1, 4, 8, 32), (2, 5, 7, 37), (3, 3, 9, 16), (1, 8, 12, 48)])
+@pytest.mark.parametrize("res,slope,out_f32", [(True, 0.01, False), (False, 0.01, True), (True, 0.0, True), (False, 1.0, False)])
+def test_conv3d_rs_vs_oracle(shape, res, slope, out_f32):
+    """Register-stationary 32 -> 32 conv on split-padded activations against the CPU oracle's conv block on the SAME
+    (16-bit-split) inputs; bricks ragged in every axis, one-brick and many-brick launches, residual, fp32 hand-over."""
+    B, d, h, w = shape
+    rng = np.random.default_rng(hash(shape) % 1000)
+    x = _g(rng.standard_normal((B, d, h, w, 32), dtype=np.float32))
+    r = _g(rng.standard_normal((B, d, h, w, 32), dtype=np.float32)) if res else None
+    wt = (rng.standard_normal((32, 32, 3, 3, 3)) / np.sqrt(27 * 32)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, 32).astype(np.float32)
+    sh = (rng.standard_normal(32) * 0.1).astype(np.float32)
+    xs, rs = H.act_to_split(x), (H.act_to_split(r) if res else None)
+    y = H.conv3d_rs(xs, H.pack_conv_weights_rs(_g(wt)), _g(sc), _g(sh), res=rs, neg_slope=slope, out_f32=out_f32)
+    got = (y if out_f32 else H.act_from_split(y)).cpu().numpy()
+    xq = H.act_from_split(xs).cpu().permute(0, 4, 1, 2, 3)            # what the kernel actually multiplied
+    rq = H.act_from_split(rs).cpu().permute(0, 4, 1, 2, 3) if res else None
+    ref = F.conv3d(xq, torch.from_numpy(wt), padding=1) * torch.from_numpy(sc).view(1, -1, 1, 1, 1) + torch.from_numpy(sh).view(1, -1, 1, 1, 1)
+    if res:
+        ref = ref + rq
+    ref = torch.where(ref > 0, ref, ref * slope).permute(0, 2, 3, 4, 1).numpy()
+    assert _rel(got, ref) <= 1e-4                                     # split-bf16 products: ~2^-16 each
+    if not out_f32:
+        for sl in (y.buf[:, 0], y.buf[:, -1], y.buf[:, :, 0], y.buf[:, :, -1], y.buf[:, :, :, 0], y.buf[:, :, :, -1]):
+            assert int(sl.abs().max()) == 0
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 32, 8, 16, 16, 2), (2, 16, 32, 7, 9, 13, 2), (1, 32, 32, 4, 6, 10, 1), (1, 16, 16, 5, 9, 11, 1)])
+def test_streaming_conv_split_padded_output_is_the_split_of_its_fp32_output(shape):
+    B, cin, cout, d, h, w, s = shape
+    rng = np.random.default_rng(11)
+    x = _g(rng.standard_normal((B, d, h, w, cin), dtype=np.float32))
+    wt = _g((rng.standard_normal((cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32))
+    wp = H.pack_conv_weights_bf16x3(wt)
+    sc, sh = _g(rng.uniform(0.5, 1.5, cout).astype(np.float32)), _g((rng.standard_normal(cout) * 0.1).astype(np.float32))
+    y = H.conv3d(x, wt, wp, sc, sh, stride=s, impl=H.CONV_BF16X3)
+    ys = H.SplitAct(*y.shape[:4], cout, x.device)
+    H.conv3d_out_split(x, wp, sc, sh, out=ys, stride=s)
+    assert torch.equal(ys.buf, H.act_to_split(y).buf)                 # bit for bit, border included
+
+
+def test_regulator_register_stationary_chain_matches_streaming_and_goldens(golden_dir):
+    """UNet level 0 of the (16, 32) regulator on the register-stationary kernels (forced on for a small case) against the
+    streaming kernels and the reference goldens."""
+    from mvs_gi_amd.dropin import cost_volume_regulator as cr
+    import parity_log
+    name = "std_d16_rand"
+    case = SMALL_CASES[name]
+    cfg, z = case["cfg"], _load(golden_dir, name)
+    inp = synth.make_inputs(cfg, seed=case["seed"], batch=case["batch"], grid_kind=case["grid_kind"],
+                            grid_mask_dtype=case["grid_mask_dtype"])
+    feats = _g(inp["feats"])
+    old_mode, old_min, old_use = H.get_conv_mode(), cr._RS_MIN_UNITS, cr._USE_RS
+    try:
+        H.set_conv_mode("bf16x3")
+        for gain in case["gains"]:
+            w = synth.make_weights(cfg, seed=case["seed"], gain=gain)
+            outs = {}
+            for use in (False, True):
+                cr._USE_RS, cr._RS_MIN_UNITS = use, 0
+                hp = HotPath(cfg, w, inp, device=DEV)
+                outs[use] = hp(feats)[0].cpu().numpy()
+                if use:
+                    assert "_mvsgi_rs_bufs" in hp.cv_regulator.down_blks[0].__dict__      # the chain really ran
+            ref = z[f"inv_dist_g{gain:g}"]
+            err = _rel(outs[True], ref)
+            parity_log.record(name + "(rs)", "bf16x3", gain, err, _l1(outs[True], ref), "golden")
+            assert err <= 1e-3 and _rel(outs[True], outs[False]) <= 2e-4
+    finally:
+        H.set_conv_mode(old_mode)
+        cr._RS_MIN_UNITS, cr._USE_RS = old_min, old_use
+
+
+def test_full_size_batch8_register_stationary_path_vs_reference_golden(golden_dir):
+    """G16V at full size with 8 frames per launch: the batch at which bench.py's path (register-stationary level-0 convs)
+    is active; every frame must reproduce the single-frame reference golden."""
+    import parity_log
+    case = FULL_CASES["full_G16V"]
+    cfg, z = case["cfg"], _load(golden_dir, "full_G16V")
+    inp = synth.make_inputs(cfg, seed=case["seed"], batch=1, grid_kind=case["grid_kind"], grid_mask_dtype=case["grid_mask_dtype"])
+    if synth.digest(inp) != str(z["inputs_sha256"]):
+        pytest.skip("regenerated inputs differ from the golden run's")
+    old = H.get_conv_mode()
+    try:
+        H.set_conv_mode("bf16x3")
+        gain = case["gains"][-1]
+        hp = HotPath(cfg, synth.make_weights(cfg, seed=case["seed"], gain=gain), inp, device=DEV)
+        inv = hp(_g(inp["feats"]).expand(8, -1, -1, -1, -1).contiguous())[0]
+        assert "_mvsgi_rs_bufs" in hp.cv_regulator.down_blks[0].__dict__
+        ref = z[f"inv_dist_g{gain:g}"]
+        got = inv.cpu().numpy()
+        for f in (0, 7):
+            err = _rel(got[f:f + 1], ref)
+            parity_log.record(f"full_G16V(B=8,rs)[{f}]", "bf16x3", gain, err, _l1(got[f:f + 1], ref), "golden")
+            assert err <= 1e-3
+        assert np.array_equal(got[0], got[7])
+    finally:
+        H.set_conv_mode(old)
+        torch.cuda.empty_cache()

@@ -78,8 +78,8 @@ def epilogue_items(k):
         s.append((1, f"t{k}[{e}] = keepB[{k}][{e}] + pt{k}[{e}];"))
     for e in range(4):
         s.append((1, f"t{k}[{e}] = __builtin_fmaf(t{k}[{e}], esc[{j}][{e}], esh[{j}][{e}]);"))
-    s.append((2.0, f"sa{k} = __builtin_amdgcn_permlane16_swap(rres[{k}][0], rres[{k}][2], false, false);"))
-    s.append((2.0, f"sb{k} = __builtin_amdgcn_permlane16_swap(rres[{k}][1], rres[{k}][3], false, false);"))
+    s.append((2.0, f"sa{k} = __builtin_amdgcn_permlane16_swap(rresB[{k}][0], rresB[{k}][2], false, false);"))
+    s.append((2.0, f"sb{k} = __builtin_amdgcn_permlane16_swap(rresB[{k}][1], rresB[{k}][3], false, false);"))
     for e, (src, sh) in enumerate((("sa", True), ("sa", False), ("sb", True), ("sb", False))):
         hi = f"{src}{k}[0] << 16" if sh else f"{src}{k}[0] & 0xffff0000u"
         lo = f"{src}{k}[1] << 16" if sh else f"{src}{k}[1] & 0xffff0000u"
@@ -91,15 +91,16 @@ def epilogue_items(k):
         s.append((1, f"u{k} = t{k}[{e}] * a.neg_slope;"))
         s.append((1, f"t{k}[{e}] = __builtin_fmaxf(t{k}[{e}], u{k});"))
     for p in range(2):
-        s.append((1, f"hb{k}[{p}] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{{t{k}[{2 * p}], t{k}[{2 * p + 1}]}}, bf16x2));"))
-        s.append((1, f"hf{k}[0] = __builtin_bit_cast(float, hb{k}[{p}] << 16);"))
-        s.append((1, f"hf{k}[1] = __builtin_bit_cast(float, hb{k}[{p}] & 0xffff0000u);"))
-        s.append((1, f"hf{k}[0] = t{k}[{2 * p}] - hf{k}[0];"))
-        s.append((1, f"hf{k}[1] = t{k}[{2 * p + 1}] - hf{k}[1];"))
-        s.append((1, f"lb{k}[{p}] = __builtin_bit_cast(unsigned, __builtin_convertvector(hf{k}, bf16x2));"))
-    s.append((2.0, f"sa{k} = __builtin_amdgcn_permlane16_swap(hb{k}[0], lb{k}[0], false, false);"))
-    s.append((2.0, f"sb{k} = __builtin_amdgcn_permlane16_swap(hb{k}[1], lb{k}[1], false, false);"))
-    s.append((2.0, f"__builtin_amdgcn_raw_buffer_store_b128(u32x4{{sa{k}[0], sb{k}[0], sa{k}[1], sb{k}[1]}}, dsc_y, voy[{T}] + {j * 64}, 0, 0);"))
+        s.append((1, f"RS_F_SPL(hb{k}[{p}] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{{t{k}[{2 * p}], t{k}[{2 * p + 1}]}}, bf16x2));)"))
+        s.append((1, f"RS_F_SPL(hf{k}[0] = __builtin_bit_cast(float, hb{k}[{p}] << 16);)"))
+        s.append((1, f"RS_F_SPL(hf{k}[1] = __builtin_bit_cast(float, hb{k}[{p}] & 0xffff0000u);)"))
+        s.append((1, f"RS_F_SPL(hf{k}[0] = t{k}[{2 * p}] - hf{k}[0];)"))
+        s.append((1, f"RS_F_SPL(hf{k}[1] = t{k}[{2 * p + 1}] - hf{k}[1];)"))
+        s.append((1, f"RS_F_SPL(lb{k}[{p}] = __builtin_bit_cast(unsigned, __builtin_convertvector(hf{k}, bf16x2));)"))
+    s.append((2.0, f"RS_F_SPL(sa{k} = __builtin_amdgcn_permlane16_swap(hb{k}[0], lb{k}[0], false, false);)"))
+    s.append((2.0, f"RS_F_SPL(sb{k} = __builtin_amdgcn_permlane16_swap(hb{k}[1], lb{k}[1], false, false);)"))
+    s.append((0.5, f"RS_F_SPL(outp[{k}] = u32x4{{sa{k}[0], sb{k}[0], sa{k}[1], sb{k}[1]}};)"))
+    s.append((0.5, f"RS_F_F32(outp[{k}] = __builtin_bit_cast(u32x4, t{k});)"))
     return [(c, f"RS_F_EPI({st})") for c, st in s]
 
 
@@ -140,13 +141,16 @@ def build(with_pairs: bool):
                     S.put(b * 24 + 3 * r, 1, read_stmt(qn, T, lo))
                     r += 1
     # B. descriptors / masks of this phase (scalar work + a few VALU), early in block 0
-    S.put(1, 0.5, "dsc_y = RS_DESC(a.y, c2, ph >= 2);")
+    S.put(1, 0.5, "if constexpr (OUTF32) dsc_y = RS_DESC_OUT(c2, ph >= 2); else dsc_y = RS_DESC(a.y, c2, ph >= 2);")
     S.put(2, 2.0, "RS_VOY()")
     S.put(4, 0.5, "dsc_x = RS_DESC(a.x, nx, ph + 1 < n);")
     # C. keepB <- keepA while pair 13 runs
     for k in range(4):
         for e in range(4):
             S.place(5, 1, f"keepB[{k}][{e}] = keepA[{k}][{e}];", end=19)
+    for k in range(4):
+        for e in range(4):
+            S.place(5, 1, f"rresB[{k}][{e}] = rres[{k}][{e}];", end=24)
     # D. the accumulators leave the accumulator file (see mfma_order): own accumulators 0..3 rest from slot 12 + a on and
     #    are overwritten at slot 24 + a; the partner's 4..7 rest from slot 16 + a on and are overwritten at slot 28 + a
     for a in range(8):
@@ -181,11 +185,16 @@ def build(with_pairs: bool):
             if cost >= 2.0:
                 s += 1                      # nothing behind a swap / store in its own slot
             last = s
-    # H. residual of the previous brick (consumed by the next phase's epilogue): the youngest VMEM operations of the phase
-    S.put(11 * 24 + 20, 0.5, "dsc_r = RS_DESC(a.res, c1, (int)(a.res != nullptr) & (int)(ph >= 1) & (int)(ph - 1 < n));")
-    s = max(12 * 24, last + 1)
+    # H. residual of the previous brick, consumed by the NEXT phase's epilogue (through rresB): requested early, so that it
+    #    has almost two phases to arrive; the output stores of this phase's epilogue go last and are the 4 youngest
+    #    vector-memory operations at the phase's end (s_waitcnt vmcnt(4) then covers exactly the staging of the next brick)
+    S.put(25, 0.5, "dsc_r = RS_DESC(a.res, c1, (int)(a.res != nullptr) & (int)(ph >= 1) & (int)(ph - 1 < n));")
+    s = 32
     for k in range(4):
-        s = S.place(s, 2.0, f"rres[{k}] = __builtin_amdgcn_raw_buffer_load_b128(dsc_r, voy0[{k >> 1}] + {(k & 1) * 64}, 0, 0);") + 2
+        s = S.place(s, 2.0, f"RS_F_RES(rres[{k}], dsc_r, voy0[{k >> 1}] + {(k & 1) * 64})") + 2
+    s = max(11 * 24, last + 1)
+    for k in range(4):
+        s = S.place(s, 2.0, f"RS_F_EPI(RS_F_STORE(outp[{k}], dsc_y, voy[{k >> 1}] + {(k & 1) * 64}))") + 3
     # I. the read bases move to the other image once their last reads of this phase are out; scratch halves swap
     tg = [(10 * 24 + 1, "rbin[0] ^= BUF1;"), (10 * 24 + 2, "rbin[1] ^= BUF1;")]
     for q in range(4):
