@@ -929,7 +929,7 @@ def test_regulator_register_stationary_chain_matches_streaming_and_goldens(golde
             ref = z[f"inv_dist_g{gain:g}"]
             err = _rel(outs[True], ref)
             parity_log.record(name + "(rs)", "bf16x3", gain, err, _l1(outs[True], ref), "golden")
-            assert err <= 1e-3 and _rel(outs[True], outs[False]) <= 2e-4
+            assert err <= 1e-3 and _rel(outs[True], outs[False]) <= 5e-4      # two 16-bit approximations of the same path
     finally:
         H.set_conv_mode(old_mode)
         cr._RS_MIN_UNITS, cr._USE_RS = old_min, old_use
