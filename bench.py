@@ -334,6 +334,16 @@ def ensure_library(local_rank: int):
     raise SystemExit("bench.py: libmvsgi_hip.so did not appear (build by local rank 0 failed or timed out)")
 
 
+def make_feats(B, shape, rng, dev, torch, np, nchw=False):
+    """[B, N, C, Hi, Wi] synthetic feature maps.  Default: channels-last storage ([B, N, Hi, Wi, C] presented with the
+    reference's shape), which is what the HIP feature extractor in front of this path emits; nchw=True is the reference
+    extractor's contiguous layout, which the sweep transposes once per step (extras.feats_nchw)."""
+    _, N, C, Hi, Wi = shape
+    if nchw:
+        return torch.from_numpy(rng.standard_normal((B, N, C, Hi, Wi), dtype=np.float32)).to(dev)
+    return torch.from_numpy(rng.standard_normal((B, N, Hi, Wi, C), dtype=np.float32)).to(dev).permute(0, 1, 4, 2, 3)
+
+
 def measure_path(cfg, B, mode, steps, warmup, dev, H, HotPath, synth, torch, np, rng, graph=False):
     """frames/s, ms/step and per-conv-kernel attribution of one configuration at one batch size (single process,
     outside the headline's timed region)."""
@@ -341,7 +351,7 @@ def measure_path(cfg, B, mode, steps, warmup, dev, H, HotPath, synth, torch, np,
     H.set_conv_mode(mode)
     inp = synth.make_inputs(cfg, seed=0, batch=1)
     hp = HotPath(cfg, synth.make_weights(cfg, seed=0), inp, device=dev)
-    feats = torch.from_numpy(rng.standard_normal((B, *inp["feats"].shape[1:]), dtype=np.float32)).to(dev)
+    feats = make_feats(B, inp["feats"].shape, rng, dev, torch, np)
 
     def step():
         hp(feats)
@@ -418,7 +428,7 @@ def main(argv=None):
     weights = synth.make_weights(cfg, seed=0)
     hp = HotPath(cfg, weights, inp, device=dev)
     rng = np.random.default_rng(1000 + rank)     # every rank owns different frames
-    feats = torch.from_numpy(rng.standard_normal((B, *inp["feats"].shape[1:]), dtype=np.float32)).to(dev)
+    feats = make_feats(B, inp["feats"].shape, rng, dev, torch, np)
     out = {}
 
     def step():
@@ -455,7 +465,8 @@ def main(argv=None):
         "config": {"workload": f"{cfg.tag}: {cfg.num_cams} cams, D={cfg.num_cands}, builder={cfg.builder}, "
                                f"regulator=({cfg.reg_in_chs},{cfg.reg_f_int_chs}), feats {cfg.feat_hw}, cv {cfg.cv_hw}",
                    "frames_per_gpu_per_step": B, "parallelism": f"frame-sharded x{world} (no collective)",
-                   "rig_constants": "grids / grid_masks / masks resident in HBM; validity byte and packed weights lowered "
+                   "feats_layout": "channels-last storage, as the HIP feature extractor emits (extras.feats_nchw: contiguous NCHW)",
+                   "rig_constants": "grids / grid_masks / masks resident in HBM (one set shared by the batch); validity byte and packed weights lowered "
                                     "once during warm-up (DESIGN.md section 1); extras.rig_cache_off re-samples them every step",
                    "path_gflop_per_frame": round(path_gflop(cfg), 2)},
         "frames_per_sec_per_gpu": round(value / world, 2),
@@ -529,6 +540,13 @@ def run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, 
         return {"frames_per_s": round(B * K / el, 2), "ms_per_step": round(el / K * 1e3, 4),
                 "note": "grid_masks / masks re-sampled inside every step (MVSGI_RIG_CACHE=0 behaviour)"}
     guarded("rig_cache_off", rig_off)
+
+    def nchw():
+        f2 = make_feats(B, (1, cfg.num_cams, cfg.feat_chs, *cfg.feat_hw), rng, dev, torch, np, nchw=True)
+        el = timed_steps(lambda: hp(f2), sync, K, W, 1, False, dev)
+        return {"frames_per_s": round(B * K / el, 2), "ms_per_step": round(el / K * 1e3, 4),
+                "note": "contiguous NCHW feats (the reference extractor's layout): transposed to channels-last once per step"}
+    guarded("feats_nchw", nchw)
 
     def graph():
         hp.capture(feats)

@@ -101,6 +101,11 @@ int mvsgi_sweep_validity_u8(const float* grids, const void* grid_masks, int grid
 int mvsgi_sweep_std_nhwc_valid_f32(const float* feats, const float* grids, const unsigned char* vmask,
                                    float* vol, int B, int N, int C, int Hi, int Wi,
                                    int D, int Ho, int Wo, mvsgi_stream_t stream);
+/* The same with ONE rig for the whole batch: grids [1][N][D][Ho][Wo][2], vmask [1][D][Ho][Wo] (the rig constants are
+ * frame-independent, api/inference_class.py:40-45); feats / vol keep their batch. */
+int mvsgi_sweep_std_nhwc_valid_rig_f32(const float* feats, const float* grids, const unsigned char* vmask,
+                                       float* vol, int B, int N, int C, int Hi, int Wi, int D, int Ho, int Wo,
+                                       mvsgi_stream_t stream);
 
 /* ---- K2: 3x3x3 convolution block -----------------------------------------------------
  * Replaces BaseConvBlk3d.forward (common/common_modules.py:107-115):

@@ -31,6 +31,7 @@ SIGNATURES = {
     "mvsgi_sweep_cat_nhwc_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P]),
     "mvsgi_sweep_validity_u8": (c_int, [_P, _P, c_int, _P, _P] + [c_int] * 7 + [_P]),
     "mvsgi_sweep_std_nhwc_valid_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
+    "mvsgi_sweep_std_nhwc_valid_rig_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
     "mvsgi_conv3d_packed_weight_floats": (c_size_t, [c_int, c_int]),
     "mvsgi_conv3d_pack_weights_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "mvsgi_conv3d_packed_weight_bytes_bf16x3": (c_size_t, [c_int, c_int]),

@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void sweep_std_nhwc_v_kernel(const float* __re
                                                                const float* __restrict__ grids,
                                                                const unsigned char* __restrict__ vmask,
                                                                float* __restrict__ vol, SweepDims s, int dchunk,
-                                                               int nd) {
+                                                               int nd, int rig_shared) {
 #pragma clang fp contract(off)
     static_assert(NCAM <= 4, "one camera per lane of a quad");
     const int q = threadIdx.x & 3;
@@ -426,9 +426,12 @@ __global__ __launch_bounds__(256) void sweep_std_nhwc_v_kernel(const float* __re
             const_cast<float*>(feats + (long long)(b * NCAM + cam) * HWi * s.C), 0, HWi * s.C * 4, 0x00020000);
     // lane q walks camera q's grid (lanes beyond the rig re-read the last camera; unused)
     const int mycam = q < NCAM ? q : NCAM - 1;
-    const float2* gp = reinterpret_cast<const float2*>(grids) + ((long long)(b * NCAM + mycam) * s.D + d0) * HW +
+    // rig_shared: one grid / validity set for the whole batch (the rig constants of api/inference_class.py:40-45 are the
+    // same for every frame): all frames read frame 0's, which then stay in L2 instead of streaming B copies from HBM
+    const int br = rig_shared ? 0 : b;
+    const float2* gp = reinterpret_cast<const float2*>(grids) + ((long long)(br * NCAM + mycam) * s.D + d0) * HW +
                        (long long)ho * s.Wo + wo;
-    const unsigned char* vp = vmask + ((long long)b * s.D + d0) * HW + (long long)ho * s.Wo + wo;
+    const unsigned char* vp = vmask + ((long long)br * s.D + d0) * HW + (long long)ho * s.Wo + wo;
     float* out = vol + ((((long long)b * s.D + d0) * s.Ho + ho) * s.Wo + wo) * s.C;
     const long long vstep = HW * s.C;
     // one candidate: grid point -> taps (lane q = camera q, broadcast through the quad) -> 4 x NCAM
@@ -646,9 +649,9 @@ extern "C" int mvsgi_sweep_validity_u8(const float* grids, const void* grid_mask
 
 // SphericalSweepStdMasked.sweep with the validity byte of mvsgi_sweep_validity_u8 in place of
 // grid_masks / masks: feats [B][N][Hi][Wi][C] -> vol [B][D][Ho][Wo][C]; identical output.
-extern "C" int mvsgi_sweep_std_nhwc_valid_f32(const float* feats, const float* grids, const unsigned char* vmask,
-                                              float* vol, int B, int N, int C, int Hi, int Wi, int D, int Ho, int Wo,
-                                              mvsgi_stream_t stream) {
+namespace {
+int sweep_std_nhwc_valid_impl(const float* feats, const float* grids, const unsigned char* vmask, float* vol, int B, int N, int C,
+                              int Hi, int Wi, int D, int Ho, int Wo, int rig_shared, mvsgi_stream_t stream) {
     SweepDims s{B, N, C, Hi, Wi, 1, 1, D, Ho, Wo};
     if (check_dims(s, "mvsgi_sweep_std_nhwc_valid_f32")) return 1;
     MVSGI_REQUIRE(feats && grids && vmask && vol, "mvsgi_sweep_std_nhwc_valid_f32: null pointer");
@@ -667,10 +670,25 @@ extern "C" int mvsgi_sweep_std_nhwc_valid_f32(const float* feats, const float* g
     const dim3 grid((unsigned)nblk), block(256);
     hipStream_t st = mvsgi::as_stream(stream);
     switch (N) {
-        case 1: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd); break;
-        case 2: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<2>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd); break;
-        case 3: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<3>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd); break;
-        case 4: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<4>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd); break;
+        case 1: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared); break;
+        case 2: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<2>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared); break;
+        case 3: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<3>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared); break;
+        case 4: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<4>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared); break;
     }
     return mvsgi::check_launch("mvsgi_sweep_std_nhwc_valid_f32");
+}
+}  // namespace
+
+extern "C" int mvsgi_sweep_std_nhwc_valid_f32(const float* feats, const float* grids, const unsigned char* vmask,
+                                              float* vol, int B, int N, int C, int Hi, int Wi, int D, int Ho, int Wo,
+                                              mvsgi_stream_t stream) {
+    return sweep_std_nhwc_valid_impl(feats, grids, vmask, vol, B, N, C, Hi, Wi, D, Ho, Wo, 0, stream);
+}
+
+// The same with ONE rig for the whole batch: grids [1][N][D][Ho][Wo][2], vmask [1][D][Ho][Wo] (frame-independent rig
+// constants, api/inference_class.py:40-45), feats / vol still [B]...
+extern "C" int mvsgi_sweep_std_nhwc_valid_rig_f32(const float* feats, const float* grids, const unsigned char* vmask,
+                                                  float* vol, int B, int N, int C, int Hi, int Wi, int D, int Ho, int Wo,
+                                                  mvsgi_stream_t stream) {
+    return sweep_std_nhwc_valid_impl(feats, grids, vmask, vol, B, N, C, Hi, Wi, D, Ho, Wo, 1, stream);
 }

@@ -20,7 +20,7 @@ from . import common_modules as cm
 from .common_modules import NORM3D_TYPE, RELU_TYPE
 
 
-_RIG_VALIDITY = weakref.WeakKeyDictionary()      # module -> ((grids, grid_masks, masks), versions, vmask)
+_RIG_VALIDITY = weakref.WeakKeyDictionary()      # module -> ((grids, grid_masks, masks), versions, vmask, shared grids | None)
 _RIG_CACHE_ENV = os.environ.get("MVSGI_RIG_CACHE", "1") != "0"
 
 
@@ -59,12 +59,18 @@ def std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=None) -> Tensor:
         and H.nhwc_sweep_ok(feats) and grids.is_cuda
     if not use_cache:
         return H.sweep_std(feats, grids, grid_masks, masks)
-    tensors = (grids, grid_masks, masks)
+    tensors = (grids, grid_masks, masks)               # identity of what the caller passed
     cached = _RIG_VALIDITY.get(owner)
     if not _rig_hit(cached, tensors):
-        cached = (tensors, tuple(t._version for t in tensors), H.sweep_validity(grids, grid_masks, masks))
+        # a batch-broadcast view (stride 0 along the batch, e.g. `grids[:1].expand(B, ...)`) is ONE rig for every frame:
+        # the kernel then reads frame 0's constants for all frames (they stay in L2) instead of B copies from HBM
+        if all(t.dim() > 0 and t.shape[0] > 1 and t.stride(0) == 0 for t in tensors):
+            g1, gm1, m1 = (t[:1].contiguous() for t in tensors)
+        else:
+            g1, gm1, m1 = grids, grid_masks, masks
+        cached = (tensors, tuple(t._version for t in tensors), H.sweep_validity(g1, gm1, m1), g1 if g1 is not grids else None)
         _RIG_VALIDITY[owner] = cached            # weak on the module: dies with it, never pickled with it
-    return H.sweep_std_valid(feats, grids, cached[2])
+    return H.sweep_std_valid(feats, cached[3] if cached[3] is not None else grids, cached[2])
 
 
 def cat_sweep_ndhwc(feats, grids) -> Tensor:

@@ -100,7 +100,8 @@ def sweep_validity(grids, grid_masks, masks) -> torch.Tensor:
 
 
 def sweep_std_valid(feats, grids, vmask) -> torch.Tensor:
-    """sweep_std with the cached validity byte (channels-last kernel only) -> vol_raw [B, D, Ho, Wo, C]."""
+    """sweep_std with the cached validity byte (channels-last kernel only) -> vol_raw [B, D, Ho, Wo, C].
+    grids / vmask with batch 1 against feats with batch B > 1 = one rig shared by the whole batch."""
     lib = _lib.load()
     if not nhwc_sweep_ok(feats):
         raise AssertionError(f"sweep_std_valid needs C % 4 == 0 and N <= 4, got feats {tuple(feats.shape)}")
@@ -109,13 +110,13 @@ def sweep_std_valid(feats, grids, vmask) -> torch.Tensor:
     grids = _dev(grids, "grids")
     vmask = _dev(vmask, "vmask", torch.uint8)
     Bg, Ng, D, Ho, Wo, two = grids.shape
-    if (Bg, Ng, two) != (B, N, 2):
+    if (Ng, two) != (N, 2) or Bg not in (1, B):
         raise AssertionError(f"grids {tuple(grids.shape)} do not match feats {tuple(feats.shape)}")
-    if tuple(vmask.shape) != (B, D, Ho, Wo):
+    if tuple(vmask.shape) != (Bg, D, Ho, Wo):
         raise AssertionError(f"vmask {tuple(vmask.shape)} does not match grids {tuple(grids.shape)}")
     vol = torch.empty((B, D, Ho, Wo, C), device=f.device, dtype=torch.float32)
-    _lib.check(lib.mvsgi_sweep_std_nhwc_valid_f32(f.data_ptr(), grids.data_ptr(), vmask.data_ptr(), vol.data_ptr(),
-                                                  B, N, C, Hi, Wi, D, Ho, Wo, _stream_ptr(f)),
+    fn = lib.mvsgi_sweep_std_nhwc_valid_rig_f32 if (Bg == 1 and B > 1) else lib.mvsgi_sweep_std_nhwc_valid_f32
+    _lib.check(fn(f.data_ptr(), grids.data_ptr(), vmask.data_ptr(), vol.data_ptr(), B, N, C, Hi, Wi, D, Ho, Wo, _stream_ptr(f)),
                "mvsgi_sweep_std_nhwc_valid_f32")
     return vol
 

@@ -47,11 +47,14 @@ class HotPath:
     def __call__(self, feats: torch.Tensor):
         B = feats.shape[0]
         g, gm, m = self.grids, self.grid_masks, self.masks
-        if g.shape[0] != B:          # rig constants are per-frame identical: replicate for a batch
-            g = g[:1].expand(B, *g.shape[1:]).contiguous()
-            gm = gm[:1].expand(B, *gm.shape[1:]).contiguous()
-            m = m[:1].expand(B, *m.shape[1:]).contiguous()
-            self.grids, self.grid_masks, self.masks = g, gm, m
+        if g.shape[0] != B:          # rig constants are per-frame identical
+            shared = self.cfg.builder == "std" and bool(getattr(self.cv_builder, "cache_rig_constants", True))
+            if getattr(self, "_rig_views", None) is None or self._rig_views[0] != (B, shared):
+                exp = [t[:1].expand(B, *t.shape[1:]) for t in (g, gm, m)]
+                # std builder with the rig cache: ONE set presented with the batch's shape (stride-0 views; the sweep reads
+                # frame 0's constants for every frame).  Otherwise replicated once.
+                self._rig_views = ((B, shared), *(exp if shared else [t.contiguous() for t in exp]))
+            _, g, gm, m = self._rig_views          # the same objects every call: the rig cache hits by identity
         vol = self.cv_builder(feats, g, gm, m)
         costs = self.cv_regulator(vol)
         return self.dist_regressor(costs)
