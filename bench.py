@@ -216,7 +216,7 @@ def read_pmc_traffic(kernel_name: str):
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         d = json.load(open(p))
-        v = d.get(kernel_name, {}).get("hbm_bytes_per_launch")
+        v = d.get(kernel_name.split(" [")[0], {}).get("hbm_bytes_per_launch")
         return v, (f"profiles/pmc_traffic.json ({d.get('_source', 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE')})"
                    if v is not None else None)
     except Exception:
