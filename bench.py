@@ -128,6 +128,7 @@ class ConvProbe:
         self.orig = H.conv3d
         self.orig_up2 = H.conv3d_up2
         self.orig_rs = H.conv3d_rs
+        self.orig_rs16 = H.conv3d_rs16
         self.orig_os = H.conv3d_out_split
         self.records = []
         self.enabled = False
@@ -185,8 +186,19 @@ class ConvProbe:
                                  2.0 * 27 * Cin * Cout * out.B * out.D * out.H * out.W, s, e))
             return y
 
+        def probed_rs16(x, w_packed_rs, scale, shift, neg_slope=0.01, out=None):
+            if not self.enabled:
+                return self.orig_rs16(x, w_packed_rs, scale, shift, neg_slope, out)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = self.orig_rs16(x, w_packed_rs, scale, shift, neg_slope, out)
+            e.record()
+            self.records.append(("conv3d_rs16_kernel", 2.0 * 27 * 16 * 16 * x.B * x.D * x.H * x.W, s, e))
+            return y
+
         H.conv3d = probed
         H.conv3d_up2 = probed_up2
+        H.conv3d_rs16 = probed_rs16
         H.conv3d_rs = probed_rs
         H.conv3d_out_split = probed_os
         return self
@@ -195,6 +207,7 @@ class ConvProbe:
         self.H.conv3d = self.orig
         self.H.conv3d_up2 = self.orig_up2
         self.H.conv3d_rs = self.orig_rs
+        self.H.conv3d_rs16 = self.orig_rs16
         self.H.conv3d_out_split = self.orig_os
 
     def summary(self):

@@ -244,6 +244,11 @@ int mvsgi_deform_conv2d_f32(const float* x, const float* offset, int offset_per_
                             int N, int Cin, int H, int W, int Cout, int Kh, int Kw, int stride_h, int stride_w,
                             int pad_h, int pad_w, int dil_h, int dil_w, float neg_slope, mvsgi_stream_t stream);
 
+/* mvsgi_sweep_std_nhwc_valid_f32 with the volume written split-padded (C == 16; see below), rig_batch in {1, B} */
+int mvsgi_sweep_std_nhwc_valid_split(const float* feats, const float* grids, const unsigned char* vmask,
+                                     void* vol_split, int B, int N, int C, int Hi, int Wi, int D, int Ho, int Wo,
+                                     int rig_batch, mvsgi_stream_t stream);
+
 /* ---- split-padded activations and the register-stationary conv (csrc/conv3d_rs.hip) ----------------------
  * Split-padded format of a channels-last activation tensor:  [B][D+2][H+2][W+2][C/16][4][8] bf16, where a voxel's
  * 16-channel slice is [hi(c 0-7) | hi(c 8-15) | lo(c 0-7) | lo(c 8-15)], x = hi + lo (hi = bf16(x), lo = bf16(x - hi));
@@ -261,6 +266,10 @@ int mvsgi_deform_conv2d_f32(const float* x, const float* offset, int offset_per_
 int mvsgi_conv3d_f32_out_split(const float* x, const float* w_packed_b3, const float* scale, const float* shift,
                                const float* res, void* y_split, int B, int Cin, int Din, int Hin, int Win, int Cout,
                                int stride, float neg_slope, mvsgi_stream_t stream);   /* mvsgi_conv3d_f32 (MVSGI_CONV_BF16X3) writing a split-padded y */
+/* post_vol (Cin = Cout = 16, stride 1, no residual) on a split-padded volume, fp32 [B][D][H][W][16] out; weights from
+ * mvsgi_conv3d_rs_pack_weights(16, 16) */
+int mvsgi_conv3d_rs16_split(const void* x_split, const void* w_packed_rs, const float* scale, const float* shift, float* y,
+                            int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream);
 size_t mvsgi_conv3d_rs_packed_weight_bytes(int Cout, int Cin);
 int mvsgi_conv3d_rs_pack_weights(const float* w_oidhw, void* w_packed, int Cout, int Cin, mvsgi_stream_t stream);
 size_t mvsgi_act_split_bytes(int B, int C, int D, int H, int W);

@@ -31,6 +31,7 @@ SIGNATURES = {
     "mvsgi_sweep_cat_nhwc_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P]),
     "mvsgi_sweep_validity_u8": (c_int, [_P, _P, c_int, _P, _P] + [c_int] * 7 + [_P]),
     "mvsgi_sweep_std_nhwc_valid_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
+    "mvsgi_sweep_std_nhwc_valid_split": (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P]),
     "mvsgi_sweep_std_nhwc_valid_rig_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
     "mvsgi_conv3d_packed_weight_floats": (c_size_t, [c_int, c_int]),
     "mvsgi_conv3d_pack_weights_f32": (c_int, [_P, _P, c_int, c_int, _P]),
@@ -65,6 +66,7 @@ SIGNATURES = {
     "mvsgi_act_f32_to_split": (c_int, [_P, _P] + [c_int] * 5 + [_P]),
     "mvsgi_act_split_to_f32": (c_int, [_P, _P] + [c_int] * 5 + [_P]),
     "mvsgi_conv3d_f32_out_split": (c_int, [_P] * 6 + [c_int] * 7 + [c_float, _P]),
+    "mvsgi_conv3d_rs16_split": (c_int, [_P] * 5 + [c_int] * 4 + [c_float, _P]),
     "mvsgi_conv3d_rs_packed_weight_bytes": (c_size_t, [c_int, c_int]),
     "mvsgi_conv3d_rs_pack_weights": (c_int, [_P, _P, c_int, c_int, _P]),
     "mvsgi_conv3d_rs_split": (c_int, [_P] * 6 + [c_int] * 7 + [c_float, _P]),

@@ -323,7 +323,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 // v_accvgpr_read every brick.  hipcc pads no hazards around asm: the schedule keeps >= 3 MFMAs between an accumulator's
 // last MFMA and its first read, and nothing else reads or writes MFMA operands.
 #define RS_MF(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "a"(WREG), "v"(XREG));
-#define RS_MF0(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(ACC) : "a"(WREG), "v"(XREG));
+// first MFMA of a brick on an accumulator: C = 0.  Declared read-write all the same ("+a"): a fresh definition would let the
+// allocator move the accumulator to other registers and reconcile with v_accvgpr_mov at the loop's back edge -- directly in
+// front of asm MFMAs whose hazards it cannot pad
+#define RS_MF0(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG));
 
 // diagnostic builds only: MVSGI_RS_ABL bit 1 drops the fragment reads, 2 the epilogue, 4 the LDS-DMA (results are wrong)
 #ifndef MVSGI_RS_ABL
@@ -354,6 +357,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 #else
 #define RS_F_RES(R, D, O) R = __builtin_amdgcn_raw_buffer_load_b128(D, O, 0, 0);
 #endif
+// 64 idle cycles: the last MFMAs' results must have landed before compiler-generated code reads the accumulators
+#define RS_HAZARD_WAIT() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 #ifdef MVSGI_RS_STAMPS   // diagnostic build (tools/rs_stamps.py): s_memtime stamps of workgroup 8, every wave
     int nst = 0;
 #define STAMP()                                                                                     \
@@ -443,6 +448,220 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 #undef RS_STEP
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// the 16 -> 16 kernel (post_vol: spherical_sweep_avg.py:30-36,165): split-padded volume in, plain fp32 out
+// ---------------------------------------------------------------------------------------------
+struct Rs16Args {
+    const unsigned char* x;    // split-padded [B][D+2][H+2][W+2][16] (64 B per voxel)
+    unsigned char* y;          // fp32 [B][D][H][W][16]
+    const bf16x8* wp;          // mvsgi_conv3d_rs_pack_weights(16, 16): [5 in-plane pairs][3 kd][hi|lo][64 lanes]
+    const float* scale;
+    const float* shift;
+    int B, D, H, W;
+    float neg_slope;
+    int tiles_d, tiles_h, tiles_w, total_units;
+};
+
+namespace rs16 {
+constexpr int TD = 4, TH = 4, TW = 16;        // brick: 256 output voxels; a wave owns one h-row and its 4 planes
+constexpr int ITD = TD + 2, ITH = TH + 2, ITW = TW + 2;
+// LDS image: voxel v = d * PL + h * ROW + w; HI region (32 B per voxel: the two 8-channel halves) then LO region; chunk
+// `half` of voxel (d, h, w) sits in slot half ^ ((w >> 3) & 1).  A ds_read_b128 lane group (8 lanes on one tap, 8 on its
+// pair partner) then covers 16 distinct 16-byte units for in-row pairs (kw 0 | 1) and for the kw = 2 taps of adjacent rows
+// (ROW = 24: a row is 48 units = 0 mod 16).
+constexpr int ROW = 24, PL = ITH * ROW;       // 144
+constexpr int NV = ITD * PL;                  // 864 voxels = 27 pieces per region
+constexpr int REGION = NV * 32;               // 27,648
+constexpr int IMG = 2 * REGION;               // 55,296
+constexpr int BUF1 = 65536;
+constexpr int NDMA = IMG / 1024;              // 54 pieces per image: 14 per wave, the last two of waves 2, 3 are dummies
+constexpr int DPW = 14;
+constexpr int LDS_BYTES = BUF1 + DPW * 4 * 1024;   // 122,880: the dummy pieces (zero-filled) land behind the image
+static_assert(ROW % 8 == 0 && NV % 32 == 0 && BUF1 >= DPW * 4 * 1024, "image geometry");
+// in-plane tap of pair pp for lane half `second`: (kh, kw) or none
+__host__ __device__ constexpr int pair_kh(int pp, int second) { return pp < 3 ? pp : (pp == 3 ? second : (second ? -1 : 2)); }
+__host__ __device__ constexpr int pair_kw(int pp, int second) { return pp < 3 ? second : 2; }
+}  // namespace rs16
+
+// [16][16][27] -> [5 pairs][3 kd][hi|lo][64 lanes][8 bf16]: lane (kg << 4) | i holds W[cout i][cin (kg>>1)*8 + j][kd][in-plane tap]
+__global__ void rs16_pack_weights_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 5 * 3 * 64) return;
+    const int lane = idx & 63, r = idx >> 6;
+    const int kd = r % 3, pp = r / 3;
+    const int kg = lane >> 4, co = lane & 15, ci = (kg >> 1) * 8;
+    const int kh = rs16::pair_kh(pp, kg & 1), kw = rs16::pair_kw(pp, kg & 1);
+    bf16x8 hi, lo;
+    for (int j = 0; j < 8; ++j) {
+        const float v = kh >= 0 ? w[((long long)co * 16 + ci + j) * 27 + kd * 9 + kh * 3 + kw] : 0.f;
+        const __bf16 h = (__bf16)v;
+        hi[j] = h;
+        lo[j] = (__bf16)(v - (float)h);
+    }
+    const int o = ((pp * 3 + kd) * 2) * 64 + lane;
+    wp[o] = hi;
+    wp[o + 64] = lo;
+}
+
+__global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
+    using namespace rs16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = the brick's h-row of this wave
+    const int col = lane & 15, kg = lane >> 4;
+    const bool second = kg & 1;
+    const int half = kg >> 1;
+    const int Hp = a.H + 2, Wp = a.W + 2;
+    const long long frame_bytes = (long long)(a.D + 2) * Hp * Wp * 64;
+    const long long total_bytes = frame_bytes * a.B;
+    const long long oframe = (long long)a.D * a.H * a.W * 64, ototal = oframe * a.B;
+
+    bf16x8 pwh[5][3], pwl[5][3];
+#pragma unroll
+    for (int pp = 0; pp < 5; ++pp)
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const bf16x8* q = a.wp + ((pp * 3 + kd) * 2) * 64 + lane;
+            pwh[pp][kd] = q[0];
+            pwl[pp][kd] = q[64];
+        }
+#pragma unroll
+    for (int pp = 0; pp < 5; ++pp)
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) asm volatile("" : "+a"(pwh[pp][kd]), "+a"(pwl[pp][kd]));
+    __builtin_amdgcn_sched_barrier(0);
+
+    // fragment read bases (image 0, HI region, input plane 0, tap row 0): in-row pairs / the kw = 2 pair of rows 0, 1 / row 2
+    const int w_in = col + (second ? 1 : 0), w_2 = col + 2;
+    int b_in = (wave * ROW + w_in) * 32 + ((half ^ ((w_in >> 3) & 1)) << 4);
+    int b_2a = (wave * ROW + w_2 + (second ? ROW : 0)) * 32 + ((half ^ ((w_2 >> 3) & 1)) << 4);
+    int b_2b = (wave * ROW + w_2) * 32 + ((half ^ ((w_2 >> 3) & 1)) << 4);
+    // DMA plan: piece i = wave + 4 m fills LDS bytes [i * 1024, +1024): 32 voxels x 2 chunks
+    unsigned voff[DPW];
+#pragma unroll
+    for (int m = 0; m < DPW; ++m) {
+        const int i = wave + 4 * m;
+        const int region = i >= NDMA / 2 ? 1 : 0, jj = i - region * (NDMA / 2);
+        const int v = 32 * jj + (lane >> 1), slot = lane & 1;
+        const int d = v / PL, r = v - d * PL;
+        const int h = r / ROW, w = r - h * ROW;
+        const int c = slot ^ ((w >> 3) & 1);
+        voff[m] = (i < NDMA && w < ITW) ? (unsigned)(((d * Hp + h) * Wp + w) * 64 + region * 32 + c * 16) : 0xffffff00u;
+    }
+    const f32x4 esc = *reinterpret_cast<const f32x4*>(a.scale + kg * 4), esh = *reinterpret_cast<const f32x4*>(a.shift + kg * 4);
+    unsigned voy0[4];      // this lane's 16 B (couts 4 kg .. 4 kg + 3) of its row's voxel in output plane o
+#pragma unroll
+    for (int o = 0; o < 4; ++o) voy0[o] = (unsigned)(((o * a.H + wave) * a.W + col) * 64 + kg * 16);
+
+    const int total = a.total_units, G = gridDim.x;
+    const int n = (total - (int)blockIdx.x + G - 1) / G;
+    const int id0 = rs_xcd_remap((int)blockIdx.x, total);
+    const int step = G == total ? 0 : G >> 3;
+    const int sw = step % a.tiles_w;
+    int tq = step / a.tiles_w;
+    const int sh_ = tq % a.tiles_h;
+    tq /= a.tiles_h;
+    const int sd = tq % a.tiles_d, sb = tq / a.tiles_d;
+    RsUnit c1{0, 0, 0, 0}, c0, nx;
+    {
+        int t_ = id0;
+        c0.ow = t_ % a.tiles_w;
+        t_ /= a.tiles_w;
+        c0.oh = t_ % a.tiles_h;
+        t_ /= a.tiles_h;
+        c0.od = t_ % a.tiles_d;
+        c0.b = t_ / a.tiles_d;
+    }
+#define RS16_STEP(DST, SRC)                                                    \
+    {                                                                          \
+        int w_ = SRC.ow + sw, c_ = w_ >= a.tiles_w;                            \
+        DST.ow = w_ - (c_ ? a.tiles_w : 0);                                    \
+        int h_ = SRC.oh + sh_ + c_;                                            \
+        c_ = h_ >= a.tiles_h;                                                  \
+        DST.oh = h_ - (c_ ? a.tiles_h : 0);                                    \
+        int d_ = SRC.od + sd + c_;                                             \
+        c_ = d_ >= a.tiles_d;                                                  \
+        DST.od = d_ - (c_ ? a.tiles_d : 0);                                    \
+        DST.b = SRC.b + sb + c_;                                               \
+    }
+    RS16_STEP(nx, c0)
+#define RS16_DESC(U, VALID)                                                                                      \
+    ({                                                                                                           \
+        const long long off_ = (long long)(U).b * frame_bytes +                                                  \
+                               ((long long)((U).od * TD * Hp + (U).oh * TH) * Wp + (U).ow * TW) * 64;            \
+        const long long left_ = total_bytes - off_;                                                              \
+        const int rec_ = left_ > 0x7fffff00ll ? 0x7fffff00 : (int)left_;                                         \
+        const int ok_ = (int)(VALID) & (int)(left_ > 0);                                                         \
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.x) + off_, 0, ok_ ? rec_ : 0, 0x00020000); \
+    })
+#define RS16_DESC_OUT(U, VALID)                                                                                  \
+    ({                                                                                                           \
+        const long long off_ = (long long)(U).b * oframe + ((long long)((U).od * TD * a.H + (U).oh * TH) * a.W + (U).ow * TW) * 64; \
+        const long long left_ = ototal - off_;                                                                   \
+        const int rec_ = left_ > 0x7fffff00ll ? 0x7fffff00 : (int)left_;                                         \
+        const int ok_ = (int)(VALID) & (int)(left_ > 0);                                                         \
+        __builtin_amdgcn_make_buffer_rsrc(a.y + off_, 0, ok_ ? rec_ : 0, 0x00020000);                            \
+    })
+#define RS16_DMA(M)                                                                                              \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(dsc_x, (__attribute__((address_space(3))) void*)(lds + nxt_img + (wave + 4 * (M)) * 1024), \
+                                             16, voff[M], 0, 0, 0);
+#define RS16_VOY()                                                                                               \
+    {                                                                                                            \
+        const int hok_ = c1.oh * TH + wave < a.H;                                                                \
+        _Pragma("unroll") for (int o = 0; o < 4; ++o)                                                            \
+            voy[o] = (hok_ & (int)(c1.od * TD + o < a.D) & (int)(c1.ow * TW + col < a.W)) ? voy0[o] : 0xffffff00u; \
+    }
+#define RS_MF(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "a"(WREG), "v"(XREG));
+// first MFMA of a brick on an accumulator: C = 0.  Declared read-write all the same ("+a"): a fresh definition would let the
+// allocator move the accumulator to other registers and reconcile with v_accvgpr_mov at the loop's back edge -- directly in
+// front of asm MFMAs whose hazards it cannot pad
+#define RS_MF0(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG));
+#define RS_PIN_V(V) asm volatile("" : "+v"(V));
+#define RS_F_STORE16(V, D, O) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, V), D, O, 0, 0);
+
+    __amdgpu_buffer_rsrc_t dsc_x, dsc_y;
+    unsigned voy[4] = {0xffffff00u, 0xffffff00u, 0xffffff00u, 0xffffff00u};
+    dsc_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, 0, 0x00020000);
+    {   // prologue: image 0 <- brick 0
+        dsc_x = RS16_DESC(c0, 1);
+        const int nxt_img = 0;
+#pragma unroll
+        for (int m = 0; m < DPW; ++m) RS16_DMA(m)
+    }
+    f32x4 acc[4], fin[4];
+    bf16x8 xh[3][2], xl[3][2];
+    float u0, u1, u2, u3;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) acc[o] = fin[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) xh[g][q] = xl[g][q] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // phase ph = [groups 13, 14 of brick ph - 1, hand-over, its epilogue] [groups 0 .. 12 of brick ph, staging of brick ph + 1]
+    int ph = 0;
+    for (; ph < n; ++ph) {
+        const int nxt_img = (ph & 1) ? 0 : BUF1;
+#include "conv3d_rs16_phase_main.inc"
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    {
+#include "conv3d_rs16_phase_drain.inc"
+    }
+#undef RS16_STEP
+#undef RS16_DESC
+#undef RS16_DESC_OUT
+#undef RS16_DMA
+#undef RS16_VOY
+#undef RS_MF
+#undef RS_MF0
+#undef RS_PIN_V
+#undef RS_F_STORE16
+}
+
 }  // namespace
 
 extern "C" size_t mvsgi_act_split_bytes(int B, int C, int D, int H, int W) {
@@ -470,12 +689,18 @@ extern "C" int mvsgi_act_split_to_f32(const void* x, float* y, int B, int C, int
 }
 
 extern "C" size_t mvsgi_conv3d_rs_packed_weight_bytes(int Cout, int Cin) {
+    if (Cout == 16 && Cin == 16) return (size_t)5 * 3 * 2 * 64 * 16;
     return Cout == 32 && Cin == 32 ? (size_t)2 * 2 * rs::kPairs * 2 * 64 * 16 : 0;
 }
 
 extern "C" int mvsgi_conv3d_rs_pack_weights(const float* w_oidhw, void* w_packed, int Cout, int Cin, mvsgi_stream_t stream) {
     MVSGI_REQUIRE(w_oidhw && w_packed, "mvsgi_conv3d_rs_pack_weights: null pointer");
-    MVSGI_REQUIRE(Cout == 32 && Cin == 32, "mvsgi_conv3d_rs_pack_weights: only 32 -> 32 channels (got %d -> %d)", Cin, Cout);
+    if (Cout == 16 && Cin == 16) {
+        hipLaunchKernelGGL(rs16_pack_weights_kernel, dim3((5 * 3 * 64 + 255) / 256), dim3(256), 0, mvsgi::as_stream(stream), w_oidhw,
+                           static_cast<bf16x8*>(w_packed));
+        return mvsgi::check_launch("mvsgi_conv3d_rs_pack_weights");
+    }
+    MVSGI_REQUIRE(Cout == 32 && Cin == 32, "mvsgi_conv3d_rs_pack_weights: only 32 -> 32 and 16 -> 16 channels (got %d -> %d)", Cin, Cout);
     hipLaunchKernelGGL(rs_pack_weights_kernel, dim3((2 * 2 * rs::kPairs * 64 + 255) / 256), dim3(256), 0, mvsgi::as_stream(stream),
                        w_oidhw, static_cast<bf16x8*>(w_packed));
     return mvsgi::check_launch("mvsgi_conv3d_rs_pack_weights");
@@ -531,4 +756,35 @@ extern "C" int mvsgi_conv3d_rs_split(const void* x, const void* w_packed_rs, con
     hipLaunchKernelGGL(kern, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), rs::LDS_BYTES,
                        mvsgi::as_stream(stream), a);
     return mvsgi::check_launch("mvsgi_conv3d_rs_split");
+}
+
+// BaseConvBlk3d.forward for Cin = Cout = 16, stride 1, no residual (post_vol, spherical_sweep_avg.py:30-36,165) on a
+// split-padded input, fp32 [B][D][H][W][16] output; w_packed_rs from mvsgi_conv3d_rs_pack_weights(16, 16).
+extern "C" int mvsgi_conv3d_rs16_split(const void* x, const void* w_packed_rs, const float* scale, const float* shift, float* y,
+                                       int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(x && y && w_packed_rs && scale && shift, "mvsgi_conv3d_rs16_split: null pointer");
+    MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_conv3d_rs16_split: bad dims");
+    MVSGI_REQUIRE(neg_slope >= 0.f && neg_slope <= 1.f, "mvsgi_conv3d_rs16_split: neg_slope %g not in [0, 1]", (double)neg_slope);
+    MVSGI_REQUIRE((long long)(D + 2) * (H + 2) * (W + 2) * 64 < (1ll << 31), "mvsgi_conv3d_rs16_split: frame too large for 32-bit offsets");
+    Rs16Args a{};
+    a.x = static_cast<const unsigned char*>(x);
+    a.y = reinterpret_cast<unsigned char*>(y);
+    a.wp = static_cast<const bf16x8*>(w_packed_rs);
+    a.scale = scale;
+    a.shift = shift;
+    a.B = B; a.D = D; a.H = H; a.W = W;
+    a.neg_slope = neg_slope;
+    a.tiles_d = (int)mvsgi::cdiv(D, rs16::TD);
+    a.tiles_h = (int)mvsgi::cdiv(H, rs16::TH);
+    a.tiles_w = (int)mvsgi::cdiv(W, rs16::TW);
+    const long long nb = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
+    MVSGI_REQUIRE(nb < (1ll << 31), "mvsgi_conv3d_rs16_split: too many units");
+    a.total_units = (int)nb;
+    static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
+    mvsgi::PersistentGeom geo;
+    if (mvsgi::persistent_geometry(conv3d_rs16_kernel, 256, rs16::LDS_BYTES, 1, geo_cache, "mvsgi_conv3d_rs16_split", geo)) return 1;
+    const long long resident = (long long)geo.cus / 8 * 8 > 0 ? (long long)geo.cus / 8 * 8 : 8;
+    hipLaunchKernelGGL(conv3d_rs16_kernel, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), rs16::LDS_BYTES,
+                       mvsgi::as_stream(stream), a);
+    return mvsgi::check_launch("mvsgi_conv3d_rs16_split");
 }

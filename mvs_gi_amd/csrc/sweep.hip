@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void sweep_std_nhwc_v_kernel(const float* __re
                                                                const float* __restrict__ grids,
                                                                const unsigned char* __restrict__ vmask,
                                                                float* __restrict__ vol, SweepDims s, int dchunk,
-                                                               int nd, int rig_shared) {
+                                                               int nd, int rig_shared, unsigned char* __restrict__ vol_split) {
 #pragma clang fp contract(off)
     static_assert(NCAM <= 4, "one camera per lane of a quad");
     const int q = threadIdx.x & 3;
@@ -434,9 +434,15 @@ __global__ __launch_bounds__(256) void sweep_std_nhwc_v_kernel(const float* __re
     const unsigned char* vp = vmask + ((long long)br * s.D + d0) * HW + (long long)ho * s.Wo + wo;
     float* out = vol + ((((long long)b * s.D + d0) * s.Ho + ho) * s.Wo + wo) * s.C;
     const long long vstep = HW * s.C;
+    // vol_split (C == 16): the volume goes out in the split-padded format of conv3d_rs.hip instead -- [B][D+2][Ho+2][Wo+2]
+    // records of 64 B = [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15]; lane q's 4 channels are 8 B of hi and 8 B of lo
+    unsigned char* outs = vol_split ? vol_split + ((((long long)b * (s.D + 2) + d0 + 1) * (s.Ho + 2) + ho + 1) * (s.Wo + 2) + wo + 1) * 64 +
+                                          (q >> 1) * 16 + (q & 1) * 8
+                                    : nullptr;
+    const long long sstep = (long long)(s.Ho + 2) * (s.Wo + 2) * 64;
     // one candidate: grid point -> taps (lane q = camera q, broadcast through the quad) -> 4 x NCAM
     // texel gathers -> masked variance
-    auto candidate = [&](const float2 gxy, const unsigned vm, float* __restrict__ o) {
+    auto candidate = [&](const float2 gxy, const unsigned vm, float* __restrict__ o, unsigned char* __restrict__ os) {
         const Bilin mine = bilin_setup(gxy.x, gxy.y, s.Wi, s.Hi);
         Bilin ft[NCAM];
         ft[0] = quad_bcast<0>(mine);
@@ -475,7 +481,24 @@ __global__ __launch_bounds__(256) void sweep_std_nhwc_v_kernel(const float* __re
                 var = div_small(var, cnt, inv);
                 r[k] = ok ? var : 0.0f;
             }
-            if (live) *reinterpret_cast<f32x4_t*>(o + c) = r;
+            if (os) {
+                // x = hi + lo, hi = bf16(x) (RNE), lo = bf16(x - hi): the same split as the conv kernels' staging
+                unsigned hi[2], lo[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    typedef float f2_t __attribute__((ext_vector_type(2)));
+                    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+                    const f2_t v = {r[2 * p], r[2 * p + 1]};
+                    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2_t));
+                    const f2_t hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+                    hi[p] = hb;
+                    lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, b2_t));
+                }
+                if (live) {
+                    *reinterpret_cast<uint2*>(os) = make_uint2(hi[0], hi[1]);
+                    *reinterpret_cast<uint2*>(os + 32) = make_uint2(lo[0], lo[1]);
+                }
+            } else if (live) *reinterpret_cast<f32x4_t*>(o + c) = r;
         }
     };
     // two candidates per trip with ping-pong registers (A, B): the loads of the next candidate are
@@ -487,14 +510,15 @@ __global__ __launch_bounds__(256) void sweep_std_nhwc_v_kernel(const float* __re
         const long long sB = hasB ? HW : 0;
         const float2 gB = gp[sB];
         const unsigned vB = vp[sB];
-        candidate(gA, vA, out);
+        candidate(gA, vA, out, outs);
         const long long sA = d + 2 < d1 ? 2 * HW : sB;
         gA = gp[sA];
         vA = vp[sA];
-        if (hasB) candidate(gB, vB, out + vstep);
+        if (hasB) candidate(gB, vB, out + vstep, outs ? outs + sstep : nullptr);
         gp += 2 * HW;
         vp += 2 * HW;
         out += 2 * vstep;
+        if (outs) outs += 2 * sstep;
     }
 }
 
@@ -651,10 +675,12 @@ extern "C" int mvsgi_sweep_validity_u8(const float* grids, const void* grid_mask
 // grid_masks / masks: feats [B][N][Hi][Wi][C] -> vol [B][D][Ho][Wo][C]; identical output.
 namespace {
 int sweep_std_nhwc_valid_impl(const float* feats, const float* grids, const unsigned char* vmask, float* vol, int B, int N, int C,
-                              int Hi, int Wi, int D, int Ho, int Wo, int rig_shared, mvsgi_stream_t stream) {
+                              int Hi, int Wi, int D, int Ho, int Wo, int rig_shared, mvsgi_stream_t stream,
+                              unsigned char* vol_split = nullptr) {
     SweepDims s{B, N, C, Hi, Wi, 1, 1, D, Ho, Wo};
     if (check_dims(s, "mvsgi_sweep_std_nhwc_valid_f32")) return 1;
-    MVSGI_REQUIRE(feats && grids && vmask && vol, "mvsgi_sweep_std_nhwc_valid_f32: null pointer");
+    MVSGI_REQUIRE(feats && grids && vmask && (vol || vol_split), "mvsgi_sweep_std_nhwc_valid_f32: null pointer");
+    MVSGI_REQUIRE(!vol_split || C == 16, "mvsgi_sweep_std_nhwc_valid_split: the split-padded output needs C == 16 (got %d)", C);
     MVSGI_REQUIRE(N >= 1 && N <= 4, "mvsgi_sweep_std_nhwc_valid_f32: num_cams %d not in [1, 4]", N);
     MVSGI_REQUIRE(C % 4 == 0, "mvsgi_sweep_std_nhwc_valid_f32: C=%d must be a multiple of 4", C);
     // candidates per block: as many as keeps >= ~8k blocks in the launch (latency hiding across d
@@ -670,10 +696,10 @@ int sweep_std_nhwc_valid_impl(const float* feats, const float* grids, const unsi
     const dim3 grid((unsigned)nblk), block(256);
     hipStream_t st = mvsgi::as_stream(stream);
     switch (N) {
-        case 1: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared); break;
-        case 2: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<2>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared); break;
-        case 3: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<3>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared); break;
-        case 4: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<4>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared); break;
+        case 1: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split); break;
+        case 2: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<2>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split); break;
+        case 3: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<3>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split); break;
+        case 4: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<4>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split); break;
     }
     return mvsgi::check_launch("mvsgi_sweep_std_nhwc_valid_f32");
 }
@@ -683,6 +709,16 @@ extern "C" int mvsgi_sweep_std_nhwc_valid_f32(const float* feats, const float* g
                                               float* vol, int B, int N, int C, int Hi, int Wi, int D, int Ho, int Wo,
                                               mvsgi_stream_t stream) {
     return sweep_std_nhwc_valid_impl(feats, grids, vmask, vol, B, N, C, Hi, Wi, D, Ho, Wo, 0, stream);
+}
+
+// The same with the volume written in the split-padded format of conv3d_rs.hip (C == 16; vol_split zero-bordered,
+// [B][D+2][Ho+2][Wo+2][64 B]); rig_batch = 1: one rig for the whole batch, = B: per-frame grids / validity
+extern "C" int mvsgi_sweep_std_nhwc_valid_split(const float* feats, const float* grids, const unsigned char* vmask,
+                                                void* vol_split, int B, int N, int C, int Hi, int Wi, int D, int Ho, int Wo,
+                                                int rig_batch, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(rig_batch == 1 || rig_batch == B, "mvsgi_sweep_std_nhwc_valid_split: rig_batch %d not in {1, B}", rig_batch);
+    return sweep_std_nhwc_valid_impl(feats, grids, vmask, nullptr, B, N, C, Hi, Wi, D, Ho, Wo, rig_batch == 1 && B > 1 ? 1 : 0, stream,
+                                     static_cast<unsigned char*>(vol_split));
 }
 
 // The same with ONE rig for the whole batch: grids [1][N][D][Ho][Wo][2], vmask [1][D][Ho][Wo] (frame-independent rig

@@ -48,7 +48,7 @@ def _rig_hit(entry, tensors) -> bool:
         and entry[1] == tuple(t._version for t in tensors)
 
 
-def std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=None) -> Tensor:
+def std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=None, split_out: bool = False):
     """Masked-variance sweep.  grids / grid_masks / masks are constants of the camera rig (the
     reference builds them once, api/inference_class.py:40-45), so the mask half of the sweep
     (spherical_sweep_avg.py:92-102) is evaluated once per rig and cached on `owner`, keyed on the
@@ -58,7 +58,7 @@ def std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=None) -> Tensor:
     use_cache = owner is not None and getattr(owner, "cache_rig_constants", True) and _RIG_CACHE_ENV \
         and H.nhwc_sweep_ok(feats) and grids.is_cuda
     if not use_cache:
-        return H.sweep_std(feats, grids, grid_masks, masks)
+        return None if split_out else H.sweep_std(feats, grids, grid_masks, masks)
     tensors = (grids, grid_masks, masks)               # identity of what the caller passed
     cached = _RIG_VALIDITY.get(owner)
     if not _rig_hit(cached, tensors):
@@ -70,16 +70,40 @@ def std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=None) -> Tensor:
             g1, gm1, m1 = grids, grid_masks, masks
         cached = (tensors, tuple(t._version for t in tensors), H.sweep_validity(g1, gm1, m1), g1 if g1 is not grids else None)
         _RIG_VALIDITY[owner] = cached            # weak on the module: dies with it, never pickled with it
-    return H.sweep_std_valid(feats, cached[3] if cached[3] is not None else grids, cached[2])
+    g_use = cached[3] if cached[3] is not None else grids
+    if split_out:
+        # vol_raw straight into a module-owned split-padded buffer (zero border, allocated once per shape) for the
+        # register-stationary post_vol
+        B, D, Ho, Wo = feats.shape[0], grids.shape[2], grids.shape[3], grids.shape[4]
+        key = (B, D, Ho, Wo, feats.device)
+        buf = owner.__dict__.get("_mvsgi_rs_vol")
+        if buf is None or buf[0] != key:
+            buf = (key, H.SplitAct(B, D, Ho, Wo, 16, feats.device))
+            owner.__dict__["_mvsgi_rs_vol"] = buf
+        return H.sweep_std_valid_split(feats, g_use, cached[2], out=buf[1])
+    return H.sweep_std_valid(feats, g_use, cached[2])
 
 
 def cat_sweep_ndhwc(feats, grids) -> Tensor:
     return H.sweep_cat(feats, grids)
 
 
+_USE_RS = os.environ.get("MVSGI_RS", "1") != "0"
+_RS_MIN_UNITS = int(os.environ.get("MVSGI_RS_MIN_UNITS", "2048"))
+
+
 def std_forward(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor) -> Tensor:
+    L = cm.lower_conv_block(self.post_vol)
+    if _USE_RS and H.get_conv_mode() == "bf16x3" and L.cin == 16 and L.cout == 16 and L.stride == 1 \
+            and 0.0 <= L.neg_slope <= 1.0 and feats.dim() == 5 and feats.shape[2] == 16 and grids.dim() == 6:
+        B, D, Ho, Wo = feats.shape[0], grids.shape[2], grids.shape[3], grids.shape[4]
+        if B * ((D + 3) // 4) * ((Ho + 3) // 4) * ((Wo + 15) // 16) >= _RS_MIN_UNITS:
+            # sweep -> split-padded vol_raw -> register-stationary post_vol (csrc/conv3d_rs.hip) -> fp32 vol
+            vs = std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=self, split_out=True)
+            if vs is not None:
+                return cm._to_ncdhw_view(H.conv3d_rs16(vs, L._wp_rs(), L.scale, L.shift, neg_slope=L.neg_slope))
     vol_raw = std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=self)
-    return cm._to_ncdhw_view(cm.lower_conv_block(self.post_vol).run(vol_raw))
+    return cm._to_ncdhw_view(L.run(vol_raw))
 
 
 def cat_forward(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor) -> Tensor:

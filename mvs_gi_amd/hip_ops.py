@@ -121,6 +121,23 @@ def sweep_std_valid(feats, grids, vmask) -> torch.Tensor:
     return vol
 
 
+def sweep_std_valid_split(feats, grids, vmask, out: "SplitAct") -> "SplitAct":
+    """sweep_std_valid with vol_raw written split-padded (C == 16) into `out` (B, D, Ho, Wo, 16)."""
+    lib = _lib.load()
+    B, N, C, Hi, Wi = feats.shape
+    f = _feats_nhwc(feats)
+    grids = _dev(grids, "grids")
+    vmask = _dev(vmask, "vmask", torch.uint8)
+    Bg, Ng, D, Ho, Wo, two = grids.shape
+    if (Ng, two) != (N, 2) or Bg not in (1, B) or tuple(vmask.shape) != (Bg, D, Ho, Wo) or C != 16:
+        raise AssertionError(f"grids {tuple(grids.shape)} / vmask {tuple(vmask.shape)} do not match feats {tuple(feats.shape)}")
+    if out.shape != (B, D, Ho, Wo, C):
+        raise AssertionError(f"split output {out.shape} does not match {(B, D, Ho, Wo, C)}")
+    _lib.check(lib.mvsgi_sweep_std_nhwc_valid_split(f.data_ptr(), grids.data_ptr(), vmask.data_ptr(), out.buf.data_ptr(), B, N, C, Hi,
+                                                    Wi, D, Ho, Wo, Bg, _stream_ptr(f)), "mvsgi_sweep_std_nhwc_valid_split")
+    return out
+
+
 def sweep_std(feats, grids, grid_masks, masks, layout: str = "auto") -> torch.Tensor:
     """-> vol_raw [B, D, Ho, Wo, C] (masked variance over cameras).  layout: 'auto' uses the
     channels-last kernel when C % 4 == 0 and N <= 4 (transposing NCHW feats once), 'nchw'
@@ -367,7 +384,7 @@ def act_from_split(x: SplitAct, out: Optional[torch.Tensor] = None) -> torch.Ten
 
 
 def pack_conv_weights_rs(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
-    """[32, 32, 3, 3, 3] -> register-stationary layout (tap pairs in the kernel's own order), or None when unsupported."""
+    """[32, 32, 3, 3, 3] or [16, 16, 3, 3, 3] -> register-stationary layout (tap pairs in the kernel's own order), or None."""
     lib = _lib.load()
     w = _dev(w_oidhw, "conv weight")
     Cout, Cin = w.shape[:2]
@@ -419,6 +436,17 @@ def conv3d_out_split(x, w_packed_b3, scale, shift, out: "SplitAct", res=None, st
                                               out.buf.data_ptr(), B, Cin, Din, Hin, Win, Cout, stride, float(neg_slope),
                                               _stream_ptr(x)), "mvsgi_conv3d_f32_out_split")
     return out
+
+
+def conv3d_rs16(x: "SplitAct", w_packed_rs, scale, shift, neg_slope=0.01, out=None) -> torch.Tensor:
+    """Register-stationary 16 -> 16 conv (post_vol) on a split-padded volume -> fp32 [B, D, H, W, 16]."""
+    lib = _lib.load()
+    if x.C != 16 or scale.numel() != 16:
+        raise AssertionError("conv3d_rs16 is the 16 -> 16 kernel")
+    y = out if out is not None else torch.empty((x.B, x.D, x.H, x.W, 16), device=x.buf.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_conv3d_rs16_split(x.buf.data_ptr(), w_packed_rs.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(),
+                                           x.B, x.D, x.H, x.W, float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_rs16_split")
+    return y
 
 
 def conv3d_rs_applies(cin: int, cout: int, stride: int, neg_slope: float) -> bool:

@@ -961,3 +961,62 @@ def test_full_size_batch8_register_stationary_path_vs_reference_golden(golden_di
     finally:
         H.set_conv_mode(old)
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 4, 16), (2, 5, 7, 37), (1, 9, 6, 20), (3, 8, 16, 48)])
+@pytest.mark.parametrize("slope", [0.01, 1.0])
+def test_conv3d_rs16_vs_oracle(shape, slope):
+    """Register-stationary 16 -> 16 conv (post_vol) on a split-padded volume against the oracle's conv block on the same
+    (16-bit-split) input: one-brick and ragged launches (the last brick of every workgroup runs the drain phase)."""
+    B, d, h, w = shape
+    rng = np.random.default_rng(sum(shape))
+    x = _g(rng.standard_normal((B, d, h, w, 16), dtype=np.float32))
+    wt = (rng.standard_normal((16, 16, 3, 3, 3)) / np.sqrt(27 * 16)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, 16).astype(np.float32), (rng.standard_normal(16) * 0.1).astype(np.float32)
+    xs = H.act_to_split(x)
+    y = H.conv3d_rs16(xs, H.pack_conv_weights_rs(_g(wt)), _g(sc), _g(sh), neg_slope=slope).cpu().numpy()
+    xq = H.act_from_split(xs).cpu().permute(0, 4, 1, 2, 3)
+    ref = F.conv3d(xq, torch.from_numpy(wt), padding=1) * torch.from_numpy(sc).view(1, -1, 1, 1, 1) + torch.from_numpy(sh).view(1, -1, 1, 1, 1)
+    ref = torch.where(ref > 0, ref, ref * slope).permute(0, 2, 3, 4, 1).numpy()
+    assert _rel(y, ref) <= 1e-4
+
+
+def test_sweep_split_padded_output_is_the_split_of_vol_raw(golden_dir):
+    """The sweep writing its volume split-padded (the register-stationary post_vol's input) against the bit-exact fp32 sweep,
+    per-frame rig and one rig for the whole batch."""
+    case = SMALL_CASES["std_d16_rand"]
+    cfg = case["cfg"]
+    inp = synth.make_inputs(cfg, seed=case["seed"], batch=2, grid_kind=case["grid_kind"], grid_mask_dtype=case["grid_mask_dtype"])
+    f, g, gm, m = (_g(inp[k]) for k in ("feats", "grids", "grid_masks", "masks"))
+    vm = H.sweep_validity(g, gm, m)
+    vol = H.sweep_std_valid(f, g, vm)
+    B, D, Ho, Wo, C = vol.shape
+    vs = H.sweep_std_valid_split(f, g, vm, out=H.SplitAct(B, D, Ho, Wo, C, f.device))
+    assert torch.equal(vs.buf, H.act_to_split(vol).buf)
+    vol1 = H.sweep_std_valid(f, g[:1].contiguous(), vm[:1].contiguous())           # one rig for both frames
+    vs1 = H.sweep_std_valid_split(f, g[:1].contiguous(), vm[:1].contiguous(), out=H.SplitAct(B, D, Ho, Wo, C, f.device))
+    assert torch.equal(vs1.buf, H.act_to_split(vol1).buf)
+
+
+def test_builder_register_stationary_post_vol_matches_streaming_and_goldens(golden_dir):
+    from mvs_gi_amd.dropin import cost_volume_builder as cb
+    name = "std_d16_rand"
+    case = SMALL_CASES[name]
+    cfg, z = case["cfg"], _load(golden_dir, name)
+    inp = synth.make_inputs(cfg, seed=case["seed"], batch=case["batch"], grid_kind=case["grid_kind"],
+                            grid_mask_dtype=case["grid_mask_dtype"])
+    w = synth.make_weights(cfg, seed=case["seed"], gain=1.0)
+    f, g, gm, m = (_g(inp[k]) for k in ("feats", "grids", "grid_masks", "masks"))
+    old_mode, old_min, old_use = H.get_conv_mode(), cb._RS_MIN_UNITS, cb._USE_RS
+    try:
+        H.set_conv_mode("bf16x3")
+        outs = {}
+        for use in (False, True):
+            cb._USE_RS, cb._RS_MIN_UNITS = use, 0
+            cvb, _, _ = build_modules(cfg, w, DEV)
+            outs[use] = cvb(f, g, gm, m).contiguous().cpu().numpy()
+            assert ("_mvsgi_rs_vol" in cvb.__dict__) == use
+        assert _rel(outs[True], z["vol"]) <= 2e-4 and _rel(outs[True], outs[False]) <= 5e-5
+    finally:
+        H.set_conv_mode(old_mode)
+        cb._RS_MIN_UNITS, cb._USE_RS = old_min, old_use

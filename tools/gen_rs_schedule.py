@@ -153,9 +153,14 @@ def build(with_pairs: bool):
             S.place(5, 1, f"rresB[{k}][{e}] = rres[{k}][{e}];", end=24)
     # D. the accumulators leave the accumulator file (see mfma_order): own accumulators 0..3 rest from slot 12 + a on and
     #    are overwritten at slot 24 + a; the partner's 4..7 rest from slot 16 + a on and are overwritten at slot 28 + a
+    if not with_pairs:
+        # no MFMAs behind pair 13 in the drain phases: the distance to the accumulator reads must be real time
+        S.put(23, 0, "RS_HAZARD_WAIT()")
     for a in range(8):
         dst = f"keepA[{a}]" if a < 4 else f"snd[{a - 4}]"
         lo, hi = (12 + a + 6, 24 + a) if a < 4 else (16 + a + 6, 28 + a)
+        if not with_pairs:
+            lo, hi = max(lo, 24), NSLOT - 1
         if OLD_ORDER:
             lo, hi = 19 + a, 24 + a
         if OLD_FIN:
