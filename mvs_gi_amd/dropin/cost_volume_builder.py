@@ -89,7 +89,7 @@ def cat_sweep_ndhwc(feats, grids) -> Tensor:
 
 
 _USE_RS = os.environ.get("MVSGI_RS", "1") != "0"
-_RS_MIN_UNITS = int(os.environ.get("MVSGI_RS_MIN_UNITS", "2048"))
+_RS_MIN_UNITS = int(os.environ.get("MVSGI_RS_MIN_UNITS", "0"))      # measured faster down to one frame (B=1: 16.9 vs 24.2 us, 23.5 vs 32.2 us)
 
 
 def std_forward(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor) -> Tensor:

@@ -32,10 +32,10 @@ class UNetDownBlk(nn.Module):
         return cm._to_ncdhw_view(down_block_ndhwc(self, H.as_ndhwc(x)))
 
 
-# MVSGI_RS=0 keeps every layer on the streaming kernels.  The register-stationary kernel walks >= MVSGI_RS_MIN_UNITS
+# MVSGI_RS=0 keeps every layer on the streaming kernels.  MVSGI_RS_MIN_UNITS: minimum
 # 128-voxel bricks per launch (one workgroup per CU, each with a prologue and two drain phases: small launches lose)
 _USE_RS = os.environ.get("MVSGI_RS", "1") != "0"
-_RS_MIN_UNITS = int(os.environ.get("MVSGI_RS_MIN_UNITS", "2048"))
+_RS_MIN_UNITS = int(os.environ.get("MVSGI_RS_MIN_UNITS", "0"))      # measured faster down to one frame (B=1: 16.9 vs 24.2 us, 23.5 vs 32.2 us)
 
 
 def _rs_chain(blk, x: Tensor):
