@@ -234,15 +234,17 @@ extern "C" int mvsgi_conv2d_f32(const float* x, const float* w_oihw, const void*
     a.shift = shift;
     a.res = res;
     a.y = y;
-    a.B = 1;
+    // one volume of B planes while its byte offsets fit 32 bits, else B one-plane frames (64-bit frame bases)
+    const bool planes = (long long)B * Hin * Win * Cin < (1ll << 29) && (long long)B * Ho * Wo * Cout < (1ll << 31);
+    a.B = planes ? 1 : B;
     a.Cin = Cin;
-    a.Din = B;
+    a.Din = planes ? B : 1;
     a.Hin = Hin;
     a.Win = Win;
     a.Cout = Cout;
     a.stride = stride;
     a.neg_slope = neg_slope;
-    a.Do = B;
+    a.Do = a.Din;
     a.Ho = Ho;
     a.Wo = Wo;
     switch (v) {

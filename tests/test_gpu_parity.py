@@ -592,6 +592,25 @@ def test_conv2d_bf16x3_and_direct_vs_aten(shape):
         assert _rel(ym.permute(0, 3, 1, 2).cpu().numpy(), yref) <= 2e-5
 
 
+def test_conv2d_batch_beyond_32bit_offsets_matches_its_halves():
+    """A 192-image extractor batch (B=64 frames x 3 cameras) exceeds the one-volume 32-bit byte offsets; the entry then
+    walks the images as frames with 64-bit bases.  Same numbers as the two halves run through the one-volume path."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    N, Hh, Ww = 132, 256, 1024                                   # 132*256*1024*16 > 2^29 elements
+    x = torch.randn(N, Hh, Ww, 16, device="cuda", generator=g)
+    w = torch.randn(16, 16, 3, 3, device="cuda", generator=g) * 0.1
+    scale = torch.rand(16, device="cuda", generator=g) + 0.5
+    shift = torch.randn(16, device="cuda", generator=g) * 0.1
+    wp = H.pack_conv2d_weights_bf16x3(w)
+    for stride in (1, 2):
+        y = H.conv2d(x, w, wp, scale, shift, stride=stride, impl=H.CONV_BF16X3)
+        h = N // 2
+        for lo in (0, h):
+            yh = H.conv2d(x[lo:lo + h], w, wp, scale, shift, stride=stride, impl=H.CONV_BF16X3)
+            assert torch.equal(y[lo:lo + h], yh)
+        del y, yh
+
+
 def test_conv2d_stem_5x5_nchw_input():
     rng = np.random.default_rng(12)
     x = rng.random((2, 3, 30, 52)).astype(np.float32)
