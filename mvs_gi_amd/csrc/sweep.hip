@@ -53,6 +53,32 @@ __device__ __forceinline__ Bilin bilin_setup(float gx, float gy, int W, int H) {
     return t;
 }
 
+// bilin_setup with the four taps as BYTE offsets into a channels-last image of C4 = 4 C bytes per texel and rowB = W C4
+// bytes per row; a tap outside the image gets an offset no buffer descriptor covers (the hardware range check reads 0).
+__device__ __forceinline__ Bilin bilin_setup_bytes(float gx, float gy, int W, int H, int C4, int rowB) {
+#pragma clang fp contract(off)
+    Bilin t;
+    const float x = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
+    const float y = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    const float xf = floorf(x), yf = floorf(y);
+    const float x1f = xf + 1.0f, y1f = yf + 1.0f;
+    t.w00 = (x1f - x) * (y1f - y);
+    t.w01 = (x1f - x) * (y - yf);
+    t.w10 = (x - xf) * (y1f - y);
+    t.w11 = (x - xf) * (y - yf);
+    const int x0 = (int)fminf(fmaxf(xf, -2.0f), (float)W + 1.0f);
+    const int y0 = (int)fminf(fmaxf(yf, -2.0f), (float)H + 1.0f);
+    const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+    const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+    const int base = __mul24(y0, rowB) + __mul24(x0, C4);        // |y0| <= H + 1, rowB < 2^23 (checked by the launcher)
+    constexpr int kOutside = (int)0x80000000;
+    t.o00 = (vx0 & vy0) ? base : kOutside;
+    t.o01 = (vx0 & vy1) ? base + rowB : kOutside;
+    t.o10 = (vx1 & vy0) ? base + C4 : kOutside;
+    t.o11 = (vx1 & vy1) ? base + rowB + C4 : kOutside;
+    return t;
+}
+
 __device__ __forceinline__ float bilin_fetch(const float* __restrict__ plane, const Bilin& t) {
 #pragma clang fp contract(off)
     // zero padding: a tap outside the image reads 0 (backports.py:58-72)
@@ -394,7 +420,7 @@ __device__ __forceinline__ Bilin quad_bcast(const Bilin& m) {
 // walks `dchunk` candidates, fetching the NEXT candidate's grid point and validity byte before the
 // 12 texel gathers of the current one, so a voxel costs one exposed memory round trip instead of
 // three.  Logical block order (b, ho, d-chunk, w-tile), XCD-contiguous (see sweep_xcd_remap).
-template <int NCAM>
+template <int NCAM, bool C16>
 __global__ __launch_bounds__(256) void sweep_std_nhwc_v_kernel(const float* __restrict__ feats,
                                                                const float* __restrict__ grids,
                                                                const unsigned char* __restrict__ vmask,
@@ -435,70 +461,136 @@ __global__ __launch_bounds__(256) void sweep_std_nhwc_v_kernel(const float* __re
     float* out = vol + ((((long long)b * s.D + d0) * s.Ho + ho) * s.Wo + wo) * s.C;
     const long long vstep = HW * s.C;
     // vol_split (C == 16): the volume goes out in the split-padded format of conv3d_rs.hip instead -- [B][D+2][Ho+2][Wo+2]
-    // records of 64 B = [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15]; lane q's 4 channels are 8 B of hi and 8 B of lo
+    // records of 64 B = [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15]; lane q's 4 channels are 8 B of hi and 8 B of lo, which
+    // the lane pairs of a quad trade so that every lane stores one whole 16 B piece (lanes 0..3 -> pieces 0, 2, 1, 3) and a
+    // wave one contiguous KiB
     unsigned char* outs = vol_split ? vol_split + ((((long long)b * (s.D + 2) + d0 + 1) * (s.Ho + 2) + ho + 1) * (s.Wo + 2) + wo + 1) * 64 +
-                                          (q >> 1) * 16 + (q & 1) * 8
+                                          ((q & 1) * 2 + (q >> 1)) * 16
                                     : nullptr;
     const long long sstep = (long long)(s.Ho + 2) * (s.Wo + 2) * 64;
     // one candidate: grid point -> taps (lane q = camera q, broadcast through the quad) -> 4 x NCAM
     // texel gathers -> masked variance
+    const int C4 = C16 ? 64 : s.C * 4, rowB = s.Wi * C4;
     auto candidate = [&](const float2 gxy, const unsigned vm, float* __restrict__ o, unsigned char* __restrict__ os) {
-        const Bilin mine = bilin_setup(gxy.x, gxy.y, s.Wi, s.Hi);
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        // taps as BYTE offsets, worked out once by the camera's lane and broadcast through the quad
+        const Bilin mine = bilin_setup_bytes(gxy.x, gxy.y, s.Wi, s.Hi, C4, rowB);
         Bilin ft[NCAM];
         ft[0] = quad_bcast<0>(mine);
         if (NCAM > 1) ft[NCAM > 1 ? 1 : 0] = quad_bcast<1>(mine);
         if (NCAM > 2) ft[NCAM > 2 ? 2 : 0] = quad_bcast<2>(mine);
         if (NCAM > 3) ft[NCAM > 3 ? 3 : 0] = quad_bcast<3>(mine);
-        float vf[NCAM];
+        bool val[NCAM];
+        f32x2_t VF[NCAM];
         float n = 0.0f;
 #pragma unroll
         for (int cam = 0; cam < NCAM; ++cam) {
-            vf[cam] = ((vm >> cam) & 1u) ? 1.0f : 0.0f;
-            n = n + vf[cam];
+            val[cam] = ((vm >> cam) & 1u) != 0;
+            const float vf = val[cam] ? 1.0f : 0.0f;
+            VF[cam] = f32x2_t{vf, vf};
+            n = n + vf;
         }
         const bool ok = n > 1.0f;
         const float cnt = ok ? n : 1.0f;
-        const float inv = 1.0f / cnt;
+        // RN(1 / cnt) for the camera counts there are: exactly what the division 1.0f / cnt returns
+        const float inv = cnt == 2.0f ? 0.5f : cnt == 3.0f ? 0x1.555556p-2f : cnt == 4.0f ? 0.25f : 1.0f;
+        const f32x2_t INV = {inv, inv}, NCNT = {-cnt, -cnt};
 #pragma unroll 1
-        for (int c = q * 4; c < s.C; c += 16) {
-            f32x4_t sv[NCAM];
+        for (int cb = q * 16; cb < (C16 ? 64 : C4); cb += 64) {      // C16: one trip, the tap offsets die with the loads
+            f32x4_t tx[NCAM][4];
+#ifdef MVSGI_SWEEP_ABL_NOGATHER              // diagnostic builds only: every tap reads texel 0 (L1 hits)
 #pragma unroll
-            for (int cam = 0; cam < NCAM; ++cam) sv[cam] = bilin_fetch4_buf(img[cam], c, s.C, ft[cam]);
+            for (int cam = 0; cam < NCAM; ++cam) { ft[cam].o00 &= 64; ft[cam].o01 &= 64; ft[cam].o10 &= 64; ft[cam].o11 &= 64; }
+#endif
+#pragma unroll
+            for (int cam = 0; cam < NCAM; ++cam) {
+                tx[cam][0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(img[cam], ft[cam].o00 + cb, 0, 0));
+                tx[cam][1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(img[cam], ft[cam].o01 + cb, 0, 0));
+                tx[cam][2] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(img[cam], ft[cam].o10 + cb, 0, 0));
+                tx[cam][3] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(img[cam], ft[cam].o11 + cb, 0, 0));
+            }
+            f32x2_t sv[NCAM][2];
+#pragma unroll
+            for (int cam = 0; cam < NCAM; ++cam) {
+                const f32x2_t W00 = {ft[cam].w00, ft[cam].w00}, W01 = {ft[cam].w01, ft[cam].w01};
+                const f32x2_t W10 = {ft[cam].w10, ft[cam].w10}, W11 = {ft[cam].w11, ft[cam].w11};
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const f32x2_t i00 = {tx[cam][0][2 * p], tx[cam][0][2 * p + 1]}, i01 = {tx[cam][1][2 * p], tx[cam][1][2 * p + 1]};
+                    const f32x2_t i10 = {tx[cam][2][2 * p], tx[cam][2][2 * p + 1]}, i11 = {tx[cam][3][2 * p], tx[cam][3][2 * p + 1]};
+                    sv[cam][p] = ((i00 * W00 + i01 * W01) + i10 * W10) + i11 * W11;          // backports.py:86, left to right
+                }
+            }
+            // spherical_sweep_avg.py:106-125 on channel pairs.  The two divisions by cnt in {1, 2, 3, 4} are Markstein's
+            // q = RN(x inv), r = x - cnt q (exact in the fma), RN(q + r inv): the correctly rounded quotient for every finite x
+            // (cnt a power of two: q is already exact or correctly rounded; cnt = 3: r / 3 is a multiple of ulp / 3, never near
+            // a rounding boundary, down to the subnormals).  Sums beyond 1e30 (and infinities) take the hardware division.
+            f32x2_t sum[2], var[2];
             f32x4_t r;
+            float big = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float sum = 0.0f;
+            for (int p = 0; p < 2; ++p) {
+                sum[p] = sv[0][p] * VF[0];
 #pragma unroll
-                for (int cam = 0; cam < NCAM; ++cam) sum = sum + sv[cam][k] * vf[cam];
-                const float avg = div_small(sum, cnt, inv);
-                float var = 0.0f;
+                for (int cam = 1; cam < NCAM; ++cam) sum[p] = sum[p] + sv[cam][p] * VF[cam];
+                const f32x2_t qa = sum[p] * INV;
+                const f32x2_t avg = __builtin_elementwise_fma(__builtin_elementwise_fma(NCNT, qa, sum[p]), INV, qa);
 #pragma unroll
                 for (int cam = 0; cam < NCAM; ++cam) {
-                    const float t = vf[cam] != 0.0f ? sv[cam][k] : avg;
-                    const float df = t - avg;
-                    var = var + df * df;
+                    const f32x2_t t = {val[cam] ? sv[cam][p].x : avg.x, val[cam] ? sv[cam][p].y : avg.y};   // :119
+                    const f32x2_t df = t - avg;
+                    var[p] = cam == 0 ? df * df : var[p] + df * df;                                           // :122
                 }
-                var = div_small(var, cnt, inv);
-                r[k] = ok ? var : 0.0f;
+                const f32x2_t qv = var[p] * INV;
+                const f32x2_t v = __builtin_elementwise_fma(__builtin_elementwise_fma(NCNT, qv, var[p]), INV, qv);
+                r[2 * p] = ok ? v.x : 0.0f;                                                                   // :125
+                r[2 * p + 1] = ok ? v.y : 0.0f;
+                big = __builtin_fmaxf(__builtin_fmaxf(big, __builtin_fmaxf(__builtin_fabsf(sum[p].x), __builtin_fabsf(sum[p].y))),
+                                      __builtin_fmaxf(var[p].x, var[p].y));
+            }
+            if (__builtin_amdgcn_ballot_w64(big > 1e30f) != 0) {                 // wave-uniform, never taken on real features
+                float dv = cnt;
+                asm volatile("; exact-division path" : "+v"(dv));          // (opaque: keeps the divisions inside the branch)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float sm = sum[k >> 1][k & 1];
+                    const float avg = sm / dv;
+                    float vr = 0.0f;
+#pragma unroll
+                    for (int cam = 0; cam < NCAM; ++cam) {
+                        const float t = val[cam] ? sv[cam][k >> 1][k & 1] : avg;
+                        const float df = t - avg;
+                        vr = vr + df * df;
+                    }
+                    vr = vr / dv;
+                    r[k] = ok ? vr : 0.0f;
+                }
             }
             if (os) {
                 // x = hi + lo, hi = bf16(x) (RNE), lo = bf16(x - hi): the same split as the conv kernels' staging
                 unsigned hi[2], lo[2];
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    typedef float f2_t __attribute__((ext_vector_type(2)));
                     typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
-                    const f2_t v = {r[2 * p], r[2 * p + 1]};
+                    const f32x2_t v = {r[2 * p], r[2 * p + 1]};
                     const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2_t));
-                    const f2_t hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+                    const f32x2_t hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
                     hi[p] = hb;
                     lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, b2_t));
                 }
+                // even lanes keep their hi and take the odd neighbour's hi; odd lanes take the even neighbour's lo
+                const bool odd = (q & 1) != 0;
+                const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? hi[0] : lo[0]), 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+                const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? hi[1] : lo[1]), 0xB1, 0xf, 0xf, true);
+                const uint4 piece = odd ? make_uint4(r0, r1, lo[0], lo[1]) : make_uint4(hi[0], hi[1], r0, r1);
+#ifdef MVSGI_SWEEP_ABL_NOSTORE               // diagnostic builds only
+                if (live && hi[0] == 0x12345678u) {
+#else
                 if (live) {
-                    *reinterpret_cast<uint2*>(os) = make_uint2(hi[0], hi[1]);
-                    *reinterpret_cast<uint2*>(os + 32) = make_uint2(lo[0], lo[1]);
+#endif
+                    *reinterpret_cast<uint4*>(os) = piece;
                 }
-            } else if (live) *reinterpret_cast<f32x4_t*>(o + c) = r;
+            } else if (live) *reinterpret_cast<f32x4_t*>(reinterpret_cast<char*>(o) + cb) = r;
         }
     };
     // two candidates per trip with ping-pong registers (A, B): the loads of the next candidate are
@@ -519,6 +611,194 @@ __global__ __launch_bounds__(256) void sweep_std_nhwc_v_kernel(const float* __re
         vp += 2 * HW;
         out += 2 * vstep;
         if (outs) outs += 2 * sstep;
+    }
+}
+
+// One rig for the whole batch (C == 16): the taps of a voxel are the same in every frame, so a block owns 64 wo of one
+// output row and walks `dchunk` candidates x F FRAMES -- grid point -> taps once per candidate, then frame after frame
+// through the same taps.  The twelve gathers roll: as soon as a camera's four texels are consumed, the same registers are
+// re-loaded from the next frame's image (soffset = frame / camera), so a wave keeps 4 N loads in flight through the
+// variance, the bf16 split and the stores of the frame before (which are younger than the loads it waits for next).
+// One descriptor spans the block's F frames; a tap outside its image carries an offset beyond any record.
+// Logical block order (frame-chunk, ho, d-chunk, w-tile), XCD-contiguous.
+template <int NCAM>
+__global__ __launch_bounds__(256) void sweep_std_rig_kernel(const float* __restrict__ feats, const float* __restrict__ grids,
+                                                            const unsigned char* __restrict__ vmask, float* __restrict__ vol,
+                                                            unsigned char* __restrict__ vol_split, SweepDims s, int dchunk,
+                                                            int nd, int F) {
+#pragma clang fp contract(off)
+    static_assert(NCAM <= 4, "one camera per lane of a quad");
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const int q = threadIdx.x & 3;
+    const int WT = (s.Wo + 63) >> 6;
+    int L = sweep_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int wt = L % WT;
+    L /= WT;
+    const int dc = L % nd;
+    L /= nd;
+    const int ho = L % s.Ho;
+    const int b0 = (L / s.Ho) * F;
+    const int nf = b0 + F < s.B ? F : s.B - b0;
+    int wo = wt * 64 + (threadIdx.x >> 2);
+    const bool live = wo < s.Wo;
+    if (!live) wo = s.Wo - 1;            // keep whole quads alive for the DPP broadcasts
+    const int d0 = dc * dchunk;
+    const int d1 = d0 + dchunk < s.D ? d0 + dchunk : s.D;
+    const int HWi = s.Hi * s.Wi;
+    const long long HW = (long long)s.Ho * s.Wo;
+    const unsigned imgB = (unsigned)HWi * 64u;
+    const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(feats + (long long)b0 * NCAM * HWi * 16), 0, (int)(nf * NCAM * imgB), 0x00020000);
+    const int mycam = q < NCAM ? q : NCAM - 1;
+    const float2* gp = reinterpret_cast<const float2*>(grids) + ((long long)mycam * s.D + d0) * HW + (long long)ho * s.Wo + wo;
+    const unsigned char* vp = vmask + (long long)d0 * HW + (long long)ho * s.Wo + wo;
+    float* out = vol ? vol + ((((long long)b0 * s.D + d0) * s.Ho + ho) * s.Wo + wo) * 16 + q * 4 : nullptr;
+    const long long vstep = HW * 16, vframe = (long long)s.D * HW * 16;
+    unsigned char* outs = vol_split ? vol_split + ((((long long)b0 * (s.D + 2) + d0 + 1) * (s.Ho + 2) + ho + 1) * (s.Wo + 2) + wo + 1) * 64 +
+                                          (q >> 1) * 16 + (q & 1) * 8
+                                    : nullptr;
+    const long long sstep = (long long)(s.Ho + 2) * (s.Wo + 2) * 64, sframe = (long long)(s.D + 2) * sstep;
+    const int rowB = s.Wi * 64;
+
+    float2 gxy = *gp;
+    unsigned vm = *vp;
+#pragma unroll 1
+    for (int d = d0; d < d1; ++d) {
+        const long long nx = d + 1 < d1 ? HW : 0;           // the next candidate's grid point, not needed for F frames
+        const float2 gN = gp[nx];
+        const unsigned vN = vp[nx];
+        const Bilin mine = bilin_setup_bytes(gxy.x, gxy.y, s.Wi, s.Hi, 64, rowB);
+        Bilin ft[NCAM];
+        ft[0] = quad_bcast<0>(mine);
+        if (NCAM > 1) ft[NCAM > 1 ? 1 : 0] = quad_bcast<1>(mine);
+        if (NCAM > 2) ft[NCAM > 2 ? 2 : 0] = quad_bcast<2>(mine);
+        if (NCAM > 3) ft[NCAM > 3 ? 3 : 0] = quad_bcast<3>(mine);
+        int off[NCAM][4];
+        bool val[NCAM];
+        f32x2_t VF[NCAM];
+        float n = 0.0f;
+#pragma unroll
+        for (int cam = 0; cam < NCAM; ++cam) {
+            off[cam][0] = ft[cam].o00 + q * 16;
+            off[cam][1] = ft[cam].o01 + q * 16;
+            off[cam][2] = ft[cam].o10 + q * 16;
+            off[cam][3] = ft[cam].o11 + q * 16;
+            val[cam] = ((vm >> cam) & 1u) != 0;
+            const float vf = val[cam] ? 1.0f : 0.0f;
+            VF[cam] = f32x2_t{vf, vf};
+            n = n + vf;
+        }
+        const bool ok = n > 1.0f;
+        const float cnt = ok ? n : 1.0f;
+        const float inv = cnt == 2.0f ? 0.5f : cnt == 3.0f ? 0x1.555556p-2f : cnt == 4.0f ? 0.25f : 1.0f;   // RN(1 / cnt)
+        const f32x2_t INV = {inv, inv}, NCNT = {-cnt, -cnt};
+        f32x4_t tx[NCAM][4];
+#pragma unroll
+        for (int cam = 0; cam < NCAM; ++cam)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                tx[cam][t] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(img, off[cam][t], cam * imgB, 0));
+        float* o = out;
+        unsigned char* os = outs;
+        // a frame's result is stored one trip later, BEFORE the gathers re-issued there: the wait for those gathers then
+        // never waits for a store younger than them (loads and stores retire through one in-order counter)
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t pend = {0u, 0u, 0u, 0u};
+        auto store_pending = [&]() {
+            if (os) {
+                if (live) {
+                    *reinterpret_cast<uint2*>(os) = make_uint2(pend[0], pend[1]);
+                    *reinterpret_cast<uint2*>(os + 32) = make_uint2(pend[2], pend[3]);
+                }
+                os += sframe;
+            } else {
+                if (live) *reinterpret_cast<u32x4_t*>(o) = pend;
+                o += vframe;
+            }
+        };
+#pragma unroll 1
+        for (int f = 0; f < nf; ++f) {
+            const unsigned fnext = (unsigned)(f + 1 < nf ? f + 1 : f) * NCAM * imgB;     // (the last frame re-reads itself)
+            f32x2_t sv[NCAM][2];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (f > 0) store_pending();
+#pragma unroll
+            for (int cam = 0; cam < NCAM; ++cam) {
+                const f32x2_t W00 = {ft[cam].w00, ft[cam].w00}, W01 = {ft[cam].w01, ft[cam].w01};
+                const f32x2_t W10 = {ft[cam].w10, ft[cam].w10}, W11 = {ft[cam].w11, ft[cam].w11};
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const f32x2_t i00 = {tx[cam][0][2 * p], tx[cam][0][2 * p + 1]}, i01 = {tx[cam][1][2 * p], tx[cam][1][2 * p + 1]};
+                    const f32x2_t i10 = {tx[cam][2][2 * p], tx[cam][2][2 * p + 1]}, i11 = {tx[cam][3][2 * p], tx[cam][3][2 * p + 1]};
+                    sv[cam][p] = ((i00 * W00 + i01 * W01) + i10 * W10) + i11 * W11;          // backports.py:86, left to right
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    tx[cam][t] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(img, off[cam][t], fnext + cam * imgB, 0));
+            }
+            // spherical_sweep_avg.py:106-125 on channel pairs; the divisions as in sweep_std_nhwc_v_kernel
+            f32x2_t sum[2], var[2];
+            f32x4_t r;
+            float big = 0.0f;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                sum[p] = sv[0][p] * VF[0];
+#pragma unroll
+                for (int cam = 1; cam < NCAM; ++cam) sum[p] = sum[p] + sv[cam][p] * VF[cam];
+                const f32x2_t qa = sum[p] * INV;
+                const f32x2_t avg = __builtin_elementwise_fma(__builtin_elementwise_fma(NCNT, qa, sum[p]), INV, qa);
+#pragma unroll
+                for (int cam = 0; cam < NCAM; ++cam) {
+                    const f32x2_t t = {val[cam] ? sv[cam][p].x : avg.x, val[cam] ? sv[cam][p].y : avg.y};
+                    const f32x2_t df = t - avg;
+                    var[p] = cam == 0 ? df * df : var[p] + df * df;
+                }
+                const f32x2_t qv = var[p] * INV;
+                const f32x2_t v = __builtin_elementwise_fma(__builtin_elementwise_fma(NCNT, qv, var[p]), INV, qv);
+                r[2 * p] = ok ? v.x : 0.0f;
+                r[2 * p + 1] = ok ? v.y : 0.0f;
+                big = __builtin_fmaxf(__builtin_fmaxf(big, __builtin_fmaxf(__builtin_fabsf(sum[p].x), __builtin_fabsf(sum[p].y))),
+                                      __builtin_fmaxf(var[p].x, var[p].y));
+            }
+            if (__builtin_amdgcn_ballot_w64(big > 1e30f) != 0) {                 // wave-uniform, never taken on real features
+                float dv = cnt;
+                asm volatile("; exact-division path" : "+v"(dv));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float sm = sum[k >> 1][k & 1];
+                    const float avg = sm / dv;
+                    float vr = 0.0f;
+#pragma unroll
+                    for (int cam = 0; cam < NCAM; ++cam) {
+                        const float t = val[cam] ? sv[cam][k >> 1][k & 1] : avg;
+                        const float df = t - avg;
+                        vr = vr + df * df;
+                    }
+                    vr = vr / dv;
+                    r[k] = ok ? vr : 0.0f;
+                }
+            }
+            if (os) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+                    const f32x2_t v = {r[2 * p], r[2 * p + 1]};
+                    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2_t));
+                    const f32x2_t hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+                    pend[p] = hb;
+                    pend[2 + p] = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, b2_t));
+                }
+            } else {
+                pend = __builtin_bit_cast(u32x4_t, r);
+            }
+        }
+        store_pending();
+        gxy = gN;
+        vm = vN;
+        gp += HW;
+        vp += HW;
+        if (out) out += vstep;
+        if (outs) outs += sstep;
     }
 }
 
@@ -686,20 +966,51 @@ int sweep_std_nhwc_valid_impl(const float* feats, const float* grids, const unsi
     // candidates per block: as many as keeps >= ~8k blocks in the launch (latency hiding across d
     // needs a few; filling 256 CUs x 4 resident blocks needs the rest)
     const long long rows = mvsgi::cdiv(Wo, 64) * Ho * B;
-    long long nd = rows >= 8192 ? 1 : mvsgi::cdiv(8192, rows);
+    // (never one chunk: with two the rows of blocks resident on an XCD span half as many feature-map rows, which then stay
+    // in its 4 MiB L2 -- FETCH_SIZE 3.7 -> 0.79 GiB per 64-frame launch, profiles/r02_pmc_sweep_l2.txt)
+    long long nd = rows >= 8192 ? 2 : mvsgi::cdiv(8192, rows);
+    static const int nd_env = getenv("MVSGI_SWEEP_ND") ? atoi(getenv("MVSGI_SWEEP_ND")) : 0;      // experiments
+    if (nd_env > 0) nd = nd_env;
     if (nd > D) nd = D;
     const int dchunk = (int)mvsgi::cdiv(D, nd);
     nd = mvsgi::cdiv(D, dchunk);
     const long long nblk = rows * nd;
-    MVSGI_REQUIRE((long long)Hi * Wi * C < (1ll << 31) && nblk < (1ll << 31),
-                  "mvsgi_sweep_std_nhwc_valid_f32: dimensions exceed the launch geometry");
-    const dim3 grid((unsigned)nblk), block(256);
+    MVSGI_REQUIRE((long long)Hi * Wi * C < (1ll << 29) && (long long)Wi * C * 4 < (1ll << 23) && nblk < (1ll << 31),
+                  "mvsgi_sweep_std_nhwc_valid_f32: dimensions exceed the launch geometry (image bytes < 2^31, row bytes < 2^23)");
     hipStream_t st = mvsgi::as_stream(stream);
+    static const bool rig_walk = getenv("MVSGI_SWEEP_RIG_WALK") && atoi(getenv("MVSGI_SWEEP_RIG_WALK")) != 0;   // measured slower: off
+    if (rig_shared && C == 16 && B >= 2 && rig_walk) {
+        // one rig for the batch: blocks walk F frames per candidate through the same taps (sweep_std_rig_kernel)
+        int F = B < 8 ? B : 8;
+        while (F > 1 && (long long)F * N * Hi * Wi * 64 >= (1ll << 31)) --F;
+        const long long rows_f = mvsgi::cdiv(Wo, 64) * Ho * mvsgi::cdiv(B, F);
+        long long ndf = rows_f >= 4096 ? 1 : mvsgi::cdiv(4096, rows_f);
+        if (ndf > D) ndf = D;
+        const int dchunk_f = (int)mvsgi::cdiv(D, ndf);
+        ndf = mvsgi::cdiv(D, dchunk_f);
+        const dim3 gridf((unsigned)(rows_f * ndf));
+        switch (N) {
+            case 1: hipLaunchKernelGGL((sweep_std_rig_kernel<1>), gridf, dim3(256), 0, st, feats, grids, vmask, vol, vol_split, s, dchunk_f, (int)ndf, F); break;
+            case 2: hipLaunchKernelGGL((sweep_std_rig_kernel<2>), gridf, dim3(256), 0, st, feats, grids, vmask, vol, vol_split, s, dchunk_f, (int)ndf, F); break;
+            case 3: hipLaunchKernelGGL((sweep_std_rig_kernel<3>), gridf, dim3(256), 0, st, feats, grids, vmask, vol, vol_split, s, dchunk_f, (int)ndf, F); break;
+            case 4: hipLaunchKernelGGL((sweep_std_rig_kernel<4>), gridf, dim3(256), 0, st, feats, grids, vmask, vol, vol_split, s, dchunk_f, (int)ndf, F); break;
+        }
+        return mvsgi::check_launch("mvsgi_sweep_std_nhwc_valid_f32(rig walk)");
+    }
+    const dim3 grid((unsigned)nblk), block(256);
     switch (N) {
-        case 1: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split); break;
-        case 2: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<2>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split); break;
-        case 3: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<3>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split); break;
-        case 4: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<4>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split); break;
+        case 1: if (C == 16) hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
+                else hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1, false>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
+                break;
+        case 2: if (C == 16) hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<2, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
+                else hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<2, false>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
+                break;
+        case 3: if (C == 16) hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<3, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
+                else hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<3, false>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
+                break;
+        case 4: if (C == 16) hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<4, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
+                else hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<4, false>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
+                break;
     }
     return mvsgi::check_launch("mvsgi_sweep_std_nhwc_valid_f32");
 }

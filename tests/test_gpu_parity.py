@@ -94,6 +94,25 @@ def test_sweep_seeded_bit_exact(golden_dir, name):
             assert np.array_equal(_ncdhw(H.sweep_std_valid(ft, _g(inp["grids"]), vm)), z["vol_raw"])
 
 
+@pytest.mark.parametrize("scale", [1e-19, 3e-13, 1.0, 1e16, 2e18])
+def test_sweep_masked_variance_divisions_exact_from_subnormal_to_huge(scale):
+    """The walking kernel divides by the camera count with a reciprocal + two fmas (correctly rounded for every finite
+    input) and takes the hardware division beyond 1e30: bit-equal to the oracle's torch.div with variances down in the
+    subnormals (scale 1e-19) and up past the switch (scale 2e18 -> variances ~ 1e36)."""
+    cfg = SMALL_CASES["std_d8"]["cfg"]
+    inp = synth.make_inputs(cfg, seed=11, batch=2)
+    feats = (inp["feats"].astype(np.float64) * scale).astype(np.float32)
+    want = O.sweep_std_masked(*(torch.from_numpy(np.ascontiguousarray(a)) for a in (feats, inp["grids"], inp["grid_masks"], inp["masks"]))).numpy()
+    assert np.isfinite(want).all()
+    if scale < 1e-15:
+        assert (np.abs(want[want != 0]) < 1.2e-38).any()            # some variances really are subnormal
+    g = _g(inp["grids"])
+    vm = H.sweep_validity(g, _g(inp["grid_masks"]), _g(inp["masks"]))
+    f = _g(feats)
+    for ft in (f, f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)):
+        assert np.array_equal(_ncdhw(H.sweep_std_valid(ft, g, vm)), want)
+
+
 def test_rig_constant_cache_follows_the_tensors():
     """The drop-in caches the validity byte per (grids, grid_masks, masks) identity + version: an
     in-place edit or a different tensor must be picked up, cache off must give the same volume."""
