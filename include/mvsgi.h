@@ -166,6 +166,11 @@ int mvsgi_conv3d_pack_weights_bf16x3_c16(const float* w_oidhw, void* w_packed, i
 size_t mvsgi_conv2d_packed_weight_floats(int Cout, int Cin);            /* exact-fp32 MFMA path (MVSGI_CONV_MFMA) */
 int mvsgi_conv2d_pack_weights_f32(const float* w_oihw, float* w_packed, int Cout, int Cin,
                                   mvsgi_stream_t stream);
+/* uint8 HWC camera images into the 5x5 stride-2 3 -> 16 stem (simple_feature_extractor.py:21-31 after the /255 of
+ * api/inference_class.py:104-107): weights / 255 cut into three bf16 pieces for the matrix cores.  Pass the packed buffer
+ * as w_packed of mvsgi_conv2d_f32 together with in_nchw == 2 (needs Win % 4 == 0; otherwise the LDS-tiled kernel runs). */
+size_t mvsgi_conv2d_stem_packed_weight_bytes(void);
+int mvsgi_conv2d_stem_pack_weights(const float* w_oihw, void* w_packed, mvsgi_stream_t stream);
 size_t mvsgi_conv2d_packed_weight_bytes_bf16x3(int Cout, int Cin);
 int mvsgi_conv2d_pack_weights_bf16x3(const float* w_oihw, void* w_packed, int Cout, int Cin,
                                      mvsgi_stream_t stream);

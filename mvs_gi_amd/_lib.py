@@ -46,6 +46,8 @@ SIGNATURES = {
     "mvsgi_conv3d_pack_weights_bf16x3_v32": (c_int, [_P, _P, c_int, c_int, _P]),
     "mvsgi_conv3d_packed_weight_bytes_bf16x3_c16": (c_size_t, [c_int]),
     "mvsgi_conv3d_pack_weights_bf16x3_c16": (c_int, [_P, _P, c_int, _P]),
+    "mvsgi_conv2d_stem_packed_weight_bytes": (c_size_t, []),
+    "mvsgi_conv2d_stem_pack_weights": (c_int, [_P, _P, _P]),
     "mvsgi_conv2d_packed_weight_floats": (c_size_t, [c_int, c_int]),
     "mvsgi_conv2d_pack_weights_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "mvsgi_conv2d_packed_weight_bytes_bf16x3": (c_size_t, [c_int, c_int]),

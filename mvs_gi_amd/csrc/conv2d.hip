@@ -132,6 +132,104 @@ __global__ __launch_bounds__(256) void conv2d_stem_kernel(Conv2dArgs a) {
     }
 }
 
+// The same stem for camera images (uint8 [B][H][W][3]) on the matrix cores.  An 8-bit pixel is exact in bf16, so the only
+// rounding left is in the weights: w / 255 is cut into THREE bf16 pieces (24 bits = the whole fp32 significand) and a k-step
+// is three MFMAs whose products are exact in the fp32 accumulator -- closer to the real-number result than the reference's
+// own fp32 sum.  K runs over (kernel row, byte of the row's 15-byte HWC segment): k = 16 ky + j, j = 3 kx + ch, the 16th byte
+// and the sixth row carry zero weights, so a k-step of 32 is two image rows and a lane's eight operands are eight consecutive
+// BYTES of one row.  A block computes 8 rows x 64 pixels from 19 staged rows (dword copies, whole dwords in or out of the image
+// because 3 W is a multiple of 4); A = weights (cout x k, in registers for the whole kernel), B = pixels, so a lane ends up with
+// four consecutive couts of one pixel and a wave stores a contiguous KiB.
+struct StemArgs {
+    const unsigned char* x;
+    const bf16x8* wp;          // [3 k-steps][3 pieces][64 lanes] (stem_pack_weights_kernel)
+    const float* scale;
+    const float* shift;
+    float* y;
+    int B, Hin, Win, Ho, Wo;
+    float neg_slope;
+};
+
+constexpr int kStemRows = 8, kStemCols = 64, kStemRowDw = 100;
+
+__global__ void stem_pack_weights_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // (kstep * 3 + piece) * 64 + lane
+    if (idx >= 9 * 64) return;
+    const int lane = idx & 63, piece = (idx >> 6) % 3, ks = idx / 192;
+    const int co = lane & 15, g = lane >> 4;
+    bf16x8 out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ky = 2 * ks + (g >> 1), j = 8 * (g & 1) + e;
+        float v = 0.f;
+        if (ky < 5 && j < 15) v = w[((co * 3 + j % 3) * 5 + ky) * 5 + j / 3] / 255.0f;
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        out[e] = piece == 0 ? h : piece == 1 ? m : (__bf16)r2;
+    }
+    wp[idx] = out;
+}
+
+__global__ __launch_bounds__(256) void conv2d_stem_u8_mfma_kernel(StemArgs a) {
+    __shared__ unsigned rows[(2 * kStemRows + 3) * kStemRowDw];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ox0 = blockIdx.x * kStemCols, oy0 = blockIdx.y * kStemRows, b = blockIdx.z;
+    const int rowB = a.Win * 3;
+    const int bo0 = 6 * ox0 - 6;                      // first byte of the tile's window in an image row (-6 at the left edge)
+    const int as = bo0 & ~3, phase = bo0 - as;        // aligned start; bo0 = 6 (64 t - 1) = 2 mod 4 -> phase 2
+    const unsigned char* img = a.x + (long long)b * a.Hin * rowB;
+    for (int e = tid; e < (2 * kStemRows + 3) * kStemRowDw; e += 256) {
+        const int r = e / kStemRowDw, dw = e - r * kStemRowDw;
+        const int gy = 2 * oy0 - 2 + r, byte = as + 4 * dw;
+        unsigned v = 0u;
+        if (gy >= 0 && gy < a.Hin && byte >= 0 && byte < rowB) v = *reinterpret_cast<const unsigned*>(img + (long long)gy * rowB + byte);
+        rows[e] = v;
+    }
+    bf16x8 wA[3][3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) wA[ks][pc] = a.wp[(ks * 3 + pc) * 64 + lane];
+    const int m = lane & 15, g = lane >> 4;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + 4 * g), sh = *reinterpret_cast<const f32x4*>(a.shift + 4 * g);
+    __syncthreads();
+#pragma unroll 1
+    for (int t = wave; t < kStemRows * (kStemCols / 16); t += 4) {
+        const int ry = t >> 2, px = (t & 3) * 16 + m;              // output row / pixel inside the tile
+        const int bo = phase + 6 * px + 8 * (g & 1);               // byte of the lane's eight inside a staged row
+        const int dq = bo >> 2, shb = (bo & 3) * 8;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            int ky = 2 * ks + (g >> 1);
+            ky = ky < 4 ? ky : 4;                                   // (the sixth row's weights are zero: any finite data do)
+            const unsigned* rp = rows + (2 * ry + ky) * kStemRowDw + dq;
+            const unsigned d0 = rp[0], d1 = rp[1], d2 = rp[2];
+            const unsigned lo = __builtin_amdgcn_alignbit(d1, d0, shb), hi = __builtin_amdgcn_alignbit(d2, d1, shb);
+            typedef float f2_t __attribute__((ext_vector_type(2)));
+            typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+            typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+            u4_t pk;
+            pk[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2_t{(float)(lo & 0xffu), (float)((lo >> 8) & 0xffu)}, b2_t));
+            pk[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2_t{(float)((lo >> 16) & 0xffu), (float)(lo >> 24)}, b2_t));
+            pk[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2_t{(float)(hi & 0xffu), (float)((hi >> 8) & 0xffu)}, b2_t));
+            pk[3] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2_t{(float)((hi >> 16) & 0xffu), (float)(hi >> 24)}, b2_t));
+            const bf16x8 xb = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+            for (int pc = 2; pc >= 0; --pc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[ks][pc], xb, acc, 0, 0, 0);   // small pieces first
+        }
+        const int ox = ox0 + px, oy = oy0 + ry;
+        if (ox < a.Wo && oy < a.Ho) {
+            f32x4 r = acc * sc + sh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : r[e] * a.neg_slope;
+            *reinterpret_cast<f32x4*>(a.y + (((long long)b * a.Ho + oy) * a.Wo + ox) * 16 + 4 * g) = r;
+        }
+    }
+}
+
 enum Variant2d { D2_DIRECT, D2_N16, D2_N32, D2_N64, D2_S2_N32, D2_S2_N64, D2_F32_N16, D2_F32_N32, D2_F32_S2, D2_COUNT };
 const char* const kNames2d[D2_COUNT] = {
     "conv2d_direct_kernel<4>",
@@ -180,6 +278,16 @@ extern "C" int mvsgi_conv2d_pack_weights_bf16x3(const float* w_oihw, void* w_pac
     return mvsgi::check_launch("mvsgi_conv2d_pack_weights_bf16x3");
 }
 
+// 5x5 stride-2 3 -> 16 RGB stem on uint8 images: weights / 255 in three bf16 pieces, MFMA operand order
+extern "C" size_t mvsgi_conv2d_stem_packed_weight_bytes(void) { return (size_t)9 * 64 * 16; }
+
+extern "C" int mvsgi_conv2d_stem_pack_weights(const float* w_oihw, void* w_packed, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(w_oihw && w_packed, "mvsgi_conv2d_stem_pack_weights: null pointer");
+    hipLaunchKernelGGL(stem_pack_weights_kernel, dim3(3), dim3(192), 0, mvsgi::as_stream(stream), w_oihw,
+                       reinterpret_cast<bf16x8*>(w_packed));
+    return mvsgi::check_launch("mvsgi_conv2d_stem_pack_weights");
+}
+
 extern "C" size_t mvsgi_conv2d_packed_weight_floats(int Cout, int Cin) { return (size_t)9 * (size_t)Cout * (size_t)Cin; }
 
 extern "C" int mvsgi_conv2d_pack_weights_f32(const float* w_oihw, float* w_packed, int Cout, int Cin, mvsgi_stream_t stream) {
@@ -215,6 +323,13 @@ extern "C" int mvsgi_conv2d_f32(const float* x, const float* w_oihw, const void*
         Conv2dArgs a{x, w_oihw, scale, shift, res, y, B, Cin, Hin, Win, Cout, Ho, Wo, ksize, stride, in_nchw, neg_slope};
         if (ksize == 5 && stride == 2 && Cin == 3 && Cout == 16 && in_nchw && !res && B < 65536) {
             const dim3 grid((unsigned)mvsgi::cdiv(Wo, 16), (unsigned)mvsgi::cdiv(Ho, 16), (unsigned)B);
+            if (in_nchw == 2 && w_packed && Win % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 3) == 0) {
+                StemArgs sa{reinterpret_cast<const unsigned char*>(x), reinterpret_cast<const bf16x8*>(w_packed), scale, shift, y,
+                            B, Hin, Win, Ho, Wo, neg_slope};
+                const dim3 gm((unsigned)mvsgi::cdiv(Wo, kStemCols), (unsigned)mvsgi::cdiv(Ho, kStemRows), (unsigned)B);
+                hipLaunchKernelGGL(conv2d_stem_u8_mfma_kernel, gm, dim3(256), 0, st, sa);
+                return mvsgi::check_launch("mvsgi_conv2d_f32(stem, matrix cores)");
+            }
             if (in_nchw == 2)
                 hipLaunchKernelGGL(conv2d_stem_kernel<true>, grid, dim3(256), 0, st, a);
             else

@@ -21,8 +21,11 @@ from . import common_modules as cm
 from .common_modules import NoOp, NORM2D_TYPE, RELU_TYPE, _is_identity
 
 
+_STEM_MFMA = os.environ.get("MVSGI_STEM_MFMA", "1") != "0"      # 0: the LDS-tiled VALU stem for uint8 images too
+
+
 class Conv2dLaunch:
-    __slots__ = ("w", "wp_b3", "wp_f32", "scale", "shift", "stride", "neg_slope", "k", "cin", "cout", "key")
+    __slots__ = ("w", "wp_b3", "wp_f32", "wp_stem", "scale", "shift", "stride", "neg_slope", "k", "cin", "cout", "key")
 
     def run(self, x: Tensor, res: Optional[Tensor] = None, in_nchw: bool = False) -> Tensor:
         impl, wp = H.CONV_AUTO, None
@@ -34,6 +37,10 @@ class Conv2dLaunch:
             if self.wp_f32 is None:                    # exact fp32 mode: fp32 MFMA kernel
                 self.wp_f32 = H.pack_conv2d_weights_f32(self.w)
             impl, wp = H.CONV_MFMA, self.wp_f32
+        elif x.dtype == torch.uint8 and (self.k, self.stride, self.cin, self.cout) == (5, 2, 3, 16) and _STEM_MFMA:
+            if self.wp_stem is None:                   # camera images: the stem on the matrix cores (exact pixels, 24-bit weights)
+                self.wp_stem = H.pack_conv2d_stem_weights(self.w)
+            wp = self.wp_stem
         return H.conv2d(x, self.w, wp, self.scale, self.shift, res=res, stride=self.stride,
                         neg_slope=self.neg_slope, impl=impl, in_nchw=in_nchw)
 
@@ -82,7 +89,7 @@ def lower_conv2d_block(blk) -> Conv2dLaunch:
     else:
         raise NotImplementedError(f"activation {type(act).__name__} has no HIP implementation")
     L = Conv2dLaunch()
-    L.w, L.wp_b3, L.wp_f32 = w, None, None
+    L.w, L.wp_b3, L.wp_f32, L.wp_stem = w, None, None, None
     L.scale, L.shift = scale.contiguous(), shift.contiguous()
     L.stride, L.neg_slope, L.k = int(conv.stride[0]), slope, int(k)
     L.cin, L.cout, L.key = int(w.shape[1]), int(cout), key

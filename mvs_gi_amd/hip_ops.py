@@ -466,6 +466,17 @@ def pack_conv2d_weights_bf16x3(w_oihw: torch.Tensor) -> Optional[torch.Tensor]:
     return wp
 
 
+def pack_conv2d_stem_weights(w_oihw: torch.Tensor) -> Optional[torch.Tensor]:
+    """[16, 3, 5, 5] RGB-stem weights -> the matrix-core layout for uint8 images (w / 255 in three bf16 pieces), or None."""
+    lib = _lib.load()
+    w = _dev(w_oihw, "conv weight")
+    if tuple(w.shape) != (16, 3, 5, 5):
+        return None
+    wp = torch.empty(lib.mvsgi_conv2d_stem_packed_weight_bytes(), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.mvsgi_conv2d_stem_pack_weights(w.data_ptr(), wp.data_ptr(), _stream_ptr(w)), "mvsgi_conv2d_stem_pack_weights")
+    return wp
+
+
 def pack_conv2d_weights_f32(w_oihw: torch.Tensor) -> Optional[torch.Tensor]:
     """[Cout, Cin, 3, 3] -> exact-fp32 MFMA layout (Cout in {16, 32}), or None when unsupported."""
     lib = _lib.load()

@@ -639,6 +639,31 @@ def test_conv2d_stem_5x5_nchw_input():
     assert _rel(y.permute(0, 3, 1, 2).cpu().numpy(), yref) <= 2e-5
 
 
+@pytest.mark.parametrize("hw", [(30, 52), (37, 132), (64, 256), (5, 4)])
+def test_conv2d_stem_uint8_on_the_matrix_cores(hw):
+    """uint8 HWC camera images through the 5x5 stride-2 stem: the MFMA kernel (exact pixels, w / 255 in three bf16 pieces)
+    against float64 of the reference's arithmetic (x.float() / 255 -> conv -> BN -> LeakyReLU) and against the LDS-tiled
+    fp32 kernel; ragged tile edges, a one-tile image and a batch."""
+    rng = np.random.default_rng(21)
+    Hh, Ww = hw
+    u8 = rng.integers(0, 256, (3, Hh, Ww, 3), dtype=np.uint8)
+    w = (rng.standard_normal((16, 3, 5, 5)) / np.sqrt(75)).astype(np.float32)
+    scale = (rng.random(16) + 0.5).astype(np.float32)
+    shift = (rng.standard_normal(16) * 0.1).astype(np.float32)
+    x64 = torch.from_numpy(u8).permute(0, 3, 1, 2).double() / 255.0
+    ref = F.conv2d(x64, torch.from_numpy(w).double(), None, stride=2, padding=2)
+    ref = F.leaky_relu(ref * torch.from_numpy(scale).double().view(1, -1, 1, 1) + torch.from_numpy(shift).double().view(1, -1, 1, 1), 0.01).numpy()
+    wg = _g(w)
+    wp = H.pack_conv2d_stem_weights(wg)
+    assert wp is not None
+    y_mfma = H.conv2d(_g(u8), wg, wp, _g(scale), _g(shift), stride=2).permute(0, 3, 1, 2).cpu().numpy()
+    y_valu = H.conv2d(_g(u8), wg, None, _g(scale), _g(shift), stride=2).permute(0, 3, 1, 2).cpu().numpy()
+    assert y_mfma.shape == ref.shape
+    assert _rel(y_mfma, ref) <= 5e-7            # a few fp32 ulps: exact products, fp32 accumulation
+    assert _rel(y_valu, ref) <= 5e-6
+    assert _rel(y_mfma, y_valu) <= 5e-6
+
+
 def test_feature_extractor_and_end_to_end_vs_reference(golden_dir, conv_mode):
     """SimpleFeatExtraction drop-in and the imgs -> inv_dist composition against the reference's outputs."""
     from mvs_gi_amd.configs import CONFIGS, DIST_8L
