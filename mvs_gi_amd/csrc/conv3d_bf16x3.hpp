@@ -43,8 +43,10 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kVSB = 80;      // LDS bytes per staged voxel
 
 // x = hi + lo for four fp32 values, hi = bf16(x) (RNE), lo = bf16(x - hi), packed two per dword:
-// 2 x (v_cvt_pk_bf16_f32, shift, and, v_pk_add_f32, v_cvt_pk_bf16_f32) = 10 VALU instructions
-// (converting element by element cost 16, and the producers share their SIMD's issue port with the MFMAs)
+// 2 x (v_cvt_pk_bf16_f32, shift, and, 2 v_sub_f32, v_cvt_pk_bf16_f32) VALU instructions (converting element by element
+// cost 16).  The subtraction and the blends below are SCALAR fp32 on purpose: beside the consumers' MFMAs the packed forms
+// (v_pk_add_f32 / v_pk_fma_f32, -DMVSGI_PK) are slower -- out_costs.0 2683 vs 2538 us, down.0.first 739 vs 712 us per 64 frames,
+// the step 4689 vs 4742 frames/s (tools/ab_bench.py, one box, 3 rounds; MI355X_MICROARCH.md's packed-VALU-beside-MFMA note)
 __device__ __forceinline__ void split_bf16x4(const f32x4 x, u32x2& hi, u32x2& lo) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -52,8 +54,30 @@ __device__ __forceinline__ void split_bf16x4(const f32x4 x, u32x2& hi, u32x2& lo
         const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
         const f32x2v hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
         hi[p] = hb;
+#ifndef MVSGI_PK
+        float r0 = v[0] - hf[0], r1 = v[1] - hf[1];
+        asm volatile("" : "+v"(r0));
+        asm volatile("" : "+v"(r1));
+        lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{r0, r1}, bf16x2));
+#else
         lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, bf16x2));
+#endif
     }
+}
+// a * b + c on four lanes' worth of channels: four v_fma_f32 (two v_pk_fma_f32 in the -DMVSGI_PK diagnostic build, see above)
+__device__ __forceinline__ f32x4 fma4(const f32x4 a, const f32x4 b, const f32x4 c) {
+#ifndef MVSGI_PK
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = __builtin_fmaf(a[e], b[e], c[e]);
+        asm volatile("" : "+v"(t));            // keeps the four apart
+        r[e] = t;
+    }
+    return r;
+#else
+    return __builtin_elementwise_fma(a, b, c);
+#endif
 }
 constexpr int pairs_of(int kd) { return (kd * 9 + 1) / 2; }      // KD = 3: 14 pairs of 27 taps; KD = 1 (2-D 3x3): 5 of 9
 
@@ -308,11 +332,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                 _Pragma("unroll") for (int it = 0; it < NITU; ++it) MVSGI_ISSUE_UPS1(CR, IM, it)        \
                 MVSGI_ISSUE_UPS_END()                                                                   \
             }
-#define MVSGI_LERP2(A, B, O0, O1)   /* O0 = 0.75 A + 0.25 B, O1 = 0.25 A + 0.75 B as A + f (B - A): 6 v_pk_fma_f32 */ \
+#define MVSGI_LERP2(A, B, O0, O1)   /* O0 = 0.75 A + 0.25 B, O1 = 0.25 A + 0.75 B as A + f (B - A): 12 v_fma_f32 */ \
             {                                                                                           \
-                const f32x4 d_ = __builtin_elementwise_fma((A), f32x4{-1.f, -1.f, -1.f, -1.f}, (B));   /* B - A, exact, packed */ \
-                O0 = __builtin_elementwise_fma(d_, f32x4{0.25f, 0.25f, 0.25f, 0.25f}, (A));             \
-                O1 = __builtin_elementwise_fma(d_, f32x4{0.75f, 0.75f, 0.75f, 0.75f}, (A));             \
+                const f32x4 d_ = fma4((A), f32x4{-1.f, -1.f, -1.f, -1.f}, (B));   /* B - A, exact, packed */ \
+                O0 = fma4(d_, f32x4{0.25f, 0.25f, 0.25f, 0.25f}, (A));             \
+                O1 = fma4(d_, f32x4{0.75f, 0.75f, 0.75f, 0.75f}, (A));             \
             }
 #define MVSGI_PUT_UPS1(CR, IM, DST, IT)                                                                 \
             if (HALF && (IT) == RF) {                                                                   \
@@ -324,8 +348,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                     const f32x4 f4_ = {f_, f_, f_, f_};                                                 \
                     f32x4 xd[2][2], xh[2][2], xo[2][2];                                                 \
                     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                     \
-                        const f32x4 d_ = __builtin_elementwise_fma(CR[IT][j], f32x4{-1.f, -1.f, -1.f, -1.f}, CR[IT][4 + j]); \
-                        xd[j >> 1][j & 1] = __builtin_elementwise_fma(d_, f4_, CR[IT][j]);              \
+                        const f32x4 d_ = fma4(CR[IT][j], f32x4{-1.f, -1.f, -1.f, -1.f}, CR[IT][4 + j]); \
+                        xd[j >> 1][j & 1] = fma4(d_, f4_, CR[IT][j]);              \
                     }                                                                                   \
                     _Pragma("unroll") for (int kw = 0; kw < 2; ++kw)                                    \
                         MVSGI_LERP2(xd[0][kw], xd[1][kw], xh[0][kw], xh[1][kw])                         \
