@@ -567,6 +567,17 @@ def run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, 
                 "note": "contiguous NCHW feats (the reference extractor's layout): transposed to channels-last once per step"}
     guarded("feats_nchw", nchw)
 
+    def inv_only():
+        hp.dist_regressor.return_norm_costs = False
+        try:
+            el = timed_steps(lambda: hp(feats), sync, K, W, 1, False, dev)
+        finally:
+            hp.dist_regressor.return_norm_costs = True
+        return {"frames_per_s": round(B * K / el, 2), "ms_per_step": round(el / K * 1e3, 4),
+                "note": "norm_costs not stored: the deployed callers discard it (spherical_sweep_stereo.py:266, api/inference_class.py); "
+                        "the headline stores it, as torch_only.py:30-36 returns it"}
+    guarded("inverse_distance_only", inv_only)
+
     def graph():
         hp.capture(feats)
         el = timed_steps(lambda: hp.replay(), sync, K, W, 1, False, dev)
