@@ -658,8 +658,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                 asm volatile("" : "+v"(l16));
                 if (t_ + LAW < 27) {
                     MVSGI_V_LOADW((t_ + LAW) % VWB, cc, t_ + LAW, ctc)
-                } else if (more) {
-                    MVSGI_V_LOADW((t_ + LAW - 27) % VWB, ncc, t_ + LAW - 27, ctn)    // first taps of the next unit
+                } else {
+                    MVSGI_V_LOADW((t_ + LAW - 27) % VWB, ncc, t_ + LAW - 27, ctn)    // first taps of the next unit (unconditional)
                 }
                 if (t_ + 2 < 27) { MVSGI_V_READX(nx2, t_ + 2) }
                 if (t_ == 26 && last && a.res) {
@@ -751,8 +751,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
             DST[j] = c_ < CT ? c_ : CT - 1;                                           \
         }
         bf16x8 wh[WB][NW], wl[WB][NW];
-        constexpr int XB = MW <= 4 ? 2 : 1;            // activation fragments: double-buffered when they fit
-        constexpr int MH = XB == 2 ? MW : MW / 2;      // voxel tiles per half
+        // activation fragments: double-buffered when they fit; the one-frame variants (3 or 6 MFMAs per slot, less than an
+        // LDS round trip) keep 7 / 3 slots of fragments in flight (stamps: 210 ticks per 48-cycle slot with one)
+        constexpr int XB = (KD == 3 && !PLANE && !V32 && MW * NW == 1) ? 8 : (KD == 3 && !PLANE && !V32 && MW * NW == 2) ? 4 : MW <= 4 ? 2 : 1;
+        constexpr int XLA = XB > 1 ? XB - 1 : 1;       // slots ahead
+        constexpr int MH = XB >= 2 ? MW : MW / 2;      // voxel tiles per half
         bf16x8 xh[XB][MW], xl[XB][MW];
 #define MVSGI_LOADW(BUFI, CC, P, CTS)                                                                 \
         _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                              \
@@ -781,15 +784,21 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[WBUF][j], xh[XBUF][i], acc[i][j], 0, 0, 0); \
         _Pragma("unroll") for (int i = (I0); i < (I1); ++i)                                           \
             _Pragma("unroll") for (int j = 0; j < NW; ++j)                                            \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[WBUF][j], xl[XBUF][i], acc[i][j], 0, 0, 0); \
+                (TACC ? acc1[i][j] : acc[i][j]) = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[WBUF][j], xl[XBUF][i], TACC ? acc1[i][j] : acc[i][j], 0, 0, 0); \
         _Pragma("unroll") for (int i = (I0); i < (I1); ++i)                                           \
             _Pragma("unroll") for (int j = 0; j < NW; ++j)                                            \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[WBUF][j], xh[XBUF][i], acc[i][j], 0, 0, 0);
-        f32x4 acc[MW][NW];
+                (TACC ? acc2[i][j] : acc[i][j]) = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[WBUF][j], xh[XBUF][i], TACC ? acc2[i][j] : acc[i][j], 0, 0, 0);
+        // one or two tiles per wave: the three products of a tile would sit back to back on ONE accumulator (each waits for
+        // the one before: stamps, 200 ticks per 48-cycle slot); they get an accumulator each, summed in the epilogue
+        constexpr bool TACC = KD == 3 && !PLANE && !V32 && MW * NW <= 2;
+        f32x4 acc[MW][NW], acc1[MW][NW], acc2[MW][NW];      // (acc1, acc2 dead unless TACC)
 #pragma unroll
         for (int i = 0; i < MW; ++i)
 #pragma unroll
-            for (int j = 0; j < NW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NW; ++j) {
+                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (TACC) acc1[i][j] = acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 
         int cb_, b_, od0, oh0, ow0;
         MVSGI_DECODE((int)blockIdx.x, cb_, b_, od0, oh0, ow0)
@@ -854,12 +863,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
             f32x4 esc[NW], esh[NW], rres[RPRE ? MW : 1][RPRE ? NW : 1];
             int eoff[MW];                  // in-frame element offset of (voxel, cout 4*kg) or -1 outside the volume
             int soff[MW];                  // split-padded output (a.y_split): in-frame byte offset of the voxel's record
-            if (last) {
+            // (requested in every slice, not only the last: loads under a run-time `if` make every later wait of the unit
+            // assume they were never issued, i.e. wait for younger weight fragments than needed)
 #pragma unroll
-                for (int j = 0; j < NW; ++j) {
-                    esc[j] = *reinterpret_cast<const f32x4*>(a.scale + ctc[j] * 16 + kg * 4);
-                    esh[j] = *reinterpret_cast<const f32x4*>(a.shift + ctc[j] * 16 + kg * 4);
-                }
+            for (int j = 0; j < NW; ++j) {
+                esc[j] = *reinterpret_cast<const f32x4*>(a.scale + ctc[j] * 16 + kg * 4);
+                esh[j] = *reinterpret_cast<const f32x4*>(a.shift + ctc[j] * 16 + kg * 4);
+            }
+            if (last) {
 #pragma unroll
                 for (int i = 0; i < MW; ++i) {
                     const int od = od0 + tdv[i], oh = oh0 + thv[i], ow = ow0 + twv[i];
@@ -880,8 +891,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                     asm volatile("" : "+v"(l16));
                     if (p_ + 2 < NPP) {
                         MVSGI_PL_LOADW((p_ + 2) % 3, cc, p_ + 2)
-                    } else if (p_ + 2 > NPP && more) {
-                        MVSGI_PL_LOADW(p_ + 2 - (NPP + 1), ncc, p_ + 2 - (NPP + 1))     // pairs 0, 1 of the next unit
+                    } else if (p_ + 2 > NPP) {
+                        MVSGI_PL_LOADW(p_ + 2 - (NPP + 1), ncc, p_ + 2 - (NPP + 1))     // pairs 0, 1 of the next unit (unconditional, see below)
                     }
                     if (p_ < NPP) {
                         if (p_ + 1 < NPP) {
@@ -907,18 +918,25 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
-            MVSGI_READX(0, 0, 0, MW)
+            if (XB >= 2) {
+#pragma unroll
+                for (int p0 = 0; p0 < XLA; ++p0) { MVSGI_READX(p0 % XB, p0, 0, MW) }
+            } else {
+                MVSGI_READX(0, 0, 0, MW)
+            }
 #pragma unroll
             for (int s_ = 0; s_ < NSLOT; ++s_) {
                 const int wcur = s_ % WB;
                 unsigned l16 = lane16;
                 asm volatile("" : "+v"(l16));      // keep `lane*16 + const` from being hoisted 28x out of the loop
-                const int xcur = XB == 2 ? (s_ & 1) : 0, xnxt = XB == 2 ? (xcur ^ 1) : 0;
+                const int xcur = XB >= 2 ? (s_ % XB) : 0, xnxt = XB >= 2 ? ((s_ + XLA) % XB) : 0;
                 // weight fragments LA slots ahead (this slice, or the first slots of the next unit)
                 if (!(MVSGI_ABL & 1)) {
                     if (s_ + LA < NSLOT) {
                         if (s_ + LA < kPairs) { MVSGI_LOADW((s_ + LA) % WB, cc, s_ + LA, ctc) }
-                    } else if (more) {
+                    } else {
+                        // unconditional (past the last unit: chunk 0 of this one again, unused): under `if (more)` the
+                        // compiler must assume the requests were never made and waits for far younger loads than needed
                         MVSGI_LOADW((s_ + LA - NSLOT) % WB, ncc, s_ + LA - NSLOT, ctn)
                     }
                 }
@@ -933,11 +951,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                             rres[i][j] = *reinterpret_cast<const f32x4*>(rb + (eoff[i] >= 0 ? eoff[i] + ctc[j] * 16 : 0));
                 }
                 if (s_ < kPairs) {
-                    if (XB == 2) {
-                        // one scheduling region per slot: the next slot's fragment requests (2*NW weight
+                    if (XB >= 2) {
+                        // one scheduling region per slot: the fragment requests of a later slot (2*NW weight
                         // loads, 2*MW LDS reads) are interleaved one per RATIO MFMAs, so their issue
                         // cycles hide in the MFMA gaps instead of draining the matrix pipe between slots
-                        if (s_ + 1 < kPairs && !(MVSGI_ABL & 2)) MVSGI_READX(xnxt, s_ + 1, 0, MW)
+                        if (s_ + XLA < kPairs && !(MVSGI_ABL & 2)) MVSGI_READX(xnxt, s_ + XLA, 0, MW)
                         if (!(MVSGI_ABL & 16)) { MVSGI_MFMAS(wcur, xcur, 0, MW) }
                         constexpr int NMEM = 2 * NW + 2 * MW, NMFMA = 3 * MW * NW;
                         constexpr int RATIO = NMFMA / NMEM > 0 ? NMFMA / NMEM : 1;
@@ -981,6 +999,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                 for (int i = 0; i < MW; ++i) {
 #pragma unroll
                     for (int j = 0; j < NW; ++j) {
+                        if (TACC) acc[i][j] = (acc[i][j] + acc1[i][j]) + acc2[i][j];    // small terms first
                         f32x4 r = acc[i][j] * esc[j] + esh[j];
                         if (a.res) r += RPRE ? rres[RPRE ? i : 0][RPRE ? j : 0] : rl[RPRE ? 0 : i][RPRE ? 0 : j];
 #pragma unroll
@@ -997,6 +1016,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                             }
                         } else if (eoff[i] >= 0 && ct0 + j < CT) *reinterpret_cast<f32x4*>(yb + eoff[i] + (ct0 + j) * 16) = r;
                         acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (TACC) acc1[i][j] = acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
                 k += 1;
