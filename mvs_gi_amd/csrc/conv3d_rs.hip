@@ -262,32 +262,35 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     // The walk: logical ids id0 + k * step (XCD-contiguous remap, cdna_hip_programming.md T1; G % 8 == 0 or G == total)
     const int id0 = rs_xcd_remap((int)blockIdx.x, total);
     const int step = G == total ? 0 : G >> 3;
+    // logical order (b, oh, od, ow), ow fastest: the bricks stacked along D share two of their four / six input planes and
+    // follow each other within one XCD round (tiles_w ids apart), the bricks above / below a round or two later -- in the
+    // (b, od, oh, ow) order the D neighbours were tiles_h * tiles_w ids (several L2 capacities) apart
     const int sw = step % a.tiles_w;
     int tq = step / a.tiles_w;
-    const int sh_ = tq % a.tiles_h;
-    tq /= a.tiles_h;
-    const int sd = tq % a.tiles_d, sb = tq / a.tiles_d;
+    const int sd = tq % a.tiles_d;
+    tq /= a.tiles_d;
+    const int sh_ = tq % a.tiles_h, sb = tq / a.tiles_h;
     RsUnit c2{0, 0, 0, 0}, c1{0, 0, 0, 0}, c0, nx;
     {
         int t_ = id0;
         c0.ow = t_ % a.tiles_w;
         t_ /= a.tiles_w;
-        c0.oh = t_ % a.tiles_h;
-        t_ /= a.tiles_h;
         c0.od = t_ % a.tiles_d;
-        c0.b = t_ / a.tiles_d;
+        t_ /= a.tiles_d;
+        c0.oh = t_ % a.tiles_h;
+        c0.b = t_ / a.tiles_h;
     }
 // tile coordinates of the next brick of the walk: mixed-radix add, no division
 #define RS_STEP(DST, SRC)                                                      \
     {                                                                          \
         int w_ = SRC.ow + sw, c_ = w_ >= a.tiles_w;                            \
         DST.ow = w_ - (c_ ? a.tiles_w : 0);                                    \
-        int h_ = SRC.oh + sh_ + c_;                                            \
-        c_ = h_ >= a.tiles_h;                                                  \
-        DST.oh = h_ - (c_ ? a.tiles_h : 0);                                    \
         int d_ = SRC.od + sd + c_;                                             \
         c_ = d_ >= a.tiles_d;                                                  \
         DST.od = d_ - (c_ ? a.tiles_d : 0);                                    \
+        int h_ = SRC.oh + sh_ + c_;                                            \
+        c_ = h_ >= a.tiles_h;                                                  \
+        DST.oh = h_ - (c_ ? a.tiles_h : 0);                                    \
         DST.b = SRC.b + sb + c_;                                               \
     }
     RS_STEP(nx, c0)
@@ -558,31 +561,34 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
     const int n = (total - (int)blockIdx.x + G - 1) / G;
     const int id0 = rs_xcd_remap((int)blockIdx.x, total);
     const int step = G == total ? 0 : G >> 3;
+    // logical order (b, oh, od, ow), ow fastest: the bricks stacked along D share two of their four / six input planes and
+    // follow each other within one XCD round (tiles_w ids apart), the bricks above / below a round or two later -- in the
+    // (b, od, oh, ow) order the D neighbours were tiles_h * tiles_w ids (several L2 capacities) apart
     const int sw = step % a.tiles_w;
     int tq = step / a.tiles_w;
-    const int sh_ = tq % a.tiles_h;
-    tq /= a.tiles_h;
-    const int sd = tq % a.tiles_d, sb = tq / a.tiles_d;
+    const int sd = tq % a.tiles_d;
+    tq /= a.tiles_d;
+    const int sh_ = tq % a.tiles_h, sb = tq / a.tiles_h;
     RsUnit c1{0, 0, 0, 0}, c0, nx;
     {
         int t_ = id0;
         c0.ow = t_ % a.tiles_w;
         t_ /= a.tiles_w;
-        c0.oh = t_ % a.tiles_h;
-        t_ /= a.tiles_h;
         c0.od = t_ % a.tiles_d;
-        c0.b = t_ / a.tiles_d;
+        t_ /= a.tiles_d;
+        c0.oh = t_ % a.tiles_h;
+        c0.b = t_ / a.tiles_h;
     }
 #define RS16_STEP(DST, SRC)                                                    \
     {                                                                          \
         int w_ = SRC.ow + sw, c_ = w_ >= a.tiles_w;                            \
         DST.ow = w_ - (c_ ? a.tiles_w : 0);                                    \
-        int h_ = SRC.oh + sh_ + c_;                                            \
-        c_ = h_ >= a.tiles_h;                                                  \
-        DST.oh = h_ - (c_ ? a.tiles_h : 0);                                    \
         int d_ = SRC.od + sd + c_;                                             \
         c_ = d_ >= a.tiles_d;                                                  \
         DST.od = d_ - (c_ ? a.tiles_d : 0);                                    \
+        int h_ = SRC.oh + sh_ + c_;                                            \
+        c_ = h_ >= a.tiles_h;                                                  \
+        DST.oh = h_ - (c_ ? a.tiles_h : 0);                                    \
         DST.b = SRC.b + sb + c_;                                               \
     }
     RS16_STEP(nx, c0)
