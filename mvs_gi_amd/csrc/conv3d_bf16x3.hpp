@@ -253,6 +253,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
 #define STAMP()
 #endif
 
+// digit order of a unit id above the w-tile: D before H (bricks stacked along D share halo planes and stay an XCD round apart)
+// or, in the -DMVSGI_ORDER_HD diagnostic build, H before D (round 1's order)
+#ifdef MVSGI_ORDER_HD
+#define MVSGI_DECODE_DH(T, OD, OH, B) { OH = (T % a.tiles_h) * TH; T /= a.tiles_h; OD = (T % a.tiles_d) * TD; B = T / a.tiles_d; }
+#else
+#define MVSGI_DECODE_DH(T, OD, OH, B) { OD = (T % a.tiles_d) * TD; T /= a.tiles_d; OH = (T % a.tiles_h) * TH; B = T / a.tiles_h; }
+#endif
 #define MVSGI_DECODE(ID, CB, B, OD, OH, OW)                       \
     {                                                             \
         int t_ = xcd_remap((ID), total);                          \
@@ -260,10 +267,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
         t_ /= ny;                                                 \
         OW = (t_ % a.tiles_w) * TW;                               \
         t_ /= a.tiles_w;                                          \
-        OH = (t_ % a.tiles_h) * TH;                               \
-        t_ /= a.tiles_h;                                          \
-        OD = (t_ % a.tiles_d) * TD;                               \
-        B = t_ / a.tiles_d;                                       \
+        MVSGI_DECODE_DH(t_, OD, OH, B)                            \
     }
 
     if (producer) {
