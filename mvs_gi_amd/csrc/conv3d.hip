@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void conv3d_head_kernel(ConvArgs a, int dchunk
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
-    int t = blockIdx.x;
+    int t = xcd_remap((int)blockIdx.x, (int)gridDim.x);     // an XCD owns a contiguous run of windows: neighbours' halo rows / columns hit its L2
     const int tw_i = t % a.tiles_w;
     t /= a.tiles_w;
     const int th_i = t % a.tiles_h;
