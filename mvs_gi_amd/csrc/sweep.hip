@@ -614,194 +614,6 @@ __global__ __launch_bounds__(256) void sweep_std_nhwc_v_kernel(const float* __re
     }
 }
 
-// One rig for the whole batch (C == 16): the taps of a voxel are the same in every frame, so a block owns 64 wo of one
-// output row and walks `dchunk` candidates x F FRAMES -- grid point -> taps once per candidate, then frame after frame
-// through the same taps.  The twelve gathers roll: as soon as a camera's four texels are consumed, the same registers are
-// re-loaded from the next frame's image (soffset = frame / camera), so a wave keeps 4 N loads in flight through the
-// variance, the bf16 split and the stores of the frame before (which are younger than the loads it waits for next).
-// One descriptor spans the block's F frames; a tap outside its image carries an offset beyond any record.
-// Logical block order (frame-chunk, ho, d-chunk, w-tile), XCD-contiguous.
-template <int NCAM>
-__global__ __launch_bounds__(256) void sweep_std_rig_kernel(const float* __restrict__ feats, const float* __restrict__ grids,
-                                                            const unsigned char* __restrict__ vmask, float* __restrict__ vol,
-                                                            unsigned char* __restrict__ vol_split, SweepDims s, int dchunk,
-                                                            int nd, int F) {
-#pragma clang fp contract(off)
-    static_assert(NCAM <= 4, "one camera per lane of a quad");
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    const int q = threadIdx.x & 3;
-    const int WT = (s.Wo + 63) >> 6;
-    int L = sweep_xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int wt = L % WT;
-    L /= WT;
-    const int dc = L % nd;
-    L /= nd;
-    const int ho = L % s.Ho;
-    const int b0 = (L / s.Ho) * F;
-    const int nf = b0 + F < s.B ? F : s.B - b0;
-    int wo = wt * 64 + (threadIdx.x >> 2);
-    const bool live = wo < s.Wo;
-    if (!live) wo = s.Wo - 1;            // keep whole quads alive for the DPP broadcasts
-    const int d0 = dc * dchunk;
-    const int d1 = d0 + dchunk < s.D ? d0 + dchunk : s.D;
-    const int HWi = s.Hi * s.Wi;
-    const long long HW = (long long)s.Ho * s.Wo;
-    const unsigned imgB = (unsigned)HWi * 64u;
-    const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(feats + (long long)b0 * NCAM * HWi * 16), 0, (int)(nf * NCAM * imgB), 0x00020000);
-    const int mycam = q < NCAM ? q : NCAM - 1;
-    const float2* gp = reinterpret_cast<const float2*>(grids) + ((long long)mycam * s.D + d0) * HW + (long long)ho * s.Wo + wo;
-    const unsigned char* vp = vmask + (long long)d0 * HW + (long long)ho * s.Wo + wo;
-    float* out = vol ? vol + ((((long long)b0 * s.D + d0) * s.Ho + ho) * s.Wo + wo) * 16 + q * 4 : nullptr;
-    const long long vstep = HW * 16, vframe = (long long)s.D * HW * 16;
-    unsigned char* outs = vol_split ? vol_split + ((((long long)b0 * (s.D + 2) + d0 + 1) * (s.Ho + 2) + ho + 1) * (s.Wo + 2) + wo + 1) * 64 +
-                                          (q >> 1) * 16 + (q & 1) * 8
-                                    : nullptr;
-    const long long sstep = (long long)(s.Ho + 2) * (s.Wo + 2) * 64, sframe = (long long)(s.D + 2) * sstep;
-    const int rowB = s.Wi * 64;
-
-    float2 gxy = *gp;
-    unsigned vm = *vp;
-#pragma unroll 1
-    for (int d = d0; d < d1; ++d) {
-        const long long nx = d + 1 < d1 ? HW : 0;           // the next candidate's grid point, not needed for F frames
-        const float2 gN = gp[nx];
-        const unsigned vN = vp[nx];
-        const Bilin mine = bilin_setup_bytes(gxy.x, gxy.y, s.Wi, s.Hi, 64, rowB);
-        Bilin ft[NCAM];
-        ft[0] = quad_bcast<0>(mine);
-        if (NCAM > 1) ft[NCAM > 1 ? 1 : 0] = quad_bcast<1>(mine);
-        if (NCAM > 2) ft[NCAM > 2 ? 2 : 0] = quad_bcast<2>(mine);
-        if (NCAM > 3) ft[NCAM > 3 ? 3 : 0] = quad_bcast<3>(mine);
-        int off[NCAM][4];
-        bool val[NCAM];
-        f32x2_t VF[NCAM];
-        float n = 0.0f;
-#pragma unroll
-        for (int cam = 0; cam < NCAM; ++cam) {
-            off[cam][0] = ft[cam].o00 + q * 16;
-            off[cam][1] = ft[cam].o01 + q * 16;
-            off[cam][2] = ft[cam].o10 + q * 16;
-            off[cam][3] = ft[cam].o11 + q * 16;
-            val[cam] = ((vm >> cam) & 1u) != 0;
-            const float vf = val[cam] ? 1.0f : 0.0f;
-            VF[cam] = f32x2_t{vf, vf};
-            n = n + vf;
-        }
-        const bool ok = n > 1.0f;
-        const float cnt = ok ? n : 1.0f;
-        const float inv = cnt == 2.0f ? 0.5f : cnt == 3.0f ? 0x1.555556p-2f : cnt == 4.0f ? 0.25f : 1.0f;   // RN(1 / cnt)
-        const f32x2_t INV = {inv, inv}, NCNT = {-cnt, -cnt};
-        f32x4_t tx[NCAM][4];
-#pragma unroll
-        for (int cam = 0; cam < NCAM; ++cam)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                tx[cam][t] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(img, off[cam][t], cam * imgB, 0));
-        float* o = out;
-        unsigned char* os = outs;
-        // a frame's result is stored one trip later, BEFORE the gathers re-issued there: the wait for those gathers then
-        // never waits for a store younger than them (loads and stores retire through one in-order counter)
-        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-        u32x4_t pend = {0u, 0u, 0u, 0u};
-        auto store_pending = [&]() {
-            if (os) {
-                if (live) {
-                    *reinterpret_cast<uint2*>(os) = make_uint2(pend[0], pend[1]);
-                    *reinterpret_cast<uint2*>(os + 32) = make_uint2(pend[2], pend[3]);
-                }
-                os += sframe;
-            } else {
-                if (live) *reinterpret_cast<u32x4_t*>(o) = pend;
-                o += vframe;
-            }
-        };
-#pragma unroll 1
-        for (int f = 0; f < nf; ++f) {
-            const unsigned fnext = (unsigned)(f + 1 < nf ? f + 1 : f) * NCAM * imgB;     // (the last frame re-reads itself)
-            f32x2_t sv[NCAM][2];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (f > 0) store_pending();
-#pragma unroll
-            for (int cam = 0; cam < NCAM; ++cam) {
-                const f32x2_t W00 = {ft[cam].w00, ft[cam].w00}, W01 = {ft[cam].w01, ft[cam].w01};
-                const f32x2_t W10 = {ft[cam].w10, ft[cam].w10}, W11 = {ft[cam].w11, ft[cam].w11};
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const f32x2_t i00 = {tx[cam][0][2 * p], tx[cam][0][2 * p + 1]}, i01 = {tx[cam][1][2 * p], tx[cam][1][2 * p + 1]};
-                    const f32x2_t i10 = {tx[cam][2][2 * p], tx[cam][2][2 * p + 1]}, i11 = {tx[cam][3][2 * p], tx[cam][3][2 * p + 1]};
-                    sv[cam][p] = ((i00 * W00 + i01 * W01) + i10 * W10) + i11 * W11;          // backports.py:86, left to right
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    tx[cam][t] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(img, off[cam][t], fnext + cam * imgB, 0));
-            }
-            // spherical_sweep_avg.py:106-125 on channel pairs; the divisions as in sweep_std_nhwc_v_kernel
-            f32x2_t sum[2], var[2];
-            f32x4_t r;
-            float big = 0.0f;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                sum[p] = sv[0][p] * VF[0];
-#pragma unroll
-                for (int cam = 1; cam < NCAM; ++cam) sum[p] = sum[p] + sv[cam][p] * VF[cam];
-                const f32x2_t qa = sum[p] * INV;
-                const f32x2_t avg = __builtin_elementwise_fma(__builtin_elementwise_fma(NCNT, qa, sum[p]), INV, qa);
-#pragma unroll
-                for (int cam = 0; cam < NCAM; ++cam) {
-                    const f32x2_t t = {val[cam] ? sv[cam][p].x : avg.x, val[cam] ? sv[cam][p].y : avg.y};
-                    const f32x2_t df = t - avg;
-                    var[p] = cam == 0 ? df * df : var[p] + df * df;
-                }
-                const f32x2_t qv = var[p] * INV;
-                const f32x2_t v = __builtin_elementwise_fma(__builtin_elementwise_fma(NCNT, qv, var[p]), INV, qv);
-                r[2 * p] = ok ? v.x : 0.0f;
-                r[2 * p + 1] = ok ? v.y : 0.0f;
-                big = __builtin_fmaxf(__builtin_fmaxf(big, __builtin_fmaxf(__builtin_fabsf(sum[p].x), __builtin_fabsf(sum[p].y))),
-                                      __builtin_fmaxf(var[p].x, var[p].y));
-            }
-            if (__builtin_amdgcn_ballot_w64(big > 1e30f) != 0) {                 // wave-uniform, never taken on real features
-                float dv = cnt;
-                asm volatile("; exact-division path" : "+v"(dv));
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float sm = sum[k >> 1][k & 1];
-                    const float avg = sm / dv;
-                    float vr = 0.0f;
-#pragma unroll
-                    for (int cam = 0; cam < NCAM; ++cam) {
-                        const float t = val[cam] ? sv[cam][k >> 1][k & 1] : avg;
-                        const float df = t - avg;
-                        vr = vr + df * df;
-                    }
-                    vr = vr / dv;
-                    r[k] = ok ? vr : 0.0f;
-                }
-            }
-            if (os) {
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
-                    const f32x2_t v = {r[2 * p], r[2 * p + 1]};
-                    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2_t));
-                    const f32x2_t hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
-                    pend[p] = hb;
-                    pend[2 + p] = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, b2_t));
-                }
-            } else {
-                pend = __builtin_bit_cast(u32x4_t, r);
-            }
-        }
-        store_pending();
-        gxy = gN;
-        vm = vN;
-        gp += HW;
-        vp += HW;
-        if (out) out += vstep;
-        if (outs) outs += sstep;
-    }
-}
-
 // grid = ceil(Wo / 64) * N * D * Ho * B blocks (flat), logical order (b, ho, d, cam, w-tile)
 __global__ __launch_bounds__(256) void sweep_cat_nhwc_kernel(const float* __restrict__ feats,
                                                              const float* __restrict__ grids,
@@ -978,25 +790,6 @@ int sweep_std_nhwc_valid_impl(const float* feats, const float* grids, const unsi
     MVSGI_REQUIRE((long long)Hi * Wi * C < (1ll << 29) && (long long)Wi * C * 4 < (1ll << 23) && nblk < (1ll << 31),
                   "mvsgi_sweep_std_nhwc_valid_f32: dimensions exceed the launch geometry (image bytes < 2^31, row bytes < 2^23)");
     hipStream_t st = mvsgi::as_stream(stream);
-    static const bool rig_walk = getenv("MVSGI_SWEEP_RIG_WALK") && atoi(getenv("MVSGI_SWEEP_RIG_WALK")) != 0;   // measured slower: off
-    if (rig_shared && C == 16 && B >= 2 && rig_walk) {
-        // one rig for the batch: blocks walk F frames per candidate through the same taps (sweep_std_rig_kernel)
-        int F = B < 8 ? B : 8;
-        while (F > 1 && (long long)F * N * Hi * Wi * 64 >= (1ll << 31)) --F;
-        const long long rows_f = mvsgi::cdiv(Wo, 64) * Ho * mvsgi::cdiv(B, F);
-        long long ndf = rows_f >= 4096 ? 1 : mvsgi::cdiv(4096, rows_f);
-        if (ndf > D) ndf = D;
-        const int dchunk_f = (int)mvsgi::cdiv(D, ndf);
-        ndf = mvsgi::cdiv(D, dchunk_f);
-        const dim3 gridf((unsigned)(rows_f * ndf));
-        switch (N) {
-            case 1: hipLaunchKernelGGL((sweep_std_rig_kernel<1>), gridf, dim3(256), 0, st, feats, grids, vmask, vol, vol_split, s, dchunk_f, (int)ndf, F); break;
-            case 2: hipLaunchKernelGGL((sweep_std_rig_kernel<2>), gridf, dim3(256), 0, st, feats, grids, vmask, vol, vol_split, s, dchunk_f, (int)ndf, F); break;
-            case 3: hipLaunchKernelGGL((sweep_std_rig_kernel<3>), gridf, dim3(256), 0, st, feats, grids, vmask, vol, vol_split, s, dchunk_f, (int)ndf, F); break;
-            case 4: hipLaunchKernelGGL((sweep_std_rig_kernel<4>), gridf, dim3(256), 0, st, feats, grids, vmask, vol, vol_split, s, dchunk_f, (int)ndf, F); break;
-        }
-        return mvsgi::check_launch("mvsgi_sweep_std_nhwc_valid_f32(rig walk)");
-    }
     const dim3 grid((unsigned)nblk), block(256);
     switch (N) {
         case 1: if (C == 16) hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
