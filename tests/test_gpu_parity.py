@@ -639,7 +639,7 @@ def test_conv2d_stem_5x5_nchw_input():
     assert _rel(y.permute(0, 3, 1, 2).cpu().numpy(), yref) <= 2e-5
 
 
-@pytest.mark.parametrize("hw", [(30, 52), (37, 132), (64, 256), (5, 4)])
+@pytest.mark.parametrize("hw", [(30, 52), (37, 132), (64, 256), (5, 4), (21, 30)])      # W = 30: not a multiple of 4 -> the fp32 stem
 def test_conv2d_stem_uint8_on_the_matrix_cores(hw):
     """uint8 HWC camera images through the 5x5 stride-2 stem: the MFMA kernel (exact pixels, w / 255 in three bf16 pieces)
     against float64 of the reference's arithmetic (x.float() / 255 -> conv -> BN -> LeakyReLU) and against the LDS-tiled
