@@ -221,7 +221,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
     // that every register-buffer index is a compile-time constant.
     // One or two tiles per wave (the one-frame variants): a slot is 3-6 MFMAs, far less than an L2 round trip, so the
     // fragments of (nearly) a whole slice are kept in flight -- 16 / 8 buffers instead of 4.
-    constexpr int WB = (KD == 3 && !PLANE && !V32 && MW * NW == 1) ? 16 : (KD == 3 && !PLANE && !V32 && MW * NW == 2) ? 8 : NW <= 2 ? 4 : 2;
+    constexpr int WB = (KD == 3 && !PLANE && !V32 && MW * NW == 1) ? 16 : (KD == 3 && !PLANE && !V32 && MW * NW == 2) ? 8 :
+#ifndef MVSGI_WBX
+#define MVSGI_WBX 5      // five buffers (four slots ahead) for the 2 x 4-tile variants: 214 + 16 registers; measured against 4 and 6
+#endif
+                       (KD == 3 && !PLANE && !V32 && NW == 2 && MW == 4) ? MVSGI_WBX :
+                       NW <= 2 ? 4 : 2;
     constexpr int LA = WB - 1;
     constexpr int NSLOT = ((kPairs + WB - 1) / WB) * WB;
     static_assert(NSLOT % WB == 0 && NSLOT >= kPairs, "pipeline geometry");
