@@ -127,23 +127,41 @@ __global__ __launch_bounds__(256) void conv3d_head_kernel(ConvArgs a, int dchunk
         for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
 
     int p = p0, cs = 0;
+    // A finished output is stored at the START of the next step, ahead of that step's loads: loads and stores retire through
+    // one in-order counter, so a store issued behind the loads a step waits for would put its own round trip on the path.
+    float pend = 0.f;
+    long long pend_vox = -1;
     for (int u = 0; u < U; ++u) {
         int ncs = cs + 1, np = p;
         if (ncs == nchunks) { ncs = 0; np = p + 1; }
         const f32x4 w0 = n < 27 ? wa[0] : f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4 w1 = n < 27 ? wa[1] : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 cx[TPW][2];
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) {
+            cx[k][0] = ok[k] ? xr[k][0] : f32x4{0.f, 0.f, 0.f, 0.f};
+            cx[k][1] = ok[k] ? xr[k][1] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (pend_vox >= 0) {
+            a.y[pend_vox] = pend;
+            pend_vox = -1;
+        }
+        {   // the next unit's operands, requested before this unit is multiplied (past the end: this unit again, unused);
+            // unconditional, so that every wait behind it is counted exactly
+            const int fp = u + 1 < U ? np : p, fcs = u + 1 < U ? ncs : cs;
+            MVSGI_HEAD_FETCH(fp, fcs)
+        }
 #pragma unroll
         for (int k = 0; k < TPW; ++k) {
             if (wave + 4 * k < NT) {                 // wave-uniform
-                const f32x4 x0 = ok[k] ? xr[k][0] : f32x4{0.f, 0.f, 0.f, 0.f};
-                const f32x4 x1 = ok[k] ? xr[k][1] : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 x0 = cx[k][0];
+                const f32x4 x1 = cx[k][1];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j], x0[j], acc[k], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[j], x1[j], acc[k], 0, 0, 0);
             }
         }
-        if (u + 1 < U) MVSGI_HEAD_FETCH(np, ncs)      // in flight during the reduction below
         if (ncs == 0) {
             // P of plane p: lane (n, h) holds rows (i / 4) * 8 + 4 * h + i % 4 of voxel T * 32 + n
 #pragma unroll
@@ -171,7 +189,8 @@ __global__ __launch_bounds__(256) void conv3d_head_kernel(ConvArgs a, int dchunk
                 const long long vox = (((long long)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
                 float r = run[0] * sc + sh;
                 if (a.res) r += a.res[vox];
-                a.y[vox] = r > 0.f ? r : r * a.neg_slope;
+                pend = r > 0.f ? r : r * a.neg_slope;
+                pend_vox = vox;
             }
             run[0] = run[1];
             run[1] = run[2];
@@ -181,6 +200,7 @@ __global__ __launch_bounds__(256) void conv3d_head_kernel(ConvArgs a, int dchunk
         p = np;
         cs = ncs;
     }
+    if (pend_vox >= 0) a.y[pend_vox] = pend;
     if (p1 < od_end && inside) {                     // the last plane of the volume: no plane behind it
         const long long vox = (((long long)b * a.Do + p1) * a.Ho + oh) * a.Wo + ow;
         float r = run[0] * sc + sh;
