@@ -15,6 +15,8 @@ from torch import nn, Tensor
 import os
 import weakref
 
+import torch
+
 from .. import hip_ops as H
 from . import common_modules as cm
 from .common_modules import NORM3D_TYPE, RELU_TYPE
@@ -89,6 +91,10 @@ def cat_sweep_ndhwc(feats, grids) -> Tensor:
 
 
 _USE_RS = os.environ.get("MVSGI_RS", "1") != "0"
+# frames per sweep -> post_vol chunk (0: the whole batch at once): a chunk's split-padded vol_raw is written by the sweep and read
+# straight back by post_vol, and the buffer is 16 frames instead of B.  4763 -> 4835 frames/s at B=64 (chunks of 4: 4845;
+# tools/ab_bench.py, one box, 3 rounds); the same chunking of out_costs.0 -> head measured slower (4769 -> 4667)
+_FRONT_CHUNK = int(os.environ.get("MVSGI_FRONT_CHUNK", "16"))
 _RS_MIN_UNITS = int(os.environ.get("MVSGI_RS_MIN_UNITS", "0"))      # measured faster down to one frame (B=1: 16.9 vs 24.2 us, 23.5 vs 32.2 us)
 
 
@@ -99,6 +105,17 @@ def std_forward(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: T
         B, D, Ho, Wo = feats.shape[0], grids.shape[2], grids.shape[3], grids.shape[4]
         if B * ((D + 3) // 4) * ((Ho + 3) // 4) * ((Wo + 15) // 16) >= _RS_MIN_UNITS:
             # sweep -> split-padded vol_raw -> register-stationary post_vol (csrc/conv3d_rs.hip) -> fp32 vol
+            k = _FRONT_CHUNK
+            shared = all(t.dim() > 0 and t.shape[0] > 1 and t.stride(0) == 0 for t in (grids, grid_masks, masks))
+            if k > 0 and B > k and shared:
+                # frames in chunks of k: a chunk's split-padded vol_raw (k x 30 MB) is written by the sweep and read straight back
+                # by post_vol while much of it is still in the 256 MB memory-side cache; the buffer is k frames, not B
+                y = torch.empty((B, D, Ho, Wo, 16), device=feats.device, dtype=torch.float32)
+                for i in range(0, B, k):
+                    j = min(i + k, B)
+                    vs = std_sweep_ndhwc(feats[i:j], grids, grid_masks, masks, owner=self, split_out=True)    # the rig tensors whole: cache identity
+                    H.conv3d_rs16(vs, L._wp_rs(), L.scale, L.shift, neg_slope=L.neg_slope, out=y[i:j])
+                return cm._to_ncdhw_view(y)
             vs = std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=self, split_out=True)
             if vs is not None:
                 return cm._to_ncdhw_view(H.conv3d_rs16(vs, L._wp_rs(), L.scale, L.shift, neg_slope=L.neg_slope))

@@ -1014,6 +1014,14 @@ def test_full_size_batch8_register_stationary_path_vs_reference_golden(golden_di
         hp = HotPath(cfg, synth.make_weights(cfg, seed=case["seed"], gain=gain), inp, device=DEV)
         inv = hp(_g(inp["feats"]).expand(8, -1, -1, -1, -1).contiguous())[0]
         assert "_mvsgi_rs_bufs" in hp.cv_regulator.down_blks[0].__dict__
+        # the sweep -> post_vol front end in chunks of frames (bench.py's B=64 runs chunks of 16): same bits
+        from mvs_gi_amd.dropin import cost_volume_builder as cvb_mod
+        old_chunk, cvb_mod._FRONT_CHUNK = cvb_mod._FRONT_CHUNK, 3
+        try:
+            inv_c = hp(_g(inp["feats"]).expand(8, -1, -1, -1, -1).contiguous())[0]
+        finally:
+            cvb_mod._FRONT_CHUNK = old_chunk
+        assert torch.equal(inv_c, inv)
         ref = z[f"inv_dist_g{gain:g}"]
         got = inv.cpu().numpy()
         for f in (0, 7):
