@@ -131,7 +131,27 @@ class ConvProbe:
         self.orig_rs16 = H.conv3d_rs16
         self.orig_os = H.conv3d_out_split
         self.records = []
+        self.hbm_records = []      # (kernel name, algorithmic bytes, start event, end event): the HBM-bound launches
+        self.hbm_orig = {}
         self.enabled = False
+
+    def _wrap_hbm(self, fname, describe):
+        """Event pair around H.<fname>; describe(args, kwargs, result) -> (kernel name, algorithmic bytes)."""
+        H, torch = self.H, self.torch
+        orig = getattr(H, fname)
+        self.hbm_orig[fname] = orig
+
+        def probed(*a, **k):
+            if not self.enabled:
+                return orig(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig(*a, **k)
+            e.record()
+            name, nbytes = describe(a, k, r)
+            self.hbm_records.append((name, float(nbytes), s, e))
+            return r
+        setattr(H, fname, probed)
 
     def __enter__(self):
         H, torch = self.H, self.torch
@@ -146,7 +166,8 @@ class ConvProbe:
             y = self.orig(x, w_oidhw, w_packed, scale, shift, res, stride, neg_slope, impl, out)
             e.record()
             vox = y.numel() // Cout
-            self.records.append((H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, impl), 2.0 * 27 * Cin * Cout * vox, s, e))
+            self.records.append((H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, impl), 2.0 * 27 * Cin * Cout * vox, s, e,
+                                 4.0 * (x.numel() + y.numel() * (2 if res is not None else 1))))
             return y
 
         def probed_up2(x, w_packed_b3, scale, shift, res=None, neg_slope=0.01, out=None, w_layout=H.CONV_BF16X3):
@@ -159,7 +180,8 @@ class ConvProbe:
             y = self.orig_up2(x, w_packed_b3, scale, shift, res, neg_slope, out, w_layout)
             e.record()
             vox = y.numel() // Cout
-            self.records.append((H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, w_layout), 2.0 * 27 * Cin * Cout * vox, s, e))
+            self.records.append((H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, w_layout), 2.0 * 27 * Cin * Cout * vox, s, e,
+                                 4.0 * (x.numel() + y.numel() * (2 if res is not None else 1))))
             return y
 
         def probed_rs(x, w_packed_rs, scale, shift, res=None, neg_slope=0.01, out=None, out_f32=False):
@@ -169,8 +191,9 @@ class ConvProbe:
             s.record()
             y = self.orig_rs(x, w_packed_rs, scale, shift, res, neg_slope, out, out_f32)
             e.record()
+            nv = x.B * x.D * x.H * x.W
             self.records.append(("conv3d_rs32_kernel<%s>" % ("true" if out_f32 else "false"),
-                                 2.0 * 27 * x.C * scale.numel() * x.B * x.D * x.H * x.W, s, e))
+                                 2.0 * 27 * x.C * scale.numel() * nv, s, e, 4.0 * nv * (x.C + scale.numel() * (2 if res is not None else 1))))
             return y
 
         def probed_os(x, w_packed_b3, scale, shift, out, res=None, stride=1, neg_slope=0.01):
@@ -183,7 +206,8 @@ class ConvProbe:
             y = self.orig_os(x, w_packed_b3, scale, shift, out, res, stride, neg_slope)
             e.record()
             self.records.append((H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3) + " [split-padded out]",
-                                 2.0 * 27 * Cin * Cout * out.B * out.D * out.H * out.W, s, e))
+                                 2.0 * 27 * Cin * Cout * out.B * out.D * out.H * out.W, s, e,
+                                 4.0 * (x.numel() + out.B * out.D * out.H * out.W * Cout * (2 if res is not None else 1))))
             return y
 
         def probed_rs16(x, w_packed_rs, scale, shift, neg_slope=0.01, out=None):
@@ -193,7 +217,7 @@ class ConvProbe:
             s.record()
             y = self.orig_rs16(x, w_packed_rs, scale, shift, neg_slope, out)
             e.record()
-            self.records.append(("conv3d_rs16_kernel", 2.0 * 27 * 16 * 16 * x.B * x.D * x.H * x.W, s, e))
+            self.records.append(("conv3d_rs16_kernel", 2.0 * 27 * 16 * 16 * x.B * x.D * x.H * x.W, s, e, 4.0 * 32 * x.B * x.D * x.H * x.W))
             return y
 
         H.conv3d = probed
@@ -201,6 +225,60 @@ class ConvProbe:
         H.conv3d_rs16 = probed_rs16
         H.conv3d_rs = probed_rs
         H.conv3d_out_split = probed_os
+
+        # ---- the HBM-bound launches of the path (K1 sweep, K4 soft-argmin, layout transposes) ----
+        def sweep_bytes(feats, grids, out_vox, C):
+            # per output voxel N x 8 B of grid + 1 validity byte + C x 4 B written; the feature maps once
+            N = feats.shape[1]
+            return out_vox * (N * 8 + 1 + C * 4) + feats.numel() * 4
+
+        def d_sweep_split(a, k, r):
+            feats, grids = a[0], a[1]
+            return f"sweep_std_nhwc_v_kernel<{feats.shape[1]}, true>", sweep_bytes(feats, grids, r.B * r.D * r.H * r.W, r.C)
+
+        def d_sweep_valid(a, k, r):
+            feats, grids = a[0], a[1]
+            return f"sweep_std_nhwc_v_kernel<{feats.shape[1]}, false>", sweep_bytes(feats, grids, r.numel() // r.shape[-1], r.shape[-1])
+
+        def d_sweep_std(a, k, r):
+            feats, grids, masks = a[0], a[1], a[3]
+            vox = r.numel() // r.shape[-1]
+            return "sweep_std (masks re-sampled)", sweep_bytes(feats, grids, vox, r.shape[-1]) + vox * feats.shape[1] * 4 + masks.numel() * 4
+
+        def d_sweep_cat(a, k, r):
+            feats = a[0]
+            vox = r.numel() // r.shape[-1]
+            return "sweep_cat_nhwc_kernel", vox * (feats.shape[1] * 8 + r.shape[-1] * 4) + feats.numel() * 4
+
+        def d_softargmin(a, k, r):
+            costs, scale = a[0], a[2]
+            inv, pr = r
+            return "softargmin_kernel", costs.numel() * 4 + inv.numel() * 4 + (pr.numel() * 4 if pr is not None else 0)
+
+        def d_transpose(name):
+            return lambda a, k, r: (name, 8 * r.numel())
+
+        def d_resize(a, k, r):
+            return "resize_trilinear_kernel", 4 * (a[0].numel() + r.numel())
+
+        for fname, d in (("sweep_std_valid_split", d_sweep_split), ("sweep_std_valid", d_sweep_valid), ("sweep_std", d_sweep_std),
+                         ("sweep_cat", d_sweep_cat), ("softargmin", d_softargmin), ("ncdhw_to_ndhwc", d_transpose("ncv_to_nvc_kernel")),
+                         ("ndhwc_to_ncdhw", d_transpose("nvc_to_ncv_kernel")), ("resize_trilinear", d_resize)):
+            self._wrap_hbm(fname, d)
+        orig_nhwc = H._feats_nhwc
+        self.hbm_orig["_feats_nhwc"] = orig_nhwc
+
+        def probed_nhwc(feats):
+            v = feats.permute(0, 1, 3, 4, 2)
+            if not self.enabled or (v.is_contiguous() and v.data_ptr() % 16 == 0):
+                return orig_nhwc(feats)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_nhwc(feats)
+            e.record()
+            self.hbm_records.append(("ncv_to_nvc_kernel (feats)", 8.0 * r.numel(), s, e))
+            return r
+        H._feats_nhwc = probed_nhwc
         return self
 
     def __exit__(self, *a):
@@ -209,16 +287,47 @@ class ConvProbe:
         self.H.conv3d_rs = self.orig_rs
         self.H.conv3d_rs16 = self.orig_rs16
         self.H.conv3d_out_split = self.orig_os
+        for fname, orig in self.hbm_orig.items():
+            setattr(self.H, fname, orig)
+
+    def hbm_summary(self):
+        agg = {}
+        for name, nbytes, s, e in self.hbm_records:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += nbytes
+            a[2] += s.elapsed_time(e)
+        return agg
 
     def summary(self):
+        """kernel name -> [launches, algorithmic FLOPs, ms, layer-granular bytes (input + output (+ residual), fp32)]"""
         agg = {}
-        for name, flops, s, e in self.records:
+        for name, flops, s, e, nbytes in self.records:
             ms = s.elapsed_time(e)
-            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops
             a[2] += ms
+            a[3] += nbytes
         return agg
+
+
+def kernels_block(agg, hbm_agg):
+    """The line's `kernels` object: every attributed launch of the timed steps with its bound and achieved rate."""
+    out = {}
+    for k, v in sorted(agg.items()):
+        ent = {"launches": v[0], "avg_us": round(v[2] / v[0] * 1e3, 2), "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2),
+               "GBps": round(v[3] / (v[2] * 1e-3) / 1e9, 1)}
+        if "head" in k:
+            ent.update(bound="hbm", hbm_frac=round(ent["GBps"] / PEAK_HBM_GBS, 4))
+        else:
+            ent["bound"] = "mfma"
+        out[k] = ent
+    for k, v in sorted(hbm_agg.items()):
+        gbps = v[1] / (v[2] * 1e-3) / 1e9
+        out[k] = {"launches": v[0], "avg_us": round(v[2] / v[0] * 1e3, 2), "bound": "hbm", "GBps": round(gbps, 1),
+                  "hbm_frac": round(gbps / PEAK_HBM_GBS, 4), "MB_per_launch": round(v[1] / v[0] / 1e6, 2)}
+    return out
 
 
 def read_pmc_traffic(kernel_name: str):
@@ -320,6 +429,24 @@ def cpu_baseline(cfg, seconds: float, dump_path=None):
 
 
 # ------------------------------------------------------------------------------------------
+def self_launch(args, argv) -> int:
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: start the N ranks as a CHILD torch.distributed.run (one process
+    per GPU, rendezvous on 127.0.0.1 at a free port), relay its output and return its exit code.  Runs before this process has
+    touched the GPU or imported torch; never an exec (a process must not replace itself once anything may have initialised HIP)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, effective_cores() // args.gpus)))     # N ranks share this host's cores
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    r = subprocess.run(cmd, env=env)
+    return r.returncode
+
+
 def ensure_library(local_rank: int):
     """The library normally travels with the tree (built by __graft_entry__.build()).  When it is missing or
     stale, local rank 0 builds it (to a temporary path, renamed into place -- never a half-written file) and the
@@ -333,15 +460,18 @@ def ensure_library(local_rank: int):
             return True
         except Exception:
             return False
-    if os.path.isfile(LIB) and loadable():
+    import __graft_entry__
+    stale = __graft_entry__._needs_rebuild()      # content hash of csrc/ against the one the library was built from
+    if not stale and loadable():
         return
     if local_rank == 0:
-        import __graft_entry__
-        __graft_entry__.build()
+        if stale and os.path.isfile(LIB):
+            print("bench.py: libmvsgi_hip.so is older than its sources: rebuilding", file=sys.stderr, flush=True)
+        __graft_entry__.build(force=False)
         return
     deadline = time.time() + 900
     while time.time() < deadline:
-        if os.path.isfile(LIB) and loadable():
+        if not __graft_entry__._needs_rebuild() and loadable():
             return
         time.sleep(1.0)
     raise SystemExit("bench.py: libmvsgi_hip.so did not appear (build by local rank 0 failed or timed out)")
@@ -379,7 +509,7 @@ def measure_path(cfg, B, mode, steps, warmup, dev, H, HotPath, synth, torch, np,
         el = timed_steps(step, sync, steps, 0, 1, False, dev)
         probe.enabled = False
         agg = probe.summary()
-    dname, (dn, dflops, dms) = max(agg.items(), key=lambda kv: kv[1][2])
+    dname, (dn, dflops, dms, _) = max(agg.items(), key=lambda kv: kv[1][2])
     ach = dflops / (dms * 1e-3) / 1e12
     res = {"frames_per_step": B, "frames_per_s": round(B * steps / el, 2), "ms_per_step": round(el / steps * 1e3, 4),
            "path_tflops": round(B * steps / el * path_gflop(cfg) / 1e3, 2),
@@ -403,9 +533,8 @@ def main(argv=None):
         print(json.dumps(cpu_baseline(_C[args.config], args.cpu_seconds, args.cpu_dump)), flush=True)
         return
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
-                             f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            raise SystemExit(self_launch(args, sys.argv[1:] if argv is None else argv))
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     cpu_res, ref_dump = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -422,6 +551,8 @@ def main(argv=None):
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     if os.environ.get("MVSGI_BENCH_SHARE_GPU"):      # test hook: N ranks on one device (use --backend gloo)
         local_rank = 0
+    if world > 1:
+        torch.set_num_threads(max(1, effective_cores() // world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend_ready = False
@@ -432,6 +563,13 @@ def main(argv=None):
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
         backend_ready = True
+    devices = [local_rank]
+    if backend_ready:       # every rank's device ordinal, in rank order (the line shows which GPUs the job really ran on)
+        on_cpu = dist.get_backend() == "gloo"
+        mine = torch.tensor([local_rank], dtype=torch.int64, device="cpu" if on_cpu else dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        devices = [int(t.item()) for t in allr]
 
     cfg = CONFIGS[args.config]
     B = args.batch
@@ -464,15 +602,17 @@ def main(argv=None):
         probe.enabled = False
         sync()
         agg = probe.summary()
+        hbm_agg = probe.hbm_summary()
 
     assert torch.isfinite(out["inv"]).all()
     frames = B * world * args.steps
     value = frames / el
     # dominant kernel = largest total time among the conv variants
     dom = max(agg.items(), key=lambda kv: kv[1][2])
-    dname, (dn, dflops, dms) = dom
+    dname, (dn, dflops, dms, _) = dom
     achieved = dflops / (dms * 1e-3) / 1e12
     conv_ms = sum(v[2] for v in agg.values())
+    attributed_ms = conv_ms + sum(v[2] for v in hbm_agg.values())
     traffic, traffic_src = read_pmc_traffic(dname)
     res = {
         "metric": f"stereo frames/sec/GPU ({cfg.tag}, {cfg.num_cams}-cam, D={cfg.num_cands}) + inv-dist L1 vs reference",
@@ -498,10 +638,12 @@ def main(argv=None):
                      "traffic": traffic, "traffic_source": traffic_src, "launches": dn,
                      "avg_launch_us": round(dms / dn * 1e3, 2), "gflop_per_launch": round(dflops / dn / 1e9, 3),
                      "conv_time_frac_of_step": round(conv_ms / (el_ev * 1e3), 3),
+                     "attributed_time_frac_of_step": round(attributed_ms / (el_ev * 1e3), 3),
                      "how": "HIP events around every conv launch in a second pass of the same K steps "
                             f"({round(el_ev / args.steps * 1e3, 4)} ms per step with the events in)"},
-        "kernels": {k: {"launches": v[0], "avg_us": round(v[2] / v[0] * 1e3, 2),
-                        "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2)} for k, v in sorted(agg.items())},
+        "kernels": kernels_block(agg, hbm_agg),
+        "n_ranks_seen": dist.get_world_size() if backend_ready else 1,
+        "devices": devices,
     }
     # ---- parity of the benchmarked weights: the seed-0 frame (B=1) against the CPU oracle's inverse distance
     if ref_dump is not None and os.path.isfile(ref_dump):
@@ -590,6 +732,28 @@ def run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, 
                 "eager_frames_per_s": r["frames_per_s"], "graph_replay_frames_per_s": r["graph_replay_frames_per_s"],
                 "dominant_kernel": r["dominant_kernel"], "frac": r["frac"]}
     guarded("latency_b1", b1)
+
+    def batch_sweep():
+        # B in {1, 4, 8, 16} frames per GPU per step beside the headline's batch (B = 1 is latency_b1)
+        r = {}
+        for b in (4, 8, 16):
+            m = measure_path(cfg, b, args.mode, K, W, dev, H, HotPath, synth, torch, np, rng)
+            r[str(b)] = {k: m[k] for k in ("frames_per_s", "ms_per_step", "dominant_kernel", "frac")}
+        return r
+    guarded("batch_sweep", batch_sweep)
+
+    def mode_f32():
+        # the exact-arithmetic companion of the split-bf16 headline: every conv on v_mfma_f32_16x16x4_f32 (bit-for-bit an fp32
+        # fmaf chain), frac against the 157.3 TFLOP/s fp32-MFMA peak
+        if args.mode == "f32":
+            return {"note": "the headline is the exact-fp32 mode"}
+        try:
+            m = measure_path(cfg, min(B, 32), "f32", max(3, K // 4), 2, dev, H, HotPath, synth, torch, np, rng)
+        finally:
+            H.set_conv_mode(args.mode)
+        m["peak_tflops"] = PEAK_TFLOPS["f32"]
+        return m
+    guarded("mode_f32", mode_f32)
 
     # ---- images -> inverse distance (HIP feature extractor in front), HBM-resident and host-fed
     Hi, Wi = cfg.feat_hw

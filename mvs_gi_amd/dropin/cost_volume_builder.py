@@ -50,15 +50,29 @@ def _rig_hit(entry, tensors) -> bool:
         and entry[1] == tuple(t._version for t in tensors)
 
 
-def std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=None, split_out: bool = False):
+def _rig_cache_usable(owner, feats, grids) -> bool:
+    """Whether the validity-byte kernels serve this call (decided ONCE per forward, before a code path is chosen)."""
+    return owner is not None and getattr(owner, "cache_rig_constants", True) and _RIG_CACHE_ENV \
+        and H.nhwc_sweep_ok(feats) and grids.is_cuda
+
+
+def _owned_split_buffer(owner, attr: str, key: tuple, make):
+    """Module-owned split-padded buffers, one per shape key, NEVER replaced or freed while the module lives: a captured
+    hipGraph holds their addresses, and their zero borders are written exactly once (at allocation)."""
+    bufs = owner.__dict__.setdefault(attr, {})
+    if key not in bufs:
+        bufs[key] = make()
+    return bufs[key]
+
+
+def std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=None, split_out: bool = False, buf_frames: int = 0):
     """Masked-variance sweep.  grids / grid_masks / masks are constants of the camera rig (the
     reference builds them once, api/inference_class.py:40-45), so the mask half of the sweep
     (spherical_sweep_avg.py:92-102) is evaluated once per rig and cached on `owner`, keyed on the
     three tensors' storage pointer, in-place version counter, shape and dtype: a new or modified
     tensor recomputes it.  `owner.cache_rig_constants = False` (or MVSGI_RIG_CACHE=0) re-samples
     the masks every call."""
-    use_cache = owner is not None and getattr(owner, "cache_rig_constants", True) and _RIG_CACHE_ENV \
-        and H.nhwc_sweep_ok(feats) and grids.is_cuda
+    use_cache = _rig_cache_usable(owner, feats, grids)
     if not use_cache:
         return None if split_out else H.sweep_std(feats, grids, grid_masks, masks)
     tensors = (grids, grid_masks, masks)               # identity of what the caller passed
@@ -76,13 +90,13 @@ def std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=None, split_out: bool
     if split_out:
         # vol_raw straight into a module-owned split-padded buffer (zero border, allocated once per shape) for the
         # register-stationary post_vol
+        # (`buf_frames` > B: the buffer is sized for a whole chunk and a shorter tail chunk uses a leading slice of it)
         B, D, Ho, Wo = feats.shape[0], grids.shape[2], grids.shape[3], grids.shape[4]
-        key = (B, D, Ho, Wo, feats.device)
-        buf = owner.__dict__.get("_mvsgi_rs_vol")
-        if buf is None or buf[0] != key:
-            buf = (key, H.SplitAct(B, D, Ho, Wo, 16, feats.device))
-            owner.__dict__["_mvsgi_rs_vol"] = buf
-        return H.sweep_std_valid_split(feats, g_use, cached[2], out=buf[1])
+        nb = max(B, int(buf_frames))
+        full = _owned_split_buffer(owner, "_mvsgi_rs_vol", (nb, D, Ho, Wo, feats.device),
+                                   lambda: H.SplitAct(nb, D, Ho, Wo, 16, feats.device))
+        out = full if nb == B else H.SplitAct(B, D, Ho, Wo, 16, feats.device, buf=full.buf[:B])
+        return H.sweep_std_valid_split(feats, g_use, cached[2], out=out)
     return H.sweep_std_valid(feats, g_use, cached[2])
 
 
@@ -103,7 +117,7 @@ def std_forward(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: T
     if _USE_RS and H.get_conv_mode() == "bf16x3" and L.cin == 16 and L.cout == 16 and L.stride == 1 \
             and 0.0 <= L.neg_slope <= 1.0 and feats.dim() == 5 and feats.shape[2] == 16 and grids.dim() == 6:
         B, D, Ho, Wo = feats.shape[0], grids.shape[2], grids.shape[3], grids.shape[4]
-        if B * ((D + 3) // 4) * ((Ho + 3) // 4) * ((Wo + 15) // 16) >= _RS_MIN_UNITS:
+        if B * ((D + 3) // 4) * ((Ho + 3) // 4) * ((Wo + 15) // 16) >= _RS_MIN_UNITS and _rig_cache_usable(self, feats, grids):
             # sweep -> split-padded vol_raw -> register-stationary post_vol (csrc/conv3d_rs.hip) -> fp32 vol
             k = _FRONT_CHUNK
             shared = all(t.dim() > 0 and t.shape[0] > 1 and t.stride(0) == 0 for t in (grids, grid_masks, masks))
@@ -113,12 +127,11 @@ def std_forward(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: T
                 y = torch.empty((B, D, Ho, Wo, 16), device=feats.device, dtype=torch.float32)
                 for i in range(0, B, k):
                     j = min(i + k, B)
-                    vs = std_sweep_ndhwc(feats[i:j], grids, grid_masks, masks, owner=self, split_out=True)    # the rig tensors whole: cache identity
+                    vs = std_sweep_ndhwc(feats[i:j], grids, grid_masks, masks, owner=self, split_out=True, buf_frames=k)    # the rig tensors whole: cache identity
                     H.conv3d_rs16(vs, L._wp_rs(), L.scale, L.shift, neg_slope=L.neg_slope, out=y[i:j])
                 return cm._to_ncdhw_view(y)
             vs = std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=self, split_out=True)
-            if vs is not None:
-                return cm._to_ncdhw_view(H.conv3d_rs16(vs, L._wp_rs(), L.scale, L.shift, neg_slope=L.neg_slope))
+            return cm._to_ncdhw_view(H.conv3d_rs16(vs, L._wp_rs(), L.scale, L.shift, neg_slope=L.neg_slope))
     vol_raw = std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=self)
     return cm._to_ncdhw_view(L.run(vol_raw))
 

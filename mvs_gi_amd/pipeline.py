@@ -82,6 +82,9 @@ class HotPath:
         if getattr(self, "_graph", None) is None:
             raise RuntimeError("HotPath.replay() before capture()")
         if feats is not None and feats.data_ptr() != self._static_in.data_ptr():
+            if tuple(feats.shape) != tuple(self._static_in.shape) or feats.dtype != self._static_in.dtype:
+                raise ValueError(f"HotPath.replay(): the graph was captured for feats {tuple(self._static_in.shape)} "
+                                 f"{self._static_in.dtype}, got {tuple(feats.shape)} {feats.dtype}; capture() again")
             self._static_in.copy_(feats, non_blocking=True)
         self._graph.replay()
         return self._static_out

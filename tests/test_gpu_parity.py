@@ -580,6 +580,30 @@ def test_bench_two_ranks_frame_sharded_on_one_gpu():
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "mfma"
 
 
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how a driver that does not use torchrun would call
+    it) starts its own ranks as a child torch.distributed.run and relays rank 0's single line; the line says how many ranks
+    and which device ordinals really ran, and attributes the HBM-bound launches (sweep, soft-argmin) beside the convs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MVSGI_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "2", "--backend", "gloo"], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["devices"] == [0, 0]
+    assert d["value"] > 0 and d["scaling"] == "weak"
+    hbm = {k: v for k, v in d["kernels"].items() if v.get("bound") == "hbm"}
+    assert any(k.startswith("sweep_std") for k in hbm) and "softargmin_kernel" in hbm and "conv3d_head_kernel" in hbm
+    assert all(v["GBps"] > 0 for v in hbm.values())
+    assert d["roofline"]["attributed_time_frac_of_step"] > 0.8
+
+
 # ------------------------------------------------------------------------------ feature extractor (§8(f) rank 1)
 @pytest.mark.parametrize("shape", [(2, 16, 16, 20, 36, 1, True), (1, 16, 16, 33, 47, 1, False), (2, 16, 16, 24, 40, 2, False),
                                    (1, 32, 32, 17, 30, 1, True), (1, 16, 64, 16, 32, 2, False), (1, 64, 64, 12, 20, 1, True)])
@@ -925,7 +949,8 @@ def test_split_padded_format_round_trip_and_border():
         assert int(sl.abs().max()) == 0                               # the border is never written
 
 
-@pytest.mark.parametrize("shape", [(1, 2, 4, 16), (1, 4, 8, 32), (2, 5, 7, 37), (3, 3, 9, 16), (1, 8, 12, 48)])
+@pytest.mark.parametrize("shape", [(1, 2, 4, 16), (1, 4, 8, 32), (2, 5, 7, 37), (3, 3, 9, 16), (1, 8, 12, 48),
+                                   (4, 9, 30, 70)])      # 800 ragged bricks on <= 256 workgroups: the steady-state walk (n > 1 per workgroup)
 @pytest.mark.parametrize("res,slope,out_f32", [(True, 0.01, False), (False, 0.01, True), (True, 0.0, True), (False, 1.0, False)])
 def test_conv3d_rs_vs_oracle(shape, res, slope, out_f32):
     """Register-stationary 32 -> 32 conv on split-padded activations against the CPU oracle's conv block on the SAME
@@ -1034,7 +1059,8 @@ def test_full_size_batch8_register_stationary_path_vs_reference_golden(golden_di
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("shape", [(1, 4, 4, 16), (2, 5, 7, 37), (1, 9, 6, 20), (3, 8, 16, 48)])
+@pytest.mark.parametrize("shape", [(1, 4, 4, 16), (2, 5, 7, 37), (1, 9, 6, 20), (3, 8, 16, 48),
+                                   (3, 10, 30, 150)])    # 720 ragged bricks: main phases with masked stores mid-walk
 @pytest.mark.parametrize("slope", [0.01, 1.0])
 def test_conv3d_rs16_vs_oracle(shape, slope):
     """Register-stationary 16 -> 16 conv (post_vol) on a split-padded volume against the oracle's conv block on the same
@@ -1091,3 +1117,96 @@ def test_builder_register_stationary_post_vol_matches_streaming_and_goldens(gold
     finally:
         H.set_conv_mode(old_mode)
         cb._RS_MIN_UNITS, cb._USE_RS = old_min, old_use
+
+
+# ------------------------------------------------------------------------------ round-3 review items
+def test_softargmin_many_candidates_multi_pass_branch():
+    """D = 48 > 32: the soft-argmin kernel's multi-pass branch (the register path serves D <= 32), x2 / x1, with and without
+    norm_costs, against the oracle."""
+    rng = np.random.default_rng(48)
+    D = 48
+    costs = (rng.standard_normal((2, 1, D, 6, 10)) * 3).astype(np.float32)
+    cands = list(np.geomspace(0.5, 100.0, D))
+    for scale, pre in ((2, True), (0, True)):
+        dr = dropin.DistanceRegressorWithFixedCandidates(bf=96, dist_cands=cands, interp_scale_factor=scale, pre_interp=pre).to(DEV)
+        inv, pr = dr(_g(costs))
+        ref_inv, ref_pr = O.soft_argmin(torch.from_numpy(costs), cands, 96, scale, pre)
+        assert _rel(inv.cpu().numpy(), ref_inv.numpy()) <= 1e-5
+        assert _rel(pr.cpu().numpy(), ref_pr.numpy()) <= 1e-5
+        assert abs(float(pr.sum(1).mean()) - 1.0) < 1e-5
+        dr.return_norm_costs = False
+        assert torch.equal(dr(_g(costs))[0], inv)
+
+
+@pytest.mark.parametrize("N", [5, 6])
+def test_sweep_std_nchw_five_and_six_cameras_bit_exact(N):
+    """The plane-gather (NCHW) std sweep with more cameras than the channels-last kernels take (N <= 4): bit-equal to the oracle."""
+    rng = np.random.default_rng(N)
+    B, C, Hi, Wi, D, Ho, Wo, Hm, Wm = 2, 6, 12, 20, 3, 5, 9, 24, 40
+    feats = rng.standard_normal((B, N, C, Hi, Wi)).astype(np.float32)
+    grids = rng.uniform(-1.15, 1.15, (B, N, D, Ho, Wo, 2)).astype(np.float32)
+    gm = rng.random((B, N, D, Ho, Wo, 1)) < 0.8
+    masks = (rng.random((B, N, 1, Hm, Wm)) < 0.7).astype(np.float32)
+    want = O.sweep_std_masked(*(torch.from_numpy(a) for a in (feats, grids, gm, masks))).numpy()
+    for gmask in (_g(gm), _g(gm).float()):
+        assert np.array_equal(_ncdhw(H.sweep_std(_g(feats), _g(grids), gmask, _g(masks))), want)
+
+
+def test_front_end_without_rig_cache_and_with_a_tail_chunk():
+    """Review items: (1) cache_rig_constants = False with a batch above the front-end chunk and stride-0 rig views must take the
+    streaming path (it used to hand None to the post_vol kernel); (2) a batch that is not a multiple of the chunk re-uses ONE
+    chunk-sized buffer (a leading slice for the tail): same bits as the unchunked run, buffer identity stable over steps."""
+    from mvs_gi_amd.dropin import cost_volume_builder as cb
+    cfg = SMALL_CASES["std_d16_rand"]["cfg"]
+    inp = synth.make_inputs(cfg, seed=3, batch=1)
+    w = synth.make_weights(cfg, seed=3)
+    old_mode, old_chunk = H.get_conv_mode(), cb._FRONT_CHUNK
+    try:
+        H.set_conv_mode("bf16x3")
+        rng = np.random.default_rng(0)
+        feats = _g(rng.standard_normal((7, *inp["feats"].shape[1:]), dtype=np.float32))
+        cb._FRONT_CHUNK = 0
+        hp0 = HotPath(cfg, w, inp, device=DEV)
+        whole = hp0(feats)[0].clone()
+        cb._FRONT_CHUNK = 3                       # chunks of 3, 3 and a tail of 1
+        hp = HotPath(cfg, w, inp, device=DEV)
+        a = hp(feats)[0].clone()
+        bufs = dict(hp.cv_builder.__dict__["_mvsgi_rs_vol"])
+        b = hp(feats)[0].clone()
+        assert torch.equal(a, whole) and torch.equal(b, whole)
+        after = hp.cv_builder.__dict__["_mvsgi_rs_vol"]
+        assert len(after) == 1 and all(after[k] is bufs[k] for k in bufs)      # one chunk-sized buffer, never replaced
+        hp.cv_builder.cache_rig_constants = False
+        c = hp(feats)[0].clone()                  # masks re-sampled every call: streaming post_vol, fp32 volume
+        assert _rel(c.cpu().numpy(), whole.cpu().numpy()) <= 5e-4
+    finally:
+        H.set_conv_mode(old_mode)
+        cb._FRONT_CHUNK = old_chunk
+
+
+def test_hipgraph_survives_eager_calls_at_other_batch_sizes():
+    """A captured graph holds the addresses of the module-owned split-padded buffers: an eager call with another batch size in
+    between must neither free nor re-zero them; replay() with a mismatching shape raises instead of replaying stale geometry."""
+    from mvs_gi_amd.configs import CONFIGS, DIST_8L
+    cfg = CONFIGS["G16V"].scaled(feat_hw=(32, 128), mask_hw=(64, 256), cv_hw=(16, 64), dist_cands=DIST_8L)
+    inp = synth.make_inputs(cfg, seed=7, batch=1)
+    old_mode = H.get_conv_mode()
+    try:
+        H.set_conv_mode("bf16x3")
+        hp = HotPath(cfg, synth.make_weights(cfg, seed=7), inp, device=DEV)
+        rng = np.random.default_rng(2)
+        f2 = _g(rng.standard_normal((2, *inp["feats"].shape[1:]), dtype=np.float32))
+        f3 = _g(rng.standard_normal((3, *inp["feats"].shape[1:]), dtype=np.float32))
+        e2 = hp(f2)[0].clone()
+        hp.capture(f2)
+        g_a = hp.replay(f2)[0].clone()
+        e3 = hp(f3)[0].clone()                      # another batch size, eagerly
+        junk = [torch.full((1 << 22,), 7, device=DEV, dtype=torch.int32) for _ in range(8)]     # would land in freed buffers
+        g_b = hp.replay(f2)[0].clone()
+        assert torch.equal(g_a, e2) and torch.equal(g_b, e2)
+        assert torch.equal(hp(f3)[0], e3)
+        del junk
+        with pytest.raises(ValueError):
+            hp.replay(f3)
+    finally:
+        H.set_conv_mode(old_mode)
