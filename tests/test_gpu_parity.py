@@ -1139,8 +1139,11 @@ def test_softargmin_many_candidates_multi_pass_branch():
 
 
 @pytest.mark.parametrize("N", [5, 6])
-def test_sweep_std_nchw_five_and_six_cameras_bit_exact(N):
-    """The plane-gather (NCHW) std sweep with more cameras than the channels-last kernels take (N <= 4): bit-equal to the oracle."""
+def test_sweep_std_nchw_five_and_six_cameras(N):
+    """The plane-gather (NCHW) std sweep with more cameras than the channels-last kernels take (N <= 4).  The kernel adds the
+    cameras in order; ATen's sum over the camera axis does too for N <= 4 (hence the bit-exact tests above), but from five
+    addends on it changes association for some element positions (its vectorised row reduction), so here the bar is 2 ulp-ish:
+    1e-6 of the tensor's maximum, and the samples / validity (which involve no sum) are exact: zeros agree exactly."""
     rng = np.random.default_rng(N)
     B, C, Hi, Wi, D, Ho, Wo, Hm, Wm = 2, 6, 12, 20, 3, 5, 9, 24, 40
     feats = rng.standard_normal((B, N, C, Hi, Wi)).astype(np.float32)
@@ -1149,7 +1152,9 @@ def test_sweep_std_nchw_five_and_six_cameras_bit_exact(N):
     masks = (rng.random((B, N, 1, Hm, Wm)) < 0.7).astype(np.float32)
     want = O.sweep_std_masked(*(torch.from_numpy(a) for a in (feats, grids, gm, masks))).numpy()
     for gmask in (_g(gm), _g(gm).float()):
-        assert np.array_equal(_ncdhw(H.sweep_std(_g(feats), _g(grids), gmask, _g(masks))), want)
+        got = _ncdhw(H.sweep_std(_g(feats), _g(grids), gmask, _g(masks)))
+        assert _rel(got, want) <= 1e-6 and np.array_equal(got == 0, want == 0)
+        assert (got != want).mean() < 0.05          # the association differs for a few positions only
 
 
 def test_front_end_without_rig_cache_and_with_a_tail_chunk():
@@ -1210,3 +1215,29 @@ def test_hipgraph_survives_eager_calls_at_other_batch_sizes():
             hp.replay(f3)
     finally:
         H.set_conv_mode(old_mode)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 5, 8), (1, 16, 7, 10), (2, 5, 6, 9), (1, 32, 4, 12), (1, 48, 6, 10), (1, 16, 3, 700), (1, 20, 1, 4),
+                                   (3, 16, 80, 320)])
+def test_softargmin_row_pair_kernel_equals_pixel_kernel_and_oracle(shape):
+    """The x2 soft-argmin as one workgroup per low-resolution row pair (LDS-staged rows, four pixels per thread, 16-byte stores)
+    against the thread-per-pixel kernel (MVSGI_SOFTARGMIN_PIXEL=1) and the oracle: W % 4 != 0, odd W, two column tiles, H = 1,
+    D in registers (<= 16, <= 32) and the multi-pass form (D = 48), with and without norm_costs, with the / bf post-division."""
+    B, D, Hh, W = shape
+    rng = np.random.default_rng(sum(shape))
+    costs = (rng.standard_normal((B, D, Hh, W)) * 4).astype(np.float32)
+    inv_idx = _g((96.0 / np.geomspace(0.5, 100.0, D)).astype(np.float32))
+    c = _g(costs)
+    inv, pr = H.softargmin(c, inv_idx, 2, True)
+    inv_only, none = H.softargmin(c, inv_idx, 2, False, post_div=96.0)
+    os.environ["MVSGI_SOFTARGMIN_PIXEL"] = "1"
+    try:
+        inv_p, pr_p = H.softargmin(c, inv_idx, 2, True)
+    finally:
+        del os.environ["MVSGI_SOFTARGMIN_PIXEL"]
+    assert none is None and _rel(inv_only.cpu().numpy() * 96.0, inv.cpu().numpy()) <= 1e-6
+    assert _rel(inv.cpu().numpy(), inv_p.cpu().numpy()) <= 1e-6 and _rel(pr.cpu().numpy(), pr_p.cpu().numpy()) <= 1e-6
+    up = F.interpolate(torch.from_numpy(costs), scale_factor=2, mode="bilinear")
+    ref_pr = F.softmax(up, 1)
+    ref_inv = (ref_pr * inv_idx.cpu().view(1, -1, 1, 1)).sum(1, keepdim=True)
+    assert _rel(inv.cpu().numpy(), ref_inv.numpy()) <= 1e-5 and _rel(pr.cpu().numpy(), ref_pr.numpy()) <= 1e-5
