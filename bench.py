@@ -220,6 +220,35 @@ class ConvProbe:
             self.records.append(("conv3d_rs16_kernel", 2.0 * 27 * 16 * 16 * x.B * x.D * x.H * x.W, s, e, 4.0 * 32 * x.B * x.D * x.H * x.W))
             return y
 
+        orig_poly, orig_up2s = H.conv3d_up2_poly, H.conv3d_up2_out_split
+        self.hbm_orig["conv3d_up2_poly"], self.hbm_orig["conv3d_up2_out_split"] = orig_poly, orig_up2s
+
+        def probed_poly(x, plan, scale, shift, neg_slope=0.01, out=None):
+            if not self.enabled:
+                return orig_poly(x, plan, scale, shift, neg_slope, out)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = orig_poly(x, plan, scale, shift, neg_slope, out)
+            e.record()
+            vox = y.numel() // 16
+            self.records.append(("conv3d_rs32_kernel<2> + up2_face_kernel + up2_edge_kernel (polyphase out_costs.0)",
+                                 2.0 * 27 * 32 * 16 * vox, s, e, 4.0 * (x.B * x.D * x.H * x.W * 32 + y.numel())))
+            return y
+
+        def probed_up2s(x, w_packed_b3, scale, shift, out, res=None, neg_slope=0.01, w_layout=H.CONV_BF16X3):
+            if not self.enabled:
+                return orig_up2s(x, w_packed_b3, scale, shift, out, res, neg_slope, w_layout)
+            B, Dl, Hl, Wl, Cin = x.shape
+            Cout = scale.numel()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = orig_up2s(x, w_packed_b3, scale, shift, out, res, neg_slope, w_layout)
+            e.record()
+            vox = out.B * out.D * out.H * out.W
+            self.records.append((H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, w_layout) + " [split-padded out]",
+                                 2.0 * 27 * Cin * Cout * vox, s, e, 4.0 * (x.numel() + vox * Cout * (2 if res is not None else 1))))
+            return y
+        H.conv3d_up2_poly, H.conv3d_up2_out_split = probed_poly, probed_up2s
         H.conv3d = probed
         H.conv3d_up2 = probed_up2
         H.conv3d_rs16 = probed_rs16

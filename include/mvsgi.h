@@ -284,6 +284,26 @@ int mvsgi_conv3d_rs_split(const void* x_split, const void* w_packed_rs, const fl
                           const void* res_split, void* y, int y_is_f32, int B, int Cin, int D, int H, int W, int Cout,
                           float neg_slope, mvsgi_stream_t stream);
 
+/* ---- polyphase ResizeConv3d (csrc/conv3d_up2poly.hip) ------------------------------------------------------
+ * ResizeConv3d.forward (dsta_mvs/model/common/common_modules.py:332-355) for Cin = 32, Cout = 16, no skip input --
+ * out_costs.0 of the (16, 32) regulator (cost_volume_regulator/unet_regulator.py:52-60): trilinear x2 (align_corners=False,
+ * :335-341) + Conv3d(k 3, padding 1) + eval BatchNorm + LeakyReLU evaluated as 8 phase convolutions over the LOW-resolution
+ * tensor (weights folded at plan time; the faces of the volume, where ATen's clamp and the conv's zero padding change the
+ * folded centre taps, by separate small launches).
+ *   mvsgi_conv3d_up2_poly_plan_bytes   size of the plan for a low-resolution input of D x H x W voxels (0: bad dims)
+ *   mvsgi_conv3d_up2_poly_plan         HOST function, no GPU call: w_oidhw_host [16][32][3][3][3] fp32 in host memory ->
+ *                                      plan_host (position independent: copy the bytes to the device unchanged)
+ *   mvsgi_conv3d_up2_poly_f32          x_split: split-padded [B][D+2][H+2][W+2][32]; y: fp32 [B][2D][2H][2W][16];
+ *                                      scale / shift: 16 floats each; neg_slope in [0, 1]
+ */
+int mvsgi_conv3d_up2_f32_out_split(const float* x, const void* w_packed, int w_layout, const float* scale, const float* shift,
+                                   const float* res, void* y_split, int B, int Cin, int Dl, int Hl, int Wl, int Cout,
+                                   float neg_slope, mvsgi_stream_t stream);   /* mvsgi_conv3d_up2_f32 writing a split-padded y */
+size_t mvsgi_conv3d_up2_poly_plan_bytes(int D, int H, int W);
+int mvsgi_conv3d_up2_poly_plan(const float* w_oidhw_host, void* plan_host, int D, int H, int W);
+int mvsgi_conv3d_up2_poly_f32(const void* x_split, const void* plan_dev, const float* scale, const float* shift, float* y,
+                              int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

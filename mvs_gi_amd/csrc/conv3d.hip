@@ -625,6 +625,25 @@ extern "C" int mvsgi_conv3d_up2_f32(const float* x, const void* w_packed, int w_
     return launch_variant(v, a, mvsgi::as_stream(stream));
 }
 
+// mvsgi_conv3d_up2_f32 with the output in the split-padded format (the input of the polyphase out_costs.0, csrc/conv3d_up2poly.hip)
+extern "C" int mvsgi_conv3d_up2_f32_out_split(const float* x, const void* w_packed, int w_layout, const float* scale, const float* shift,
+                                              const float* res, void* y_split, int B, int Cin, int Dl, int Hl, int Wl, int Cout,
+                                              float neg_slope, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(w_layout == MVSGI_CONV_BF16X3 || (w_layout == MVSGI_CONV_BF16X3_C16 && Cout == 16),
+                  "mvsgi_conv3d_up2_f32_out_split: w_layout %d not valid for Cout %d", w_layout, Cout);
+    MVSGI_REQUIRE(x && y_split && scale && shift && w_packed, "mvsgi_conv3d_up2_f32_out_split: null pointer");
+    MVSGI_REQUIRE(Dl > 0 && Hl > 0 && Wl > 0 && Dl < (1 << 20) && Hl < (1 << 20) && Wl < (1 << 20),
+                  "mvsgi_conv3d_up2_f32_out_split: bad dims");
+    ConvArgs a{};
+    if (fill_args(a, x, nullptr, static_cast<const float*>(w_packed), scale, shift, res, reinterpret_cast<float*>(y_split), B, Cin,
+                  2 * Dl, 2 * Hl, 2 * Wl, Cout, 1, neg_slope))
+        return 1;
+    a.y_split = static_cast<unsigned char*>(y_split);
+    const int v = select_variant_up2(a, w_layout);
+    if (v == V_COUNT) return 1;
+    return launch_variant(v, a, mvsgi::as_stream(stream));
+}
+
 extern "C" const char* mvsgi_conv3d_up2_variant_f32(int B, int Cin, int Dl, int Hl, int Wl, int Cout, int w_layout) {
     ConvArgs a{};
     static const float dummy = 0.f;

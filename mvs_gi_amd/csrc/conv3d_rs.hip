@@ -26,6 +26,8 @@
 //   x = hi + lo, hi = bf16(x) (RNE), lo = bf16(x - hi): 16-17 significant bits, the same 4 B per element as fp32;
 //   the border voxels are zero and never written (the convolution's padding).
 #include "common.hpp"
+
+#include <cstring>
 #ifdef MVSGI_RS_STAMPS
 #include <cstdio>
 #include <cstdlib>
@@ -123,6 +125,10 @@ struct RsArgs {
     float neg_slope;           // in [0, 1]: act(v) = max(v, v * neg_slope)
     int tiles_d, tiles_h, tiles_w, total_units;
     unsigned long long* dbg;   // MVSGI_RS_STAMPS diagnostic build only
+    // polyphase mode (MODE 2 below): `wp` holds 16 weight sets [pd 2][d-class 4][ph 2] of `wp_set` bf16x8 elements each;
+    // walkers per (XCD, role)
+    long long wp_set;
+    int walkers;
 };
 
 __device__ __forceinline__ int rs_xcd_remap(int bid, int n) {
@@ -185,10 +191,27 @@ struct RsUnit {      // coordinates of a brick (wave-uniform)
     int b, od, oh, ow;
 };
 
-// OUTF32: the output goes to a plain fp32 channels-last tensor [B][D][H][W][32] (the hand-over to a kernel that stages fp32)
-template <bool OUTF32>
+// MODE 0: split-padded output (the next register-stationary layer's input).
+// MODE 1: the output goes to a plain fp32 channels-last tensor [B][D][H][W][32] (the hand-over to a kernel that stages fp32).
+// MODE 2: POLYPHASE form of ResizeConv3d (common_modules.py:332-355; 32 -> 16 channels: out_costs.0 of the (16, 32) regulator,
+//   unet_regulator.py:52-60).  conv(trilinear_x2(x)) is, per output phase (pd, ph, pw) in {0,1}^3, an ordinary 3x3x3 convolution
+//   over the LOW-resolution tensor with weights (M_d x M_h x M_w) w folded at lowering time (dropin/polyphase.py), i.e. one
+//   32 -> 128 convolution + a depth-to-space shuffle, and a 32 -> 32 slice of it -- the two pw phases of one (pd, ph) -- is exactly
+//   this kernel's shape: no upsampled tensor, no blend arithmetic, the same register-stationary weights, LDS-DMA staging and
+//   schedule as the level-0 residual convs.  A workgroup has a ROLE (pd, ph, od): it walks the bricks (b, oh, ow) of ONE
+//   d-brick od for one (pd, ph) (all roles of an XCD walk the same (b, oh, ow) range: the bricks they share come from that
+//   XCD's L2), because the folded weights of a wave's plane depend on whether the plane is the first / an interior / the last
+//   low-resolution plane (the upsample clamps, the conv zero-pads the UPSAMPLED grid): a wave keeps one weight set for the
+//   whole launch.  The output cell (i_d, i_h, i_w), cout tile pw, goes to hi-res voxel (2 i_d + pd, 2 i_h + ph, 2 i_w + pw) of a
+//   plain fp32 [B][2D][2H][2W][16] tensor = the MODE 1 addressing with other strides.  Cells on the H / W faces of the volume
+//   need other centre taps along that axis: their difference arrives as a raw (pre-scale) correction that
+//   csrc/conv3d_up2face.hip has written into the output voxels beforehand; the epilogue reads it back (masked to face cells)
+//   where the other modes read the residual.
+template <int MODE>
 __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     using namespace rs;
+    constexpr bool OUTF32 = MODE != 0;
+    constexpr bool UP2 = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -199,6 +222,18 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     const int Hp = a.H + 2, Wp = a.W + 2;
     const long long frame_bytes = (long long)(a.D + 2) * Hp * Wp * 128;
     const long long total_bytes = frame_bytes * a.B;
+    // ---- polyphase role of this workgroup: blockIdx = (walker * R + role) * 8 + xcd ----
+    const int Hh = 2 * a.H, Wh = 2 * a.W;
+    const int up_R = 4 * a.tiles_d;
+    const int up_q = (int)blockIdx.x >> 3;
+    const int up_role = UP2 ? up_q % up_R : 0, up_walker = UP2 ? up_q / up_R : 0;
+    const int up_pd = (up_role >> 1) & 1, up_ph = up_role & 1, up_od = up_role >> 2;
+    const long long oframe_bytes = UP2 ? (long long)(2 * a.D) * Hh * Wh * 64 : (long long)a.D * a.H * a.W * 128;
+    if constexpr (UP2) {
+        const int i_d = up_od * TD + pl;
+        const int cls = a.D == 1 ? 3 : (i_d == 0 ? 0 : (i_d == a.D - 1 ? 2 : 1));
+        a.wp += (long long)((up_pd * 4 + cls) * 2 + up_ph) * a.wp_set;
+    }
 
     // ---- weights: resident in the accumulator half of the register file for the whole launch ----
     bf16x8 wh[kPairs][2], wl[kPairs][2];
@@ -245,8 +280,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
                           : 0xffffff00u;     // row padding: beyond num_records, zero-filled
     }
     // ---- output side: this lane's 16-byte piece of the own tiles' voxel records ----
-    const f32x4 esc[2] = {*reinterpret_cast<const f32x4*>(a.scale + kg * 4), *reinterpret_cast<const f32x4*>(a.scale + 16 + kg * 4)};
-    const f32x4 esh[2] = {*reinterpret_cast<const f32x4*>(a.shift + kg * 4), *reinterpret_cast<const f32x4*>(a.shift + 16 + kg * 4)};
+    // (polyphase mode: the two cout tiles are the two pw phases of the SAME 16 output channels)
+    const f32x4 esc[2] = {*reinterpret_cast<const f32x4*>(a.scale + kg * 4), *reinterpret_cast<const f32x4*>(a.scale + (UP2 ? 0 : 16) + kg * 4)};
+    const f32x4 esh[2] = {*reinterpret_cast<const f32x4*>(a.shift + kg * 4), *reinterpret_cast<const f32x4*>(a.shift + (UP2 ? 0 : 16) + kg * 4)};
     unsigned voy0[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -254,40 +290,57 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     unsigned voyo[2];     // the same for the OUTPUT tensor (fp32: unpadded, couts 4 kg .. 4 kg + 3 of the tile are 16 contiguous bytes)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-        voyo[i] = OUTF32 ? (unsigned)(((pl * a.H + 2 * s + i) * a.W + col) * 128 + kg * 16) : voy0[i];
+        voyo[i] = UP2 ? (unsigned)(((2 * pl * Hh + 2 * (2 * s + i)) * Wh) * 64 + col * 128 + kg * 16)       // cell -> hi-res voxel pair
+                      : (OUTF32 ? (unsigned)(((pl * a.H + 2 * s + i) * a.W + col) * 128 + kg * 16) : voy0[i]);
     int sp_rd = SCR + (wave ^ 2) * 4096 + lane * 16, sp_wr = SCR + 16384 + wave * 4096 + lane * 16;
 
-    const int total = a.total_units, G = gridDim.x;
-    const int n = (total - (int)blockIdx.x + G - 1) / G;       // bricks of this workgroup (the same for its 4 waves)
-    // The walk: logical ids id0 + k * step (XCD-contiguous remap, cdna_hip_programming.md T1; G % 8 == 0 or G == total)
-    const int id0 = rs_xcd_remap((int)blockIdx.x, total);
-    const int step = G == total ? 0 : G >> 3;
+    int total = a.total_units;
+    const int G = gridDim.x;
+    int n, id0, step;
+    if constexpr (UP2) {
+        // per role the space (b, oh, ow) of tiles_h * tiles_w * B bricks; XCD x owns a contiguous eighth of it, shared by the
+        // roles; walker j of `walkers` takes every walkers-th brick of that range
+        total = a.B * a.tiles_h * a.tiles_w;
+        const int x = (int)blockIdx.x & 7, q8 = total >> 3, r8 = total & 7;
+        const int lo = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8, cnt = q8 + (x < r8 ? 1 : 0);
+        n = cnt > up_walker ? (cnt - up_walker + a.walkers - 1) / a.walkers : 0;
+        id0 = lo + up_walker;
+        step = a.walkers;
+        if (n == 0) return;        // the whole workgroup (uniform): nothing was started yet
+    } else {
+        n = (total - (int)blockIdx.x + G - 1) / G;       // bricks of this workgroup (the same for its 4 waves)
+        // The walk: logical ids id0 + k * step (XCD-contiguous remap, cdna_hip_programming.md T1; G % 8 == 0 or G == total)
+        id0 = rs_xcd_remap((int)blockIdx.x, total);
+        step = G == total ? 0 : G >> 3;
+    }
     // logical order (b, oh, od, ow), ow fastest: the bricks stacked along D share two of their four / six input planes and
     // follow each other within one XCD round (tiles_w ids apart), the bricks above / below a round or two later -- in the
     // (b, od, oh, ow) order the D neighbours were tiles_h * tiles_w ids (several L2 capacities) apart
+    // (polyphase mode: od is the role's, the walk's digits are (b, oh, ow): a d-radix of 1 makes the same code do that)
+    const int walk_td = UP2 ? 1 : a.tiles_d;
     const int sw = step % a.tiles_w;
     int tq = step / a.tiles_w;
-    const int sd = tq % a.tiles_d;
-    tq /= a.tiles_d;
+    const int sd = tq % walk_td;
+    tq /= walk_td;
     const int sh_ = tq % a.tiles_h, sb = tq / a.tiles_h;
     RsUnit c2{0, 0, 0, 0}, c1{0, 0, 0, 0}, c0, nx;
     {
         int t_ = id0;
         c0.ow = t_ % a.tiles_w;
         t_ /= a.tiles_w;
-        c0.od = t_ % a.tiles_d;
-        t_ /= a.tiles_d;
+        c0.od = t_ % walk_td;
+        t_ /= walk_td;
         c0.oh = t_ % a.tiles_h;
         c0.b = t_ / a.tiles_h;
     }
-// tile coordinates of the next brick of the walk: mixed-radix add, no division
+// tile coordinates of the next brick of the walk: mixed-radix add, no division (od counts within the WALK: 0 in polyphase mode)
 #define RS_STEP(DST, SRC)                                                      \
     {                                                                          \
         int w_ = SRC.ow + sw, c_ = w_ >= a.tiles_w;                            \
         DST.ow = w_ - (c_ ? a.tiles_w : 0);                                    \
         int d_ = SRC.od + sd + c_;                                             \
-        c_ = d_ >= a.tiles_d;                                                  \
-        DST.od = d_ - (c_ ? a.tiles_d : 0);                                    \
+        c_ = d_ >= walk_td;                                                    \
+        DST.od = d_ - (c_ ? walk_td : 0);                                      \
         int h_ = SRC.oh + sh_ + c_;                                            \
         c_ = h_ >= a.tiles_h;                                                  \
         DST.oh = h_ - (c_ ? a.tiles_h : 0);                                    \
@@ -301,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 #define RS_DESC(PTR, U, VALID)                                                                                   \
     ({                                                                                                           \
         const long long off_ = (long long)(U).b * frame_bytes +                                                  \
-                               ((long long)((U).od * TD * Hp + (U).oh * TH) * Wp + (U).ow * TW) * 128;           \
+                               ((long long)(((U).od + up_od) * TD * Hp + (U).oh * TH) * Wp + (U).ow * TW) * 128; \
         const long long left_ = total_bytes - off_;                                                              \
         const int rec_ = left_ > 0x7fffff00ll ? 0x7fffff00 : (int)left_;                                         \
         const int ok_ = (int)(VALID) & (int)(left_ > 0);                                                         \
@@ -309,15 +362,22 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     })
 #define RS_DESC_OUT(U, VALID)                                                                                   \
     ({                                                                                                           \
-        const long long off_ = (long long)(U).b * ((long long)a.D * a.H * a.W * 128) +                           \
-                               ((long long)((U).od * TD * a.H + (U).oh * TH) * a.W + (U).ow * TW) * 128;         \
-        const long long left_ = (long long)a.B * a.D * a.H * a.W * 128 - off_;                                   \
+        const long long off_ = (long long)(U).b * oframe_bytes +                                                 \
+            (UP2 ? ((long long)((2 * up_od * TD + up_pd) * Hh + 2 * (U).oh * TH + up_ph) * Wh + 2 * (U).ow * TW) * 64 \
+                 : ((long long)((U).od * TD * a.H + (U).oh * TH) * a.W + (U).ow * TW) * 128);                    \
+        const long long left_ = (long long)a.B * oframe_bytes - off_;                                            \
         const int rec_ = left_ > 0x7fffff00ll ? 0x7fffff00 : (int)left_;                                         \
         const int ok_ = (int)(VALID) & (int)(left_ > 0);                                                         \
         __builtin_amdgcn_make_buffer_rsrc(a.y + off_, 0, ok_ ? rec_ : 0, 0x00020000);                            \
     })
 #define RS_F_SPL(...) if constexpr (!OUTF32) { __VA_ARGS__ }
 #define RS_F_F32(...) if constexpr (OUTF32) { __VA_ARGS__ }
+#define RS_F_UP2(...) if constexpr (UP2) { __VA_ARGS__ }
+#define RS_F_NUP2(...) if constexpr (!UP2) { __VA_ARGS__ }
+#define RS_DSC_Y(U, VALID) (OUTF32 ? RS_DESC_OUT(U, VALID) : RS_DESC(a.y, U, VALID))
+// the "residual" descriptor: the residual tensor, or (polyphase mode) the OUTPUT tensor, whose face voxels hold the corrections
+#define RS_DSC_R(U, VALID) (UP2 ? RS_DESC_OUT(U, VALID) : RS_DESC(a.res, U, (int)(a.res != nullptr) & (int)(VALID)))
+#define RS_RES_OFF(I) (UP2 ? voc[I] : voy0[I])
 #define RS_DMA(M)                                                                                                \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(dsc_x, (__attribute__((address_space(3))) void*)(lds + nxt_img + (wave + 4 * (M)) * 1024), \
                                              16, voff[M], 0, 0, 0);
@@ -409,13 +469,26 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     // ph - 1.  The last two phases (no brick left to multiply) run the same stream without the pairs.
     __amdgpu_buffer_rsrc_t dsc_x, dsc_r, dsc_y;
     unsigned voy[2] = {0xffffff00u, 0xffffff00u};
+    unsigned voc[2] = {0xffffff00u, 0xffffff00u};
     dsc_x = dsc_r = dsc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.x), 0, 0, 0x00020000);
 // stores of the brick two phases back: voxels outside the volume (ragged sizes) are sent out of range
 #define RS_VOY()                                                                                     \
     {                                                                                                \
-        const int dok_ = c2.od * TD + pl < a.D;                                                      \
+        const int dok_ = (c2.od + up_od) * TD + pl < a.D;                                            \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                \
             voy[i] = (dok_ & (int)(c2.oh * TH + 2 * s + i < a.H) & (int)(c2.ow * TW + col < a.W)) ? voyo[i] : 0xffffff00u; \
+    }
+// polyphase mode: correction offsets of brick c1 -- cells on an H or W face of the volume (and inside it), else out of range (= 0)
+#define RS_VOC()                                                                                     \
+    if constexpr (UP2) {                                                                             \
+        const int dok_ = up_od * TD + pl < a.D;                                                      \
+        const int iw_ = c1.ow * TW + col;                                                            \
+        const int wf_ = (int)(iw_ == 0) | (int)(iw_ == a.W - 1);                                     \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
+            const int ih_ = c1.oh * TH + 2 * s + i;                                                  \
+            const int face_ = wf_ | (int)(ih_ == 0) | (int)(ih_ == a.H - 1);                         \
+            voc[i] = (dok_ & face_ & (int)(ih_ < a.H) & (int)(iw_ < a.W)) ? voyo[i] : 0xffffff00u;   \
+        }                                                                                            \
     }
     // One code path per loop (a main / drain diamond inside one loop made hipcc park the accumulators in VGPRs at the
     // loop header: 64 v_accvgpr moves per phase).
@@ -439,6 +512,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
         __builtin_amdgcn_s_barrier();
     }
 #undef RS_VOY
+#undef RS_VOC
+#undef RS_F_UP2
+#undef RS_F_NUP2
+#undef RS_DSC_Y
+#undef RS_DSC_R
+#undef RS_RES_OFF
 #undef t1
 #undef STAMP
 #undef RS_MF
@@ -756,13 +835,83 @@ extern "C" int mvsgi_conv3d_rs_split(const void* x, const void* w_packed_rs, con
 #endif
     static mvsgi::PersistentGeom geo_cache[2][mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
-    auto kern = y_is_f32 ? conv3d_rs32_kernel<true> : conv3d_rs32_kernel<false>;
+    auto kern = y_is_f32 ? conv3d_rs32_kernel<1> : conv3d_rs32_kernel<0>;
     if (mvsgi::persistent_geometry(kern, 256, rs::LDS_BYTES, 1, geo_cache[y_is_f32 ? 1 : 0], "mvsgi_conv3d_rs_split", geo)) return 1;
     const long long resident = (long long)geo.cus / 8 * 8 > 0 ? (long long)geo.cus / 8 * 8 : 8;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), rs::LDS_BYTES,
                        mvsgi::as_stream(stream), a);
     return mvsgi::check_launch("mvsgi_conv3d_rs_split");
 }
+
+// ---- polyphase ResizeConv3d on the 32 -> 32 kernel (MODE 2): internal entry points used by csrc/conv3d_up2poly.hip ----
+namespace mvsgi {
+
+static inline unsigned short host_bf16_rne(float v) {      // round to nearest even, as the device's (__bf16) cast
+    unsigned u;
+    memcpy(&u, &v, 4);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float host_bf16_to_f32(unsigned short h) {
+    const unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// the host statement of rs_pack_weights_kernel: [32][32][27] fp32 -> kRs32PackedBytes in the register-stationary lane order
+void rs32_pack_weights_host(const float* w, void* packed) {
+    unsigned short* out = static_cast<unsigned short*>(packed);
+    for (int sl = 0; sl < 2; ++sl)
+        for (int ct = 0; ct < 2; ++ct)
+            for (int p = 0; p < rs::kPairs; ++p)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int kg = lane >> 4, co = ct * 16 + (lane & 15), ci = sl * 16 + (kg >> 1) * 8;
+                    const int k = rs::pair_k(p, kg & 1), kw = rs::pair_kw(p, kg & 1);
+                    const size_t o = ((((size_t)(sl * 2 + ct) * rs::kPairs + p) * 2) * 64 + lane) * 8;
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = k >= 0 ? w[((size_t)co * 32 + ci + j) * 27 + k * 3 + kw] : 0.f;
+                        const unsigned short h = host_bf16_rne(v);
+                        out[o + j] = h;
+                        out[o + 64 * 8 + j] = host_bf16_rne(v - host_bf16_to_f32(h));
+                    }
+                }
+}
+
+int rs32_up2_launch(const void* x_split, const void* w_sets, const float* scale32, const float* shift32, float* y, int B, int D,
+                    int H, int W, float neg_slope, hipStream_t st) {
+    MVSGI_REQUIRE((long long)(D + 2) * (H + 2) * (W + 2) * 128 < (1ll << 31) && (long long)D * H * W * 512 < (1ll << 31),
+                  "mvsgi_conv3d_up2_poly_f32: frame too large for 32-bit offsets");
+    RsArgs a{};
+    a.x = static_cast<const unsigned char*>(x_split);
+    a.y = reinterpret_cast<unsigned char*>(y);
+    a.res = nullptr;
+    a.wp = static_cast<const bf16x8*>(w_sets);
+    a.scale = scale32;
+    a.shift = shift32;
+    a.B = B; a.D = D; a.H = H; a.W = W;
+    a.neg_slope = neg_slope;
+    a.tiles_d = (int)cdiv(D, rs::TD);
+    a.tiles_h = (int)cdiv(H, rs::TH);
+    a.tiles_w = (int)cdiv(W, rs::TW);
+    const long long per_role = (long long)B * a.tiles_h * a.tiles_w;
+    MVSGI_REQUIRE(per_role < (1ll << 31), "mvsgi_conv3d_up2_poly_f32: too many units");
+    a.total_units = (int)per_role;
+    a.wp_set = (long long)(kRs32PackedBytes / 16);
+    static PersistentGeom geo_cache[kMaxDevices] = {};
+    PersistentGeom geo;
+    if (persistent_geometry(conv3d_rs32_kernel<2>, 256, rs::LDS_BYTES, 1, geo_cache, "mvsgi_conv3d_up2_poly_f32", geo)) return 1;
+    // grid = 8 XCDs x R roles x walkers; one workgroup per CU when the roles fit, never fewer than one walker per (XCD, role)
+    const int R = 4 * a.tiles_d;
+    long long walkers = geo.cus / (8 * R);
+    const long long most = cdiv(per_role, 8);             // bricks of the largest XCD share
+    if (walkers > most) walkers = most;
+    if (walkers < 1) walkers = 1;
+    a.walkers = (int)walkers;
+    hipLaunchKernelGGL(conv3d_rs32_kernel<2>, dim3((unsigned)(8 * R * walkers)), dim3(256), rs::LDS_BYTES, st, a);
+    return check_launch("mvsgi_conv3d_up2_poly_f32(main)");
+}
+
+}  // namespace mvsgi
 
 // BaseConvBlk3d.forward for Cin = Cout = 16, stride 1, no residual (post_vol, spherical_sweep_avg.py:30-36,165) on a
 // split-padded input, fp32 [B][D][H][W][16] output; w_packed_rs from mvsgi_conv3d_rs_pack_weights(16, 16).

@@ -42,7 +42,7 @@ _USE_V32 = os.environ.get("MVSGI_V32", "0") != "0"
 class ConvLaunch:
     """Device-resident launch arguments of one BaseConvBlk3d: PyTorch-layout weight, packed
     MFMA weight (or None), per-channel scale/shift (eval BatchNorm3d or bias), stride, slope."""
-    __slots__ = ("w", "wp", "wp_b3", "wp_c16", "wp_v32", "wp_rs", "scale", "shift", "stride", "neg_slope", "cin", "cout", "key")
+    __slots__ = ("w", "wp", "wp_b3", "wp_c16", "wp_v32", "wp_rs", "wp_poly", "scale", "shift", "stride", "neg_slope", "cin", "cout", "key")
 
     def run(self, x_ndhwc: Tensor, res: Optional[Tensor] = None, impl: Optional[int] = None) -> Tensor:
         wp = self.wp
@@ -92,6 +92,27 @@ class ConvLaunch:
         if self.wp_v32 is None:
             self.wp_v32 = H.pack_conv_weights_bf16x3_v32(self.w)
         return self.wp_v32
+
+    def poly_ok(self) -> bool:
+        """ResizeConv3d in polyphase form on the register-stationary kernel (csrc/conv3d_up2poly.hip)."""
+        return H.get_conv_mode() == "bf16x3" and self.stride == 1 and H.conv3d_up2_poly_applies(self.cin, self.cout, self.neg_slope)
+
+    def _poly_plan(self, D: int, Hh: int, W: int):
+        """Folded phase weights + face tables for a low-resolution input of D x Hh x W (built once per size, kept)."""
+        if self.wp_poly is None:
+            self.wp_poly = {}
+        k = (int(D), int(Hh), int(W))
+        if k not in self.wp_poly:
+            self.wp_poly[k] = H.conv3d_up2_poly_plan(self.w, *k)
+        return self.wp_poly[k]
+
+    def run_up2_poly(self, x_split, out=None) -> Tensor:
+        return H.conv3d_up2_poly(x_split, self._poly_plan(x_split.D, x_split.H, x_split.W), self.scale, self.shift,
+                                 neg_slope=self.neg_slope, out=out)
+
+    def run_up2_split(self, x_lowres_ndhwc: Tensor, res: Optional[Tensor], out) -> "H.SplitAct":
+        """conv(trilinear_x2(x)) (+ res) written split-padded into `out` (the polyphase layer's input)."""
+        return H.conv3d_up2_out_split(x_lowres_ndhwc, self._wp_b3(), self.scale, self.shift, out=out, res=res, neg_slope=self.neg_slope)
 
     def can_fuse_up2(self) -> bool:
         return H.get_conv_mode() == "bf16x3" and self.stride == 1 and self.cin % 16 == 0 and self.cout % 16 == 0
@@ -193,6 +214,7 @@ def lower_conv_block(blk) -> ConvLaunch:
     L.wp_c16 = None
     L.wp_v32 = None
     L.wp_rs = None
+    L.wp_poly = None
     L.scale = scale.contiguous()
     L.shift = shift.contiguous()
     L.stride = int(conv.stride[0])

@@ -96,6 +96,34 @@ def down_block_ndhwc(blk, x: Tensor) -> Tensor:
     return x
 
 
+# MVSGI_POLY=0 keeps out_costs.0 on the streaming kernel with the upsample evaluated in its producers.  MVSGI_POLY_MIN_UNITS: minimum
+# 128-cell bricks (low resolution) per launch for the polyphase form
+_USE_POLY = os.environ.get("MVSGI_POLY", "1") != "0"
+_POLY_MIN_UNITS = int(os.environ.get("MVSGI_POLY_MIN_UNITS", "0"))
+
+
+def _poly_tail(self, x: Tensor, skip: Tensor):
+    """The last up block + out_costs.0 as (up block writing its result split-padded) -> (polyphase ResizeConv3d on the
+    register-stationary kernel), when the layer shapes allow it (32 -> 16 channels: the (16, 32) regulator); else None."""
+    if not (_USE_POLY and len(self.upBlks) > 0):
+        return None
+    up, oc = self.upBlks[len(self.upBlks) - 1], self.out_costs[0]
+    Lu, Lo = cm.lower_conv_block(up.conv), cm.lower_conv_block(oc.conv)
+    if not (Lo.poly_ok() and Lu.can_fuse_up2() and Lu.cout == 32 and oc.scale == 2 and oc.out_pad == 0 and up.scale == 2 and up.out_pad == 0):
+        return None
+    B, Dl, Hl, Wl, _ = x.shape
+    if tuple(skip.shape[1:4]) != (2 * Dl, 2 * Hl, 2 * Wl):
+        return None                                      # odd pyramid: the second trilinear resize of common_modules.py:343-350
+    if B * ((2 * Dl + 1) // 2) * ((2 * Hl + 3) // 4) * ((2 * Wl + 15) // 16) < _POLY_MIN_UNITS:
+        return None
+    bufs = self.__dict__.setdefault("_mvsgi_poly_bufs", {})          # one split-padded buffer per shape, never replaced
+    key = (B, 2 * Dl, 2 * Hl, 2 * Wl, x.device)
+    if key not in bufs:
+        bufs[key] = H.SplitAct(B, 2 * Dl, 2 * Hl, 2 * Wl, 32, x.device)
+    xs = Lu.run_up2_split(x, skip, bufs[key])
+    return Lo.run_up2_poly(xs)
+
+
 def regulator_forward_ndhwc(self, x: Tensor) -> Tensor:
     """unet_regulator.py:120-140 on channels-last tensors."""
     skips = []
@@ -105,7 +133,12 @@ def regulator_forward_ndhwc(self, x: Tensor) -> Tensor:
         if i != n_down - 1:
             skips.append(x)
     skips.reverse()
+    n_up = len(self.upBlks)
     for i, up in enumerate(self.upBlks):
+        if i == n_up - 1:
+            y = _poly_tail(self, x, skips[i])
+            if y is not None:
+                return cm.lower_conv_block(self.out_costs[1]).run(y)
         x = cm.resize_conv_ndhwc(up, x, res=skips[i])
     x = cm.resize_conv_ndhwc(self.out_costs[0], x)
     return cm.lower_conv_block(self.out_costs[1]).run(x)

@@ -328,6 +328,59 @@ def conv3d_up2(x, w_packed_b3, scale, shift, res=None, neg_slope=0.01, out=None,
     return y
 
 
+def conv3d_up2_out_split(x, w_packed_b3, scale, shift, out: "SplitAct", res=None, neg_slope=0.01, w_layout=CONV_BF16X3) -> "SplitAct":
+    """conv3d_up2 with the result written split-padded into `out` (B, 2Dl, 2Hl, 2Wl, Cout)."""
+    lib = _lib.load()
+    x = _dev(x, "x")
+    B, Dl, Hl, Wl, Cin = x.shape
+    Cout = scale.numel()
+    if out.shape != (B, 2 * Dl, 2 * Hl, 2 * Wl, Cout):
+        raise AssertionError(f"split output {out.shape} does not match {(B, 2 * Dl, 2 * Hl, 2 * Wl, Cout)}")
+    if res is not None:
+        res = _dev(res, "res")
+        if tuple(res.shape) != out.shape:
+            raise AssertionError(f"residual {tuple(res.shape)} does not match output {out.shape}")
+    _lib.check(lib.mvsgi_conv3d_up2_f32_out_split(x.data_ptr(), _ptr(w_packed_b3), w_layout, scale.data_ptr(), shift.data_ptr(), _ptr(res),
+                                                  out.buf.data_ptr(), B, Cin, Dl, Hl, Wl, Cout, float(neg_slope), _stream_ptr(x)),
+               "mvsgi_conv3d_up2_f32_out_split")
+    return out
+
+
+def conv3d_up2_poly_applies(cin: int, cout: int, neg_slope: float) -> bool:
+    """The polyphase ResizeConv3d kernel (csrc/conv3d_up2poly.hip) serves this layer (no skip input)."""
+    return cin == 32 and cout == 16 and 0.0 <= neg_slope <= 1.0
+
+
+def conv3d_up2_poly_plan(w_oidhw: torch.Tensor, D: int, H: int, W: int) -> torch.Tensor:
+    """Lowering of a [16, 32, 3, 3, 3] ResizeConv3d weight for a low-resolution input of D x H x W voxels: folded phase weights in
+    the register-stationary layout, face-correction weights and role tables (built on the host by the library, float64)."""
+    lib = _lib.load()
+    if tuple(w_oidhw.shape) != (16, 32, 3, 3, 3):
+        raise AssertionError(f"polyphase plan needs a [16, 32, 3, 3, 3] weight, got {tuple(w_oidhw.shape)}")
+    n = lib.mvsgi_conv3d_up2_poly_plan_bytes(D, H, W)
+    if not n:
+        raise RuntimeError("mvsgi_conv3d_up2_poly_plan_bytes: bad dims")
+    wh = w_oidhw.detach().to("cpu", torch.float32).contiguous()
+    plan = torch.empty(n, dtype=torch.uint8)
+    _lib.check(lib.mvsgi_conv3d_up2_poly_plan(wh.data_ptr(), plan.data_ptr(), D, H, W), "mvsgi_conv3d_up2_poly_plan")
+    return plan.to(w_oidhw.device)
+
+
+def conv3d_up2_poly(x: "SplitAct", plan: torch.Tensor, scale, shift, neg_slope=0.01, out=None) -> torch.Tensor:
+    """act(conv(trilinear_x2(x)) * scale + shift) for Cin = 32, Cout = 16 in polyphase form: x split-padded (low resolution)
+    -> fp32 [B, 2D, 2H, 2W, 16]."""
+    lib = _lib.load()
+    if x.C != 32 or scale.numel() != 16:
+        raise AssertionError("conv3d_up2_poly is the 32 -> 16 kernel")
+    shp = (x.B, 2 * x.D, 2 * x.H, 2 * x.W, 16)
+    y = out if out is not None else torch.empty(shp, device=x.buf.device, dtype=torch.float32)
+    if tuple(y.shape) != shp or not y.is_contiguous():
+        raise AssertionError(f"output {tuple(y.shape)} does not match {shp}")
+    _lib.check(lib.mvsgi_conv3d_up2_poly_f32(x.buf.data_ptr(), plan.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(),
+                                             x.B, x.D, x.H, x.W, float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_up2_poly_f32")
+    return y
+
+
 def conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, w_layout=CONV_BF16X3) -> str:
     lib = _lib.load()
     name = lib.mvsgi_conv3d_up2_variant_f32(B, Cin, Dl, Hl, Wl, Cout, w_layout)

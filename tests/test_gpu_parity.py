@@ -1241,3 +1241,66 @@ def test_softargmin_row_pair_kernel_equals_pixel_kernel_and_oracle(shape):
     ref_pr = F.softmax(up, 1)
     ref_inv = (ref_pr * inv_idx.cpu().view(1, -1, 1, 1)).sum(1, keepdim=True)
     assert _rel(inv.cpu().numpy(), ref_inv.numpy()) <= 1e-5 and _rel(pr.cpu().numpy(), ref_pr.numpy()) <= 1e-5
+
+
+# ------------------------------------------------------------------------------ polyphase ResizeConv3d (out_costs.0)
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (2, 1, 3, 5), (1, 2, 4, 16), (1, 3, 5, 7), (2, 4, 6, 18), (3, 5, 9, 33), (1, 2, 2, 2),
+                                   (2, 8, 40, 160), (9, 3, 12, 40)])
+@pytest.mark.parametrize("slope", [0.01, 1.0])
+def test_conv3d_up2_polyphase_vs_interpolate_then_conv(shape, slope):
+    """ResizeConv3d 32 -> 16 in polyphase form (8 phase convolutions over the low-resolution tensor on the register-stationary
+    kernel + face / edge corrections) against F.interpolate(trilinear x2) -> conv3d -> scale / shift -> LeakyReLU on the same
+    16-bit-split input: single-cell axes (every cell first AND last), two-cell axes (no interior), odd and ragged sizes, the
+    full out_costs.0 size, and more bricks than workgroups."""
+    B, d, h, w = shape
+    rng = np.random.default_rng(sum(shape))
+    x = _g(rng.standard_normal((B, d, h, w, 32), dtype=np.float32))
+    wt = (rng.standard_normal((16, 32, 3, 3, 3)) / np.sqrt(27 * 32)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, 16).astype(np.float32)
+    sh = (rng.standard_normal(16) * 0.1).astype(np.float32)
+    xs = H.act_to_split(x)
+    plan = H.conv3d_up2_poly_plan(_g(wt), d, h, w)
+    y = torch.full((B, 2 * d, 2 * h, 2 * w, 16), float("nan"), device=DEV)          # every voxel must be written
+    H.conv3d_up2_poly(xs, plan, _g(sc), _g(sh), neg_slope=slope, out=y)
+    xq = H.act_from_split(xs).cpu().permute(0, 4, 1, 2, 3).double()
+    up = F.interpolate(xq, scale_factor=2, mode="trilinear", align_corners=False)
+    ref = F.conv3d(up, torch.from_numpy(wt).double(), padding=1) * torch.from_numpy(sc).double().view(1, -1, 1, 1, 1) \
+        + torch.from_numpy(sh).double().view(1, -1, 1, 1, 1)
+    ref = torch.where(ref > 0, ref, ref * slope).permute(0, 2, 3, 4, 1).numpy()
+    got = y.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert _rel(got, ref) <= 1e-4                                     # split-bf16 products: ~2^-16 each
+    # the faces on their own (a wrong correction is a small fraction of the tensor's maximum only there)
+    for sl in (np.s_[:, :2], np.s_[:, -2:], np.s_[:, :, :2], np.s_[:, :, -2:], np.s_[:, :, :, :2], np.s_[:, :, :, -2:]):
+        assert _rel(got[sl], ref[sl]) <= 1e-4
+
+
+def test_regulator_polyphase_tail_matches_streaming_and_goldens(golden_dir):
+    """The (16, 32) regulator with out_costs.0 in polyphase form (and the last up block writing split-padded) against the
+    streaming kernels and the reference goldens."""
+    from mvs_gi_amd.dropin import cost_volume_regulator as cr
+    import parity_log
+    name = "std_d16_rand"
+    case = SMALL_CASES[name]
+    cfg, z = case["cfg"], _load(golden_dir, name)
+    inp = synth.make_inputs(cfg, seed=case["seed"], batch=case["batch"], grid_kind=case["grid_kind"],
+                            grid_mask_dtype=case["grid_mask_dtype"])
+    feats = _g(inp["feats"])
+    old_mode, old_use = H.get_conv_mode(), cr._USE_POLY
+    try:
+        H.set_conv_mode("bf16x3")
+        for gain in case["gains"]:
+            w = synth.make_weights(cfg, seed=case["seed"], gain=gain)
+            outs = {}
+            for use in (False, True):
+                cr._USE_POLY = use
+                hp = HotPath(cfg, w, inp, device=DEV)
+                outs[use] = hp(feats)[0].cpu().numpy()
+                assert ("_mvsgi_poly_bufs" in hp.cv_regulator.__dict__) == use        # the polyphase tail really ran
+            ref = z[f"inv_dist_g{gain:g}"]
+            err = _rel(outs[True], ref)
+            parity_log.record(name + "(poly)", "bf16x3", gain, err, _l1(outs[True], ref), "golden")
+            assert err <= 1e-3 and _rel(outs[True], outs[False]) <= 5e-4
+    finally:
+        H.set_conv_mode(old_mode)
+        cr._USE_POLY = old_use

@@ -76,17 +76,20 @@ def epilogue_items(k):
     s = []
     for e in range(4):
         s.append((1, f"t{k}[{e}] = keepB[{k}][{e}] + pt{k}[{e}];"))
+    # polyphase mode: the face correction (raw, pre-scale) read back from the output tensor joins the sum before scale / shift
+    for e in range(4):
+        s.append((0, f"RS_F_UP2(t{k}[{e}] = t{k}[{e}] + __builtin_bit_cast(float, rresB[{k}][{e}]);)"))
     for e in range(4):
         s.append((1, f"t{k}[{e}] = __builtin_fmaf(t{k}[{e}], esc[{j}][{e}], esh[{j}][{e}]);"))
-    s.append((2.0, f"sa{k} = __builtin_amdgcn_permlane16_swap(rresB[{k}][0], rresB[{k}][2], false, false);"))
-    s.append((2.0, f"sb{k} = __builtin_amdgcn_permlane16_swap(rresB[{k}][1], rresB[{k}][3], false, false);"))
+    s.append((2.0, f"RS_F_NUP2(sa{k} = __builtin_amdgcn_permlane16_swap(rresB[{k}][0], rresB[{k}][2], false, false);)"))
+    s.append((2.0, f"RS_F_NUP2(sb{k} = __builtin_amdgcn_permlane16_swap(rresB[{k}][1], rresB[{k}][3], false, false);)"))
     for e, (src, sh) in enumerate((("sa", True), ("sa", False), ("sb", True), ("sb", False))):
         hi = f"{src}{k}[0] << 16" if sh else f"{src}{k}[0] & 0xffff0000u"
         lo = f"{src}{k}[1] << 16" if sh else f"{src}{k}[1] & 0xffff0000u"
-        s.append((1, f"rh{k} = __builtin_bit_cast(float, {hi});"))
-        s.append((1, f"rl{k} = __builtin_bit_cast(float, {lo});"))
-        s.append((1, f"rh{k} = rh{k} + rl{k};"))
-        s.append((1, f"t{k}[{e}] = t{k}[{e}] + rh{k};"))
+        s.append((1, f"RS_F_NUP2(rh{k} = __builtin_bit_cast(float, {hi});)"))
+        s.append((1, f"RS_F_NUP2(rl{k} = __builtin_bit_cast(float, {lo});)"))
+        s.append((1, f"RS_F_NUP2(rh{k} = rh{k} + rl{k};)"))
+        s.append((1, f"RS_F_NUP2(t{k}[{e}] = t{k}[{e}] + rh{k};)"))
     for e in range(4):
         s.append((1, f"u{k} = t{k}[{e}] * a.neg_slope;"))
         s.append((1, f"t{k}[{e}] = __builtin_fmaxf(t{k}[{e}], u{k});"))
@@ -141,7 +144,7 @@ def build(with_pairs: bool):
                     S.put(b * 24 + 3 * r, 1, read_stmt(qn, T, lo))
                     r += 1
     # B. descriptors / masks of this phase (scalar work + a few VALU), early in block 0
-    S.put(1, 0.5, "if constexpr (OUTF32) dsc_y = RS_DESC_OUT(c2, ph >= 2); else dsc_y = RS_DESC(a.y, c2, ph >= 2);")
+    S.put(1, 0.5, "dsc_y = RS_DSC_Y(c2, ph >= 2);")
     S.put(2, 2.0, "RS_VOY()")
     S.put(4, 0.5, "dsc_x = RS_DESC(a.x, nx, ph + 1 < n);")
     # C. keepB <- keepA while pair 13 runs
@@ -193,10 +196,11 @@ def build(with_pairs: bool):
     # H. residual of the previous brick, consumed by the NEXT phase's epilogue (through rresB): requested early, so that it
     #    has almost two phases to arrive; the output stores of this phase's epilogue go last and are the 4 youngest
     #    vector-memory operations at the phase's end (s_waitcnt vmcnt(4) then covers exactly the staging of the next brick)
-    S.put(25, 0.5, "dsc_r = RS_DESC(a.res, c1, (int)(a.res != nullptr) & (int)(ph >= 1) & (int)(ph - 1 < n));")
+    S.put(25, 0.5, "dsc_r = RS_DSC_R(c1, (int)(ph >= 1) & (int)(ph - 1 < n));")
+    S.put(27, 0, "RS_VOC()")        # polyphase mode: this lane's correction offsets for brick c1 (cells on an H / W face), else nothing
     s = 32
     for k in range(4):
-        s = S.place(s, 2.0, f"RS_F_RES(rres[{k}], dsc_r, voy0[{k >> 1}] + {(k & 1) * 64})") + 2
+        s = S.place(s, 2.0, f"RS_F_RES(rres[{k}], dsc_r, RS_RES_OFF({k >> 1}) + {(k & 1) * 64})") + 2
     s = max(11 * 24, last + 1)
     for k in range(4):
         s = S.place(s, 2.0, f"RS_F_EPI(RS_F_STORE(outp[{k}], dsc_y, voy[{k >> 1}] + {(k & 1) * 64}))") + 3
