@@ -78,7 +78,8 @@ def epilogue_items(k):
         s.append((1, f"t{k}[{e}] = keepB[{k}][{e}] + pt{k}[{e}];"))
     # polyphase mode: the face correction (raw, pre-scale) read back from the output tensor joins the sum before scale / shift
     for e in range(4):
-        s.append((0, f"RS_F_UP2(t{k}[{e}] = t{k}[{e}] + __builtin_bit_cast(float, rresB[{k}][{e}]);)"))
+        # (`| 0u`: an rvalue -- __builtin_bit_cast of a vector-element LVALUE reads element 0 whatever the index, hipcc 7.2)
+        s.append((0, f"RS_F_UP2(t{k}[{e}] = t{k}[{e}] + __builtin_bit_cast(float, rresB[{k}][{e}] | 0u);)"))
     for e in range(4):
         s.append((1, f"t{k}[{e}] = __builtin_fmaf(t{k}[{e}], esc[{j}][{e}], esh[{j}][{e}]);"))
     s.append((2.0, f"RS_F_NUP2(sa{k} = __builtin_amdgcn_permlane16_swap(rresB[{k}][0], rresB[{k}][2], false, false);)"))
