@@ -99,7 +99,9 @@ def down_block_ndhwc(blk, x: Tensor) -> Tensor:
 # MVSGI_POLY=0 keeps out_costs.0 on the streaming kernel with the upsample evaluated in its producers.  MVSGI_POLY_MIN_UNITS: minimum
 # 128-cell bricks (low resolution) per launch for the polyphase form
 _USE_POLY = os.environ.get("MVSGI_POLY", "1") != "0"
-_POLY_MIN_UNITS = int(os.environ.get("MVSGI_POLY_MIN_UNITS", "0"))
+# (measured on MI355X, G16V: 400 bricks per frame and role; B = 4: 2722 vs 2837 frames/s with / without, B = 8: 3714 vs 3742, B = 16:
+# 4335 vs 4291, B = 64: 5091 vs 4820 -- three launches and a prologue + two drain phases per workgroup need ~12 frames to pay)
+_POLY_MIN_UNITS = int(os.environ.get("MVSGI_POLY_MIN_UNITS", "4800"))
 
 
 def _poly_tail(self, x: Tensor, skip: Tensor):

@@ -1286,9 +1286,10 @@ def test_regulator_polyphase_tail_matches_streaming_and_goldens(golden_dir):
     inp = synth.make_inputs(cfg, seed=case["seed"], batch=case["batch"], grid_kind=case["grid_kind"],
                             grid_mask_dtype=case["grid_mask_dtype"])
     feats = _g(inp["feats"])
-    old_mode, old_use = H.get_conv_mode(), cr._USE_POLY
+    old_mode, old_use, old_min = H.get_conv_mode(), cr._USE_POLY, cr._POLY_MIN_UNITS
     try:
         H.set_conv_mode("bf16x3")
+        cr._POLY_MIN_UNITS = 0
         for gain in case["gains"]:
             w = synth.make_weights(cfg, seed=case["seed"], gain=gain)
             outs = {}
@@ -1303,4 +1304,4 @@ def test_regulator_polyphase_tail_matches_streaming_and_goldens(golden_dir):
             assert err <= 1e-3 and _rel(outs[True], outs[False]) <= 5e-4
     finally:
         H.set_conv_mode(old_mode)
-        cr._USE_POLY = old_use
+        cr._USE_POLY, cr._POLY_MIN_UNITS = old_use, old_min
