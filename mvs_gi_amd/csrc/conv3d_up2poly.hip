@@ -122,7 +122,8 @@ struct PolyHeader {
     int magic, D, H, W;
     int n_roles, n_edge_cells, n_groups, max_tpf;
     long long off_main, off_facew, off_roles, off_edgew, off_edgecells, total;
-    int pad[12];
+    int sum_tpf;        // 16-cell tiles per frame over all face roles
+    int pad[11];
 };
 static_assert(sizeof(PolyHeader) == 128, "header");
 
@@ -148,13 +149,15 @@ PolyHeader layout(int D, int H, int W) {
     h.off_edgecells = (long long)(o = align256(o));
     o += (size_t)h.n_edge_cells * 4 * 4;
     h.total = (long long)align256(o);
-    int tpf = 0;
+    int tpf = 0, sum = 0;
     for (const Group& g : groups_of(D)) {
         const int a = g.count * (int)mvsgi::cdiv(W, 16), b = g.count * (int)mvsgi::cdiv(H, 16);
         tpf = a > tpf ? a : tpf;
         tpf = b > tpf ? b : tpf;
+        sum += 4 * (nfh * a + nfw * b);       // (pd, ph | pw) roles per face and group
     }
     h.max_tpf = tpf;
+    h.sum_tpf = sum;
     return h;
 }
 
@@ -189,11 +192,13 @@ void pack_face_weights(const float* wsrc, const int* taps, unsigned short* out) 
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void up2_face_kernel(const unsigned char* __restrict__ x, const unsigned char* __restrict__ plan,
                                                           unsigned char* __restrict__ y, int B, long long x_frame, long long y_frame,
-                                                          long long off_facew, long long off_roles) {
+                                                          long long off_facew, long long off_roles, int tiles_per_wg) {
     const int* R = reinterpret_cast<const int*>(plan + off_roles) + (int)blockIdx.y * kRoleInts;
     const int n0 = R[R_N0], nrun = R[R_NRUN];
     const int tiles_run = (nrun + 15) >> 4, tpf = n0 * tiles_run;
-    long long want = ((long long)B * tpf + 95) / 96;             // ~24 tiles per wave
+    // workgroups of this role: its share of ONE resident round of the whole launch (the host sizes tiles_per_wg so that the
+    // roles' workgroups together fill the chip once: a second, nearly empty round doubled the kernel's time)
+    long long want = ((long long)B * tpf + tiles_per_wg - 1) / tiles_per_wg;
     const int chunks = want < 1 ? 1 : (want > (long long)gridDim.x ? (int)gridDim.x : (int)want);
     if ((int)blockIdx.x >= chunks) return;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -427,11 +432,18 @@ extern "C" int mvsgi_conv3d_up2_poly_f32(const void* x_split, const void* plan_d
         hipLaunchKernelGGL(up2_edge_kernel, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, st, static_cast<const unsigned char*>(x_split),
                            P, y, B, D, H, W, h.n_edge_cells, h.n_groups, h.off_edgew, h.off_edgecells);
         if (mvsgi::check_launch("mvsgi_conv3d_up2_poly_f32(edges)")) return 1;
-        long long chunks = mvsgi::cdiv((long long)B * h.max_tpf, 96);
+        // two workgroups per CU are resident (launch bounds): size the roles' workgroups so that all of them fit one round
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        long long slots = 2ll * cus - h.n_roles;          // every role rounds its share up
+        if (slots < 8) slots = 8;
+        long long tpw = mvsgi::cdiv((long long)B * h.sum_tpf, slots);
+        if (tpw < 4) tpw = 4;                             // at least one tile per wave
+        long long chunks = mvsgi::cdiv((long long)B * h.max_tpf, tpw);
         chunks = chunks < 1 ? 1 : (chunks > 4096 ? 4096 : chunks);
         hipLaunchKernelGGL(up2_face_kernel, dim3((unsigned)chunks, (unsigned)h.n_roles), dim3(256), 0, st,
                            static_cast<const unsigned char*>(x_split), P, reinterpret_cast<unsigned char*>(y), B, x_frame, y_frame,
-                           h.off_facew, h.off_roles);
+                           h.off_facew, h.off_roles, (int)tpw);
         if (mvsgi::check_launch("mvsgi_conv3d_up2_poly_f32(faces)")) return 1;
     }
     return mvsgi::rs32_up2_launch(x_split, P + h.off_main, scale, shift, y, B, D, H, W, neg_slope, st);
