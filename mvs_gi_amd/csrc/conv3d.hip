@@ -299,7 +299,7 @@ enum Variant {
     V_DIRECT1, V_DIRECT4, V_HEAD,
     V_S1_N16_B256, V_S1_N32_B256, V_S1_N32_B64, V_S1_N64_B128, V_S1_N64_B64, V_S2_N32_B64, V_S2_N64_B64,
     // split-bf16 kernel: 16-wide bricks (conflict-free LDS reads); N = couts per workgroup
-    B3_N16, B3_N32, B3_N48, B3_N64, B3_N96, B3_N32_S, B3_N64_S, B3_N16_T, B3_N32_T, B3_S2_N32, B3_S2_N64,
+    B3_N16, B3_N32, B3_N48, B3_N64, B3_N64_H5, B3_N96, B3_N32_S, B3_N64_S, B3_N16_T, B3_N32_T, B3_S2_N32, B3_S2_N64,
     // split-bf16 kernel with the trilinear x2 upsample fused into its producers (even bricks only)
     B3U_N16, B3U_N32, B3U_N32_M, B3U_N48, B3U_N64, B3U_N96,
     // Cout == 16 plane schedule (weights from mvsgi_conv3d_pack_weights_bf16x3_c16), plain and fused-upsample
@@ -316,6 +316,7 @@ const char* const kVariantNames[V_COUNT] = {
     "conv3d_mfma_kernel<2, 2, 2, 2, 2, 4, 8, 2>",
     "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false>",
     "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, false, false, false>",
+    "conv3d_bf16x3_kernel<2, 5, 2, 2, 2, 5, 16, 1, 3, false, false, false>",
     "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false>",
     "conv3d_bf16x3_kernel<2, 2, 2, 2, 1, 4, 16, 1, 3, false, false, false>",
     "conv3d_bf16x3_kernel<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false>",
@@ -407,6 +408,11 @@ int select_variant(const ConvArgs& a, int impl) {
         if (CT == 2) return big >= 384 ? B3_N32 : B3_N32_S;
         if (CT == 3) return B3_N48;
         if (CT % 6 == 0 && mid * (CT / 6) >= 384) return B3_N96;
+        // planes whose height is a multiple of 5 but not of 4 (the 10 x 40 planes of UNet level 2): 2 x 5 x 16 bricks cover them
+        // exactly where 2 x 4 x 16 ones pad 10 rows to 12 (17 % of the MFMAs) and stage 7 % more halo per voxel
+        static const bool h5 = !getenv("MVSGI_NO_H5");
+        if (h5 && a.Ho % 5 == 0 && a.Ho % 4 != 0 && (long long)a.B * mvsgi::cdiv(a.Do, 2) * (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16) * mvsgi::cdiv(CT, 4) >= 384)
+            return B3_N64_H5;
         if (mid * mvsgi::cdiv(CT, 4) >= 384) return B3_N64;
         // a frame or two (latency path): 64-voxel bricks, and as few couts per workgroup as it takes to put a few hundred
         // workgroups on the chip -- each then walks Cin / 16 slices of 42 (16 couts) or 84 (32 couts) MFMAs per wave
@@ -442,6 +448,7 @@ int launch_variant(int v, const ConvArgs& a, hipStream_t st) {
         case B3_N32: return launch_bf16x3<2, 4, 4, 1, 4, 4, 16, 1>(a, st);
         case B3_N48: return launch_bf16x3<3, 4, 4, 1, 4, 4, 16, 1>(a, st);
         case B3_N64: return launch_bf16x3<2, 4, 2, 2, 2, 4, 16, 1>(a, st);
+        case B3_N64_H5: return launch_bf16x3<2, 5, 2, 2, 2, 5, 16, 1>(a, st);
         case B3_N96: return launch_bf16x3<3, 4, 2, 2, 2, 4, 16, 1>(a, st);
         case B3_N32_S: return launch_bf16x3<2, 1, 4, 1, 1, 4, 16, 1>(a, st);
         case B3_N64_S: return launch_bf16x3<2, 2, 2, 2, 1, 4, 16, 1>(a, st);

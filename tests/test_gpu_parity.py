@@ -168,6 +168,8 @@ CONV_SHAPES = [
     (1, 96, 96, 3, 6, 10, 1, True, 0.0),        # ReLU
     (1, 96, 192, 3, 6, 10, 2, False, 0.01),
     (1, 64, 32, 5, 7, 9, 1, False, 1.0),        # identity activation
+    (32, 128, 128, 2, 10, 40, 1, True, 0.01),   # UNet level 2 at 32 frames: the 2 x 5 x 16 brick variant (H a multiple of 5, not of 4)
+    (32, 64, 64, 3, 15, 21, 1, True, 0.01),     # the same variant, ragged in D and W
 ]
 
 
@@ -217,6 +219,8 @@ def test_conv3d_bf16x3_vs_oracle(shape):
     wg = _g(w)
     wp = H.pack_conv_weights_bf16x3(wg)
     assert "bf16x3" in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3)
+    if B == 32:
+        assert "<2, 5, 2, 2, 2, 5, 16" in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3)
     y = H.conv3d(xg, wg, wp, _g(scale), _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3)
     err = _rel(_ncdhw(y), yref)
     assert err <= 1e-4, err
