@@ -192,7 +192,7 @@ class ConvProbe:
             y = self.orig_rs(x, w_packed_rs, scale, shift, res, neg_slope, out, out_f32)
             e.record()
             nv = x.B * x.D * x.H * x.W
-            self.records.append(("conv3d_rs32_kernel<%s>" % ("true" if out_f32 else "false"),
+            self.records.append(("conv3d_rs32_kernel<%d>" % (1 if out_f32 else 0),
                                  2.0 * 27 * x.C * scale.numel() * nv, s, e, 4.0 * nv * (x.C + scale.numel() * (2 if res is not None else 1))))
             return y
 
@@ -282,7 +282,9 @@ class ConvProbe:
         def d_softargmin(a, k, r):
             costs, scale = a[0], a[2]
             inv, pr = r
-            return "softargmin_kernel", costs.numel() * 4 + inv.numel() * 4 + (pr.numel() * 4 if pr is not None else 0)
+            D = costs.shape[1]
+            name = f"softargmin_rows_kernel<{16 if D <= 16 else (32 if D <= 32 else 0)}>" if scale == 2 else "softargmin_kernel"
+            return name, costs.numel() * 4 + inv.numel() * 4 + (pr.numel() * 4 if pr is not None else 0)
 
         def d_transpose(name):
             return lambda a, k, r: (name, 8 * r.numel())

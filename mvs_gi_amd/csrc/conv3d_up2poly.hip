@@ -113,9 +113,9 @@ std::vector<Face> faces_of(int n) {
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kMagic = 0x50325032;
 constexpr int kRoleInts = 32;
-enum { R_WOFF = 0, R_NTAPS, R_TAP0, R_XBASE = 11, R_XS0, R_XSRUN, R_N0, R_NRUN, R_YBASE0, R_YBASE1, R_YS0, R_YSRUN, R_MFIRST, R_MLAST };
+enum { R_WOFF = 0, R_NTAPS, R_TAP0, R_XBASE = 11, R_XS0, R_XSRUN, R_N0, R_NRUN, R_YS0, R_YSRUN, R_MFIRST, R_MLAST, R_YBASE0 = 20 };   // R_YBASE0 .. +7: one per phase
 enum { ST_WRITE = 0, ST_RMW = 1, ST_SKIP = 2 };
-constexpr size_t kFaceRoleWBytes = (size_t)9 * 2 * 2 * 64 * 16;      // [tap][n-tile][hi|lo][lane] bf16x8
+constexpr size_t kFaceRoleWBytes = (size_t)9 * 8 * 2 * 64 * 16;      // [tap][phase][hi|lo][lane] bf16x8 = 147,456 B: the role's LDS image
 constexpr size_t kEdgeSetFloats = (size_t)9 * 32 * 16;               // [tap (td, th)][ci][co]
 
 struct PolyHeader {
@@ -135,7 +135,7 @@ PolyHeader layout(int D, int H, int W) {
     h.D = D; h.H = H; h.W = W;
     const int ng = (int)groups_of(D).size(), nfh = (int)faces_of(H).size(), nfw = (int)faces_of(W).size();
     h.n_groups = ng;
-    h.n_roles = (nfh + nfw) * 2 * 2 * ng;
+    h.n_roles = (nfh + nfw) * ng;            // (face, D class): a role evaluates all 8 phases of its cells
     h.n_edge_cells = nfh * nfw;
     size_t o = sizeof(PolyHeader);
     h.off_main = (long long)(o = align256(o));
@@ -154,22 +154,22 @@ PolyHeader layout(int D, int H, int W) {
         const int a = g.count * (int)mvsgi::cdiv(W, 16), b = g.count * (int)mvsgi::cdiv(H, 16);
         tpf = a > tpf ? a : tpf;
         tpf = b > tpf ? b : tpf;
-        sum += 4 * (nfh * a + nfw * b);       // (pd, ph | pw) roles per face and group
+        sum += nfh * a + nfw * b;
     }
     h.max_tpf = tpf;
     h.sum_tpf = sum;
     return h;
 }
 
-// face-role weights: wsrc [2 n-tiles][16][32][27] (folded), taps[9] = indices into the 27 -> [tap][j][hi|lo][lane][8]
+// face-role weights: wsrc [8 phases][16][32][27] (folded), taps[9] = indices into the 27 -> [tap][phase][hi|lo][lane][8]
 void pack_face_weights(const float* wsrc, const int* taps, unsigned short* out) {
     for (int t = 0; t < 9; ++t)
-        for (int j = 0; j < 2; ++j)
+        for (int ph = 0; ph < 8; ++ph)
             for (int lane = 0; lane < 64; ++lane) {
                 const int kg = lane >> 4, co = lane & 15;
-                const size_t o = (((size_t)(t * 2 + j) * 2) * 64 + lane) * 8;
+                const size_t o = (((size_t)(t * 8 + ph) * 2) * 64 + lane) * 8;
                 for (int e = 0; e < 8; ++e) {
-                    const float v = wsrc[(((size_t)j * 16 + co) * 32 + kg * 8 + e) * 27 + taps[t]];
+                    const float v = wsrc[(((size_t)ph * 16 + co) * 32 + kg * 8 + e) * 27 + taps[t]];
                     unsigned u;
                     memcpy(&u, &v, 4);
                     const unsigned short hi = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
@@ -186,42 +186,43 @@ void pack_face_weights(const float* wsrc, const int* taps, unsigned short* out) 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// device: face convolutions on the matrix cores.  grid = (chunks, roles); a wave keeps its role's 9 x 2 weight fragments
-// (hi, lo) in registers and walks 16-cell tiles along the role's run axis; A = weights [16 couts][32 cin], B = the cells'
-// split-padded records read straight from global memory (already hi | lo), D[cout 4 kg + r][cell] -> 16-byte stores.
+// device: face convolutions on the matrix cores.  grid = (chunks, roles), role = (face, D class); one workgroup of 16 waves per CU: the
+// role's 9 taps x 8 phases of weight fragments (hi, lo: 144 KiB) sit in LDS for the whole launch and every wave walks 16-cell
+// tiles along the role's run axis, evaluating ALL 8 output phases of a tile from one set of 18 activation fragments (the
+// first version kept 2 phases' weights in registers and re-read the cells per (pd, ph) role: 89 % of its wave cycles were
+// waits on those loads).  A = weights [16 couts][32 cin] from LDS, B = the cells' split-padded records straight from global
+// memory (already hi | lo), D[cout 4 kg + r][cell] -> 16-byte stores.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void up2_face_kernel(const unsigned char* __restrict__ x, const unsigned char* __restrict__ plan,
+__global__ __launch_bounds__(1024) void up2_face_kernel(const unsigned char* __restrict__ x, const unsigned char* __restrict__ plan,
                                                           unsigned char* __restrict__ y, int B, long long x_frame, long long y_frame,
                                                           long long off_facew, long long off_roles, int tiles_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fw_lds[];
     const int* R = reinterpret_cast<const int*>(plan + off_roles) + (int)blockIdx.y * kRoleInts;
     const int n0 = R[R_N0], nrun = R[R_NRUN];
     const int tiles_run = (nrun + 15) >> 4, tpf = n0 * tiles_run;
-    // workgroups of this role: its share of ONE resident round of the whole launch (the host sizes tiles_per_wg so that the
-    // roles' workgroups together fill the chip once: a second, nearly empty round doubled the kernel's time)
+    // workgroups of this role: its share of ONE resident round of the whole launch (sized by the host)
     long long want = ((long long)B * tpf + tiles_per_wg - 1) / tiles_per_wg;
     const int chunks = want < 1 ? 1 : (want > (long long)gridDim.x ? (int)gridDim.x : (int)want);
     if ((int)blockIdx.x >= chunks) return;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, kg = lane >> 4;
-    const bf16x8* wp = reinterpret_cast<const bf16x8*>(plan + off_facew) + (long long)R[R_WOFF] + lane;
-    bf16x8 wh[9][2], wl[9][2];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            wh[t][j] = wp[((t * 2 + j) * 2) * 64];
-            wl[t][j] = wp[((t * 2 + j) * 2 + 1) * 64];
-        }
-    int tap[9];
+    {   // the role's weights -> LDS (16-byte pieces, coalesced)
+        const u32x4* src = reinterpret_cast<const u32x4*>(plan + off_facew) + (long long)R[R_WOFF];
+        for (int i = tid; i < (int)(kFaceRoleWBytes / 16); i += 1024) reinterpret_cast<u32x4*>(fw_lds)[i] = src[i];
+    }
+    __syncthreads();
+    int tap[9], yb[8];
 #pragma unroll
     for (int t = 0; t < 9; ++t) tap[t] = R[R_TAP0 + t];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) yb[p] = R[R_YBASE0 + p];
     const int x_base = R[R_XBASE], x_s0 = R[R_XS0], x_srun = R[R_XSRUN];
     const int y_s0 = R[R_YS0], y_srun = R[R_YSRUN];
-    const int yb[2] = {R[R_YBASE0], R[R_YBASE1]};
     const int m_first = R[R_MFIRST], m_last = R[R_MLAST];
     const int lane_x = (kg >> 1) * 64 + (kg & 1) * 16;           // this lane's 8 input channels: hi piece (lo piece 32 B on)
-    const int total = B * tpf, stride = chunks * 4;
-    for (int t = (int)blockIdx.x * 4 + wave; t < total; t += stride) {
+    const bf16x8* wl_ = reinterpret_cast<const bf16x8*>(fw_lds) + lane;
+    const int total = B * tpf, stride = chunks * 16;
+    for (int t = (int)blockIdx.x * 16 + wave; t < total; t += stride) {
         const int rt = t % tiles_run;
         int q = t / tiles_run;
         const int o0 = q % n0, b = q / n0;
@@ -236,24 +237,32 @@ __global__ __launch_bounds__(256, 2) void up2_face_kernel(const unsigned char* _
             fh[k] = __builtin_amdgcn_raw_buffer_load_b128(dx, xo + (unsigned)tap[k], 0, 0);
             fl[k] = __builtin_amdgcn_raw_buffer_load_b128(dx, xo + (unsigned)tap[k] + 32u, 0, 0);
         }
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 acc[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the weight fragments are the same LDS words for every tile: launder the base per tile (and fence the taps) or the compiler
+        // hoists all 144 fragment reads out of the tile loop and spills them
+        const bf16x8* wt = wl_;
+        asm volatile("" : "+v"(wt));
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const bf16x8 xh = __builtin_bit_cast(bf16x8, fh[k]), xl = __builtin_bit_cast(bf16x8, fl[k]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[k][j], xh, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[k][j], xl, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[k][j], xh, acc[j], 0, 0, 0);
+            for (int p = 0; p < 8; ++p) {
+                const bf16x8 wh = wt[((k * 8 + p) * 2) * 64], wl = wt[((k * 8 + p) * 2 + 1) * 64];
+                acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[p], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         const int mode = run == 0 ? m_first : (run == nrun - 1 ? m_last : ST_WRITE);
         if (ok && mode != ST_SKIP) {
             unsigned char* yf = y + (long long)b * y_frame + (long long)o0 * y_s0 + (long long)run * y_srun + kg * 16;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                f32x4* dst = reinterpret_cast<f32x4*>(yf + yb[j]);
-                *dst = mode == ST_RMW ? *dst + acc[j] : acc[j];
+            for (int p = 0; p < 8; ++p) {
+                f32x4* dst = reinterpret_cast<f32x4*>(yf + yb[p]);
+                *dst = mode == ST_RMW ? *dst + acc[p] : acc[p];
             }
         }
     }
@@ -339,54 +348,57 @@ extern "C" int mvsgi_conv3d_up2_poly_plan(const float* w_oidhw_host, void* plan_
     const std::vector<Face> fhs = faces_of(H), fws = faces_of(W);
     int* roles = reinterpret_cast<int*>(P + h.off_roles);
     int r = 0;
-    std::vector<float> w2(2 * 16 * 32 * 27);
-    auto emit = [&](const int* taps27, const int* tap_off, int x_base, int x_s0, int x_srun, int n0, int nrun, int y0, int y1, int y_s0,
+    std::vector<float> w8(8 * 16 * 32 * 27);
+    auto emit = [&](const int* taps27, const int* tap_off, int x_base, int x_s0, int x_srun, int n0, int nrun, const int* yb, int y_s0,
                     int y_srun, int m_first, int m_last) {
-        pack_face_weights(w2.data(), taps27, reinterpret_cast<unsigned short*>(P + h.off_facew + (size_t)r * kFaceRoleWBytes));
+        pack_face_weights(w8.data(), taps27, reinterpret_cast<unsigned short*>(P + h.off_facew + (size_t)r * kFaceRoleWBytes));
         int* R = roles + (size_t)r * kRoleInts;
         R[R_WOFF] = (int)((size_t)r * kFaceRoleWBytes / 16);
         R[R_NTAPS] = 9;
         for (int t = 0; t < 9; ++t) R[R_TAP0 + t] = tap_off[t];
         R[R_XBASE] = x_base; R[R_XS0] = x_s0; R[R_XSRUN] = x_srun; R[R_N0] = n0; R[R_NRUN] = nrun;
-        R[R_YBASE0] = y0; R[R_YBASE1] = y1; R[R_YS0] = y_s0; R[R_YSRUN] = y_srun; R[R_MFIRST] = m_first; R[R_MLAST] = m_last;
+        for (int p = 0; p < 8; ++p) R[R_YBASE0 + p] = yb[p];
+        R[R_YS0] = y_s0; R[R_YSRUN] = y_srun; R[R_MFIRST] = m_first; R[R_MLAST] = m_last;
         ++r;
     };
-    for (const Group& g : gs)
-        for (int pd = 0; pd < 2; ++pd) {
-            const M3 Md = class_matrix(pd, g.cls);
-            // H faces: (Md x delta_h x Mw_interior), taps (td, tw) at th = 1, run axis = w, n-tiles = pw; the run ends are edge cells:
-            // the edge kernel has written there, accumulate
-            for (const Face& fh : fhs)
-                for (int ph = 0; ph < 2; ++ph) {
-                    for (int pw = 0; pw < 2; ++pw)
-                        fold(Md, face_delta(ph, fh.cls), class_matrix(pw, INT), w, w2.data() + (size_t)pw * 16 * 32 * 27);
-                    int taps27[9], tap_off[9];
-                    for (int td = 0; td < 3; ++td)
-                        for (int tw = 0; tw < 3; ++tw) {
-                            taps27[td * 3 + tw] = td * 9 + 3 + tw;
-                            tap_off[td * 3 + tw] = ((td - 1) * Hp * Wp + (tw - 1)) * 128;
-                        }
-                    const int yb = ((2 * g.first + pd) * Hh + 2 * fh.idx + ph) * Wh * 64;
-                    emit(taps27, tap_off, (((g.first + 1) * Hp + fh.idx + 1) * Wp + 1) * 128, Hp * Wp * 128, 128, g.count, W, yb, yb + 64,
-                         2 * Hh * Wh * 64, 128, ST_RMW, ST_RMW);
+    for (const Group& g : gs) {
+        // H faces: (Md x delta_h x Mw_interior), taps (td, tw) at th = 1, run axis = w; the run ends are edge cells: the edge
+        // kernel has written there, accumulate
+        for (const Face& fh : fhs) {
+            int yb[8];
+            for (int p = 0; p < 8; ++p) {
+                const int pd = p >> 2, ph = (p >> 1) & 1, pw = p & 1;
+                fold(class_matrix(pd, g.cls), face_delta(ph, fh.cls), class_matrix(pw, INT), w, w8.data() + (size_t)p * 16 * 32 * 27);
+                yb[p] = ((2 * g.first + pd) * Hh + 2 * fh.idx + ph) * Wh * 64 + pw * 64;
+            }
+            int taps27[9], tap_off[9];
+            for (int td = 0; td < 3; ++td)
+                for (int tw = 0; tw < 3; ++tw) {
+                    taps27[td * 3 + tw] = td * 9 + 3 + tw;
+                    tap_off[td * 3 + tw] = ((td - 1) * Hp * Wp + (tw - 1)) * 128;
                 }
-            // W faces: (Md x Mh_interior x delta_w), taps (td, th) at tw = 1, run axis = h, n-tiles = ph; the run ends belong to the
-            // edge kernel (which applies the H CLASS matrix there): skipped
-            for (const Face& fw : fws)
-                for (int pw = 0; pw < 2; ++pw) {
-                    for (int ph = 0; ph < 2; ++ph)
-                        fold(Md, class_matrix(ph, INT), face_delta(pw, fw.cls), w, w2.data() + (size_t)ph * 16 * 32 * 27);
-                    int taps27[9], tap_off[9];
-                    for (int td = 0; td < 3; ++td)
-                        for (int th = 0; th < 3; ++th) {
-                            taps27[td * 3 + th] = td * 9 + th * 3 + 1;
-                            tap_off[td * 3 + th] = ((td - 1) * Hp + (th - 1)) * Wp * 128;
-                        }
-                    const int yb = (((2 * g.first + pd) * Hh) * Wh + 2 * fw.idx + pw) * 64;
-                    emit(taps27, tap_off, (((g.first + 1) * Hp + 1) * Wp + fw.idx + 1) * 128, Hp * Wp * 128, Wp * 128, g.count, H, yb,
-                         yb + Wh * 64, 2 * Hh * Wh * 64, 2 * Wh * 64, ST_SKIP, ST_SKIP);
-                }
+            emit(taps27, tap_off, (((g.first + 1) * Hp + fh.idx + 1) * Wp + 1) * 128, Hp * Wp * 128, 128, g.count, W, yb,
+                 2 * Hh * Wh * 64, 128, ST_RMW, ST_RMW);
         }
+        // W faces: (Md x Mh_interior x delta_w), taps (td, th) at tw = 1, run axis = h; the run ends belong to the edge kernel
+        // (which applies the H CLASS matrix there): skipped
+        for (const Face& fw : fws) {
+            int yb[8];
+            for (int p = 0; p < 8; ++p) {
+                const int pd = p >> 2, ph = (p >> 1) & 1, pw = p & 1;
+                fold(class_matrix(pd, g.cls), class_matrix(ph, INT), face_delta(pw, fw.cls), w, w8.data() + (size_t)p * 16 * 32 * 27);
+                yb[p] = (((2 * g.first + pd) * Hh + ph) * Wh + 2 * fw.idx + pw) * 64;
+            }
+            int taps27[9], tap_off[9];
+            for (int td = 0; td < 3; ++td)
+                for (int th = 0; th < 3; ++th) {
+                    taps27[td * 3 + th] = td * 9 + th * 3 + 1;
+                    tap_off[td * 3 + th] = ((td - 1) * Hp + (th - 1)) * Wp * 128;
+                }
+            emit(taps27, tap_off, (((g.first + 1) * Hp + 1) * Wp + fw.idx + 1) * 128, Hp * Wp * 128, Wp * 128, g.count, H, yb,
+                 2 * Hh * Wh * 64, 2 * Wh * 64, ST_SKIP, ST_SKIP);
+        }
+    }
     MVSGI_REQUIRE(r == h.n_roles, "mvsgi_conv3d_up2_poly_plan: internal role count mismatch");
     // ---- edge cells: (Md x Mh_class x delta_w) over taps (td, th), [group][cell][phase][tap][ci][co] fp32 ----
     int* cells = reinterpret_cast<int*>(P + h.off_edgecells);
@@ -432,16 +444,24 @@ extern "C" int mvsgi_conv3d_up2_poly_f32(const void* x_split, const void* plan_d
         hipLaunchKernelGGL(up2_edge_kernel, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, st, static_cast<const unsigned char*>(x_split),
                            P, y, B, D, H, W, h.n_edge_cells, h.n_groups, h.off_edgew, h.off_edgecells);
         if (mvsgi::check_launch("mvsgi_conv3d_up2_poly_f32(edges)")) return 1;
-        // two workgroups per CU are resident (launch bounds): size the roles' workgroups so that all of them fit one round
+        // one workgroup per CU is resident (its LDS holds a role's weights): size the roles' workgroups so that all of them fit
+        // one round
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        long long slots = 2ll * cus - h.n_roles;          // every role rounds its share up
+        static bool attr_set[mvsgi::kMaxDevices] = {};
+        if (dev >= 0 && dev < mvsgi::kMaxDevices && !attr_set[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(up2_face_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)kFaceRoleWBytes);
+            MVSGI_REQUIRE(e == hipSuccess, "mvsgi_conv3d_up2_poly_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_set[dev] = true;
+        }
+        long long slots = (long long)cus - h.n_roles;     // every role rounds its share up
         if (slots < 8) slots = 8;
         long long tpw = mvsgi::cdiv((long long)B * h.sum_tpf, slots);
-        if (tpw < 4) tpw = 4;                             // at least one tile per wave
+        if (tpw < 16) tpw = 16;                           // at least one tile per wave
         long long chunks = mvsgi::cdiv((long long)B * h.max_tpf, tpw);
         chunks = chunks < 1 ? 1 : (chunks > 4096 ? 4096 : chunks);
-        hipLaunchKernelGGL(up2_face_kernel, dim3((unsigned)chunks, (unsigned)h.n_roles), dim3(256), 0, st,
+        hipLaunchKernelGGL(up2_face_kernel, dim3((unsigned)chunks, (unsigned)h.n_roles), dim3(1024), kFaceRoleWBytes, st,
                            static_cast<const unsigned char*>(x_split), P, reinterpret_cast<unsigned char*>(y), B, x_frame, y_frame,
                            h.off_facew, h.off_roles, (int)tpw);
         if (mvsgi::check_launch("mvsgi_conv3d_up2_poly_f32(faces)")) return 1;

@@ -603,7 +603,7 @@ def test_bench_self_launches_its_ranks():
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["devices"] == [0, 0]
     assert d["value"] > 0 and d["scaling"] == "weak"
     hbm = {k: v for k, v in d["kernels"].items() if v.get("bound") == "hbm"}
-    assert any(k.startswith("sweep_std") for k in hbm) and "softargmin_kernel" in hbm and "conv3d_head_kernel" in hbm
+    assert any(k.startswith("sweep_std") for k in hbm) and any(k.startswith("softargmin") for k in hbm) and "conv3d_head_kernel" in hbm
     assert all(v["GBps"] > 0 for v in hbm.values())
     assert d["roofline"]["attributed_time_frac_of_step"] > 0.8
 
