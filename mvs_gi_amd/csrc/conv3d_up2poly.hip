@@ -193,17 +193,21 @@ void pack_face_weights(const float* wsrc, const int* taps, unsigned short* out) 
 // waits on those loads).  A = weights [16 couts][32 cin] from LDS, B = the cells' split-padded records straight from global
 // memory (already hi | lo), D[cout 4 kg + r][cell] -> 16-byte stores.
 // ------------------------------------------------------------------------------------------------------------------
+struct FaceGrid {          // workgroups of role r: [first[r], first[r + 1]) of a flat grid (every launched workgroup has work:
+    int n_roles;           // a workgroup needs the CU's whole LDS, so idle ones would queue for a CU only to exit)
+    int first[13];
+};
 __global__ __launch_bounds__(1024) void up2_face_kernel(const unsigned char* __restrict__ x, const unsigned char* __restrict__ plan,
                                                           unsigned char* __restrict__ y, int B, long long x_frame, long long y_frame,
-                                                          long long off_facew, long long off_roles, int tiles_per_wg) {
+                                                          long long off_facew, long long off_roles, FaceGrid fg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fw_lds[];
-    const int* R = reinterpret_cast<const int*>(plan + off_roles) + (int)blockIdx.y * kRoleInts;
+    int role = 0;
+#pragma unroll
+    for (int r = 1; r < 12; ++r) role += (r < fg.n_roles && (int)blockIdx.x >= fg.first[r]) ? 1 : 0;
+    const int chunk = (int)blockIdx.x - fg.first[role], chunks = fg.first[role + 1] - fg.first[role];
+    const int* R = reinterpret_cast<const int*>(plan + off_roles) + role * kRoleInts;
     const int n0 = R[R_N0], nrun = R[R_NRUN];
     const int tiles_run = (nrun + 15) >> 4, tpf = n0 * tiles_run;
-    // workgroups of this role: its share of ONE resident round of the whole launch (sized by the host)
-    long long want = ((long long)B * tpf + tiles_per_wg - 1) / tiles_per_wg;
-    const int chunks = want < 1 ? 1 : (want > (long long)gridDim.x ? (int)gridDim.x : (int)want);
-    if ((int)blockIdx.x >= chunks) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, kg = lane >> 4;
     {   // the role's weights -> LDS (16-byte pieces, coalesced)
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(1024) void up2_face_kernel(const unsigned char* __r
     const int lane_x = (kg >> 1) * 64 + (kg & 1) * 16;           // this lane's 8 input channels: hi piece (lo piece 32 B on)
     const bf16x8* wl_ = reinterpret_cast<const bf16x8*>(fw_lds) + lane;
     const int total = B * tpf, stride = chunks * 16;
-    for (int t = (int)blockIdx.x * 16 + wave; t < total; t += stride) {
+    for (int t = chunk * 16 + wave; t < total; t += stride) {
         const int rt = t % tiles_run;
         int q = t / tiles_run;
         const int o0 = q % n0, b = q / n0;
@@ -455,15 +459,28 @@ extern "C" int mvsgi_conv3d_up2_poly_f32(const void* x_split, const void* plan_d
             MVSGI_REQUIRE(e == hipSuccess, "mvsgi_conv3d_up2_poly_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr_set[dev] = true;
         }
+        MVSGI_REQUIRE(h.n_roles <= 12, "mvsgi_conv3d_up2_poly_f32: internal: %d face roles", h.n_roles);
         long long slots = (long long)cus - h.n_roles;     // every role rounds its share up
         if (slots < 8) slots = 8;
         long long tpw = mvsgi::cdiv((long long)B * h.sum_tpf, slots);
         if (tpw < 16) tpw = 16;                           // at least one tile per wave
-        long long chunks = mvsgi::cdiv((long long)B * h.max_tpf, tpw);
-        chunks = chunks < 1 ? 1 : (chunks > 4096 ? 4096 : chunks);
-        hipLaunchKernelGGL(up2_face_kernel, dim3((unsigned)chunks, (unsigned)h.n_roles), dim3(1024), kFaceRoleWBytes, st,
+        FaceGrid fg{};
+        fg.n_roles = h.n_roles;
+        {   // tiles per frame of every role, in the plan's role order (groups outermost; per group the H faces, then the W faces)
+            int r = 0, acc = 0;
+            for (const Group& g : groups_of(D)) {
+                const int nfh = (int)faces_of(H).size(), nfw = (int)faces_of(W).size();
+                for (int f = 0; f < nfh + nfw; ++f) {
+                    const long long tpf = (long long)g.count * mvsgi::cdiv(f < nfh ? W : H, 16);
+                    fg.first[r++] = acc;
+                    acc += (int)mvsgi::cdiv((long long)B * tpf, tpw);
+                }
+            }
+            fg.first[r] = acc;
+        }
+        hipLaunchKernelGGL(up2_face_kernel, dim3((unsigned)fg.first[h.n_roles]), dim3(1024), kFaceRoleWBytes, st,
                            static_cast<const unsigned char*>(x_split), P, reinterpret_cast<unsigned char*>(y), B, x_frame, y_frame,
-                           h.off_facew, h.off_roles, (int)tpw);
+                           h.off_facew, h.off_roles, fg);
         if (mvsgi::check_launch("mvsgi_conv3d_up2_poly_f32(faces)")) return 1;
     }
     return mvsgi::rs32_up2_launch(x_split, P + h.off_main, scale, shift, y, B, D, H, W, neg_slope, st);
