@@ -186,7 +186,7 @@ void pack_face_weights(const float* wsrc, const int* taps, unsigned short* out) 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// device: face convolutions on the matrix cores.  grid = (chunks, roles), role = (face, D class); one workgroup of 16 waves per CU: the
+// device: face convolutions on the matrix cores.  grid = (chunks, roles), role = (face, D class); one workgroup of 8 waves per CU: the
 // role's 9 taps x 8 phases of weight fragments (hi, lo: 144 KiB) sit in LDS for the whole launch and every wave walks 16-cell
 // tiles along the role's run axis, evaluating ALL 8 output phases of a tile from one set of 18 activation fragments (the
 // first version kept 2 phases' weights in registers and re-read the cells per (pd, ph) role: 89 % of its wave cycles were
@@ -197,7 +197,7 @@ struct FaceGrid {          // workgroups of role r: [first[r], first[r + 1]) of 
     int n_roles;           // a workgroup needs the CU's whole LDS, so idle ones would queue for a CU only to exit)
     int first[13];
 };
-__global__ __launch_bounds__(1024) void up2_face_kernel(const unsigned char* __restrict__ x, const unsigned char* __restrict__ plan,
+__global__ __launch_bounds__(512, 2) void up2_face_kernel(const unsigned char* __restrict__ x, const unsigned char* __restrict__ plan,
                                                           unsigned char* __restrict__ y, int B, long long x_frame, long long y_frame,
                                                           long long off_facew, long long off_roles, FaceGrid fg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fw_lds[];
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(1024) void up2_face_kernel(const unsigned char* __r
     const int col = lane & 15, kg = lane >> 4;
     {   // the role's weights -> LDS (16-byte pieces, coalesced)
         const u32x4* src = reinterpret_cast<const u32x4*>(plan + off_facew) + (long long)R[R_WOFF];
-        for (int i = tid; i < (int)(kFaceRoleWBytes / 16); i += 1024) reinterpret_cast<u32x4*>(fw_lds)[i] = src[i];
+        for (int i = tid; i < (int)(kFaceRoleWBytes / 16); i += 512) reinterpret_cast<u32x4*>(fw_lds)[i] = src[i];
     }
     __syncthreads();
     int tap[9], yb[8];
@@ -224,9 +224,8 @@ __global__ __launch_bounds__(1024) void up2_face_kernel(const unsigned char* __r
     const int y_s0 = R[R_YS0], y_srun = R[R_YSRUN];
     const int m_first = R[R_MFIRST], m_last = R[R_MLAST];
     const int lane_x = (kg >> 1) * 64 + (kg & 1) * 16;           // this lane's 8 input channels: hi piece (lo piece 32 B on)
-    const bf16x8* wl_ = reinterpret_cast<const bf16x8*>(fw_lds) + lane;
-    const int total = B * tpf, stride = chunks * 16;
-    for (int t = chunk * 16 + wave; t < total; t += stride) {
+    const int total = B * tpf, stride = chunks * 8;
+    for (int t = chunk * 8 + wave; t < total; t += stride) {
         const int rt = t % tiles_run;
         int q = t / tiles_run;
         const int o0 = q % n0, b = q / n0;
@@ -244,21 +243,28 @@ __global__ __launch_bounds__(1024) void up2_face_kernel(const unsigned char* __r
         f32x4 acc[8];
 #pragma unroll
         for (int p = 0; p < 8; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // the weight fragments are the same LDS words for every tile: launder the base per tile (and fence the taps) or the compiler
-        // hoists all 144 fragment reads out of the tile loop and spills them
-        const bf16x8* wt = wl_;
-        asm volatile("" : "+v"(wt));
+        // the weight fragments are the same LDS words for every tile: launder the OFFSET per tile (an integer: a laundered pointer
+        // loses its LDS address space and the reads become flat loads) or the compiler hoists all 144 fragment reads out of the
+        // tile loop and spills them.  A tap's 16 fragments are requested one tap ahead; its 24 MFMAs run term-major over the 8
+        // independent accumulators.
+        int woff = lane * 16;
+        asm volatile("" : "+v"(woff));
+        bf16x8 wb[2][16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wb[0][i] = *reinterpret_cast<const bf16x8*>(fw_lds + woff + i * 1024);
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
+            if (k + 1 < 9) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) wb[(k + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(fw_lds + woff + ((k + 1) * 16 + i) * 1024);
+            }
             const bf16x8 xh = __builtin_bit_cast(bf16x8, fh[k]), xl = __builtin_bit_cast(bf16x8, fl[k]);
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const bf16x8 wh = wt[((k * 8 + p) * 2) * 64], wl = wt[((k * 8 + p) * 2 + 1) * 64];
-                acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[p], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[k & 1][2 * p + 1], xh, acc[p], 0, 0, 0);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[k & 1][2 * p], xl, acc[p], 0, 0, 0);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[k & 1][2 * p], xh, acc[p], 0, 0, 0);
         }
         const int mode = run == 0 ? m_first : (run == nrun - 1 ? m_last : ST_WRITE);
         if (ok && mode != ST_SKIP) {
@@ -463,7 +469,7 @@ extern "C" int mvsgi_conv3d_up2_poly_f32(const void* x_split, const void* plan_d
         long long slots = (long long)cus - h.n_roles;     // every role rounds its share up
         if (slots < 8) slots = 8;
         long long tpw = mvsgi::cdiv((long long)B * h.sum_tpf, slots);
-        if (tpw < 16) tpw = 16;                           // at least one tile per wave
+        if (tpw < 8) tpw = 8;                             // at least one tile per wave
         FaceGrid fg{};
         fg.n_roles = h.n_roles;
         {   // tiles per frame of every role, in the plan's role order (groups outermost; per group the H faces, then the W faces)
@@ -478,7 +484,7 @@ extern "C" int mvsgi_conv3d_up2_poly_f32(const void* x_split, const void* plan_d
             }
             fg.first[r] = acc;
         }
-        hipLaunchKernelGGL(up2_face_kernel, dim3((unsigned)fg.first[h.n_roles]), dim3(1024), kFaceRoleWBytes, st,
+        hipLaunchKernelGGL(up2_face_kernel, dim3((unsigned)fg.first[h.n_roles]), dim3(512), kFaceRoleWBytes, st,
                            static_cast<const unsigned char*>(x_split), P, reinterpret_cast<unsigned char*>(y), B, x_frame, y_frame,
                            h.off_facew, h.off_roles, fg);
         if (mvsgi::check_launch("mvsgi_conv3d_up2_poly_f32(faces)")) return 1;
