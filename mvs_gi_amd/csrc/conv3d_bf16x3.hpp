@@ -505,8 +505,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
             if (e < IV * 4) {                                                                           \
                 const int v = e >> 2, q = e & 3;                                                        \
                 u32x2 hi, lo;                                                                           \
-                split_bf16x4(PRE[IT], hi, lo);                                                          \
-                if (!(((OK) >> (IT)) & 1u)) hi = lo = u32x2{0u, 0u};                                    \
+                if (MVSGI_ABL & 4) {     /* diagnostic: what a pre-split input would cost the producers (no split, no mask) */ \
+                    hi = u32x2{__builtin_bit_cast(unsigned, PRE[IT][0] + 0.f), __builtin_bit_cast(unsigned, PRE[IT][1] + 0.f)}; \
+                    lo = u32x2{__builtin_bit_cast(unsigned, PRE[IT][2] + 0.f), __builtin_bit_cast(unsigned, PRE[IT][3] + 0.f)}; \
+                } else {                                                                                \
+                    split_bf16x4(PRE[IT], hi, lo);                                                      \
+                    if (!(((OK) >> (IT)) & 1u)) hi = lo = u32x2{0u, 0u};                                \
+                }                                                                                       \
                 const int vo_ = V32 ? (v / ITW) * ROWP + (v % ITW) * kVSB : v * kVSB;                   \
                 *reinterpret_cast<u32x2*>((DST) + vo_ + q * 8) = hi;                                    \
                 *reinterpret_cast<u32x2*>((DST) + vo_ + 32 + q * 8) = lo;                               \
