@@ -452,44 +452,59 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
 #undef MVSGI_UPS_LIVE
         } else {
         int goff[NIT];
-        unsigned okmask = 0, okA = 0, okB = 0;
-        const float* xb = a.x;
+        unsigned okA = 0, okB = 0;      // (kept for the macro signatures: out-of-volume items are zero-filled by the loads' range check)
+        (void)okA; (void)okB;
         // Two register sets: the loads of unit u+2 are requested BEFORE the loads of unit u+1 are waited
         // for, split and written, so an HBM / L2 round trip overlaps a whole unit period instead of being
         // exposed once per unit (stamps: a staged unit took ~8k ticks of which ~5k were that wait, which made
         // the Cout == 16 layers producer-bound).
         f32x4 preA[NIT], preB[NIT];
-        // staging plan of a brick: item e = ptid + it*256 -> (halo voxel e>>2, channel quad e&3);
-        // padding / surplus items read a valid dummy address and are zeroed by a select (a branch
-        // per load would make hipcc wait for each one in turn)
+        // staging plan of a brick: item e = ptid + it*256 -> (halo voxel e>>2, channel quad e&3); padding / surplus items read a
+        // valid dummy address and are zeroed by a select (a branch per load would make hipcc wait for each one in turn).
+        // An item's halo coordinates and its element offset RELATIVE to the brick's origin never change: they are worked out
+        // once per launch (three divisions by constants, two multiplies), and a brick's plan is one add of the (scalar) origin
+        // offset plus three range checks per item -- the per-brick plan used to redo all of it and was most of the ~40 vector
+        // instructions a producer spent per 16 staged bytes in the single-slice layers (Cin = 16: down.0.first).
+        int ibase[NIT];          // byte offset of the item relative to the brick's origin voxel
+        __amdgpu_buffer_rsrc_t xdesc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0, 0x00020000);
+        unsigned cpk[NIT];       // id | ih << 8 | iw << 16
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = ptid + it * 256;
+            const int v = e >> 2, q = e & 3;
+            const int iw = v % ITW, ih = (v / ITW) % ITH, id = v / (ITW * ITH);
+            const bool live = e < IV * 4;             // surplus items of the last round: halo voxel 0 again (loaded, never stored)
+            ibase[it] = live ? (((id * a.Hin + ih) * a.Win + iw) * a.Cin + q * 4) * 4 : 0;       // bytes
+            cpk[it] = live ? (unsigned)(id | (ih << 8) | (iw << 16)) : 0u;
+        }
+        static_assert(ITD < 255 && ITH < 255 && ITW < 255, "packed halo coordinates");
 #define MVSGI_PLAN(UNIT)                                                                                \
         {                                                                                               \
             int cb_, b_, od_, oh_, ow_;                                                                 \
             MVSGI_DECODE(UNIT, cb_, b_, od_, oh_, ow_)                                                  \
             (void)cb_;                                                                                  \
             const int id0_ = od_ * SD - KD / 2, ih0_ = oh_ * S - 1, iw0_ = ow_ * S - 1;                 \
-            okmask = 0;                                                                                 \
+            const int bbase_ = ((id0_ * a.Hin + ih0_) * a.Win + iw0_) * a.Cin * 4;                      \
             _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                        \
-                const int e = ptid + it * 256;                                                          \
-                const int v = e >> 2, q = e & 3;                                                        \
-                const int iw = v % ITW, ih = (v / ITW) % ITH, id = v / (ITW * ITH);                     \
-                const int gd = id0_ + id, gh = ih0_ + ih, gw = iw0_ + iw;                               \
-                const bool ok = (e < IV * 4) && gd >= 0 && gd < a.Din && gh >= 0 && gh < a.Hin && gw >= 0 && gw < a.Win; \
-                goff[it] = ok ? ((gd * a.Hin + gh) * a.Win + gw) * a.Cin + q * 4 : 0;                   \
-                okmask |= ok ? (1u << it) : 0u;                                                         \
+                const unsigned gd = (unsigned)(id0_ + (int)(cpk[it] & 255u));                           \
+                const unsigned gh = (unsigned)(ih0_ + (int)((cpk[it] >> 8) & 255u));                    \
+                const unsigned gw = (unsigned)(iw0_ + (int)(cpk[it] >> 16));                            \
+                const bool ok = gd < (unsigned)a.Din && gh < (unsigned)a.Hin && gw < (unsigned)a.Win;   \
+                /* outside the volume: an offset the frame's buffer descriptor does not cover -- the load returns zeros (the \
+                   convolution's padding) with no select behind it */                                  \
+                goff[it] = ok ? ibase[it] + bbase_ : (int)0x80000000;                                   \
             }                                                                                           \
-            xb = a.x + (long long)b_ * a.Din * a.Hin * a.Win * a.Cin;                                   \
+            xdesc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (long long)b_ * a.Din * a.Hin * a.Win * a.Cin, 0, \
+                                                      a.Din * a.Hin * a.Win * a.Cin * 4, 0x00020000);  \
         }
         // request the next unit in walking order (k2, cc2) into a register set; the plan moves on with it
         int k2 = 0, cc2 = 0;
 #define MVSGI_ISSUE_BEGIN()                                                                             \
         if (cc2 == 0 && k2 > 0) { MVSGI_PLAN((int)blockIdx.x + k2 * G) }
 #define MVSGI_ISSUE1(PRE, IT)                                                                           \
-        PRE[IT] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xb) +                   \
-                                                  (unsigned)((goff[IT] + cc2 * 16) * 4));
+        PRE[IT] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xdesc, goff[IT] + cc2 * 64, 0, 0));
 #define MVSGI_ISSUE_END(OK)                                                                             \
         {                                                                                               \
-            OK = okmask;                                                                                \
             if (++cc2 == nchunks) { cc2 = 0; ++k2; }                                                    \
             if (k2 >= nmine) { k2 = nmine - 1; cc2 = nchunks - 1; }   /* past the end: re-request the last unit */ \
         }
@@ -510,7 +525,6 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                     lo = u32x2{__builtin_bit_cast(unsigned, PRE[IT][2] + 0.f), __builtin_bit_cast(unsigned, PRE[IT][3] + 0.f)}; \
                 } else {                                                                                \
                     split_bf16x4(PRE[IT], hi, lo);                                                      \
-                    if (!(((OK) >> (IT)) & 1u)) hi = lo = u32x2{0u, 0u};                                \
                 }                                                                                       \
                 const int vo_ = V32 ? (v / ITW) * ROWP + (v % ITW) * kVSB : v * kVSB;                   \
                 *reinterpret_cast<u32x2*>((DST) + vo_ + q * 8) = hi;                                    \
