@@ -248,6 +248,32 @@ class ConvProbe:
             self.records.append((H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, w_layout) + " [split-padded out]",
                                  2.0 * 27 * Cin * Cout * vox, s, e, 4.0 * (x.numel() + vox * Cout * (2 if res is not None else 1))))
             return y
+        orig_polys, orig_heads = H.conv3d_up2_poly_split, H.conv3d_head_split
+        self.hbm_orig["conv3d_up2_poly_split"], self.hbm_orig["conv3d_head_split"] = orig_polys, orig_heads
+
+        def probed_polys(x, plan, scale, shift, out, neg_slope=0.01):
+            if not self.enabled:
+                return orig_polys(x, plan, scale, shift, out, neg_slope)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = orig_polys(x, plan, scale, shift, out, neg_slope)
+            e.record()
+            vox = out.B * out.D * out.H * out.W
+            self.records.append(("conv3d_rs32_kernel<3> + up2_face_kernel + up2_edge_kernel (polyphase out_costs.0, split-padded out)",
+                                 2.0 * 27 * 32 * 16 * vox, s, e, 4.0 * (x.B * x.D * x.H * x.W * 32 + vox * 16)))
+            return y
+
+        def probed_heads(x, w_packed, scale, shift, neg_slope=1.0, out=None):
+            if not self.enabled:
+                return orig_heads(x, w_packed, scale, shift, neg_slope, out)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = orig_heads(x, w_packed, scale, shift, neg_slope, out)
+            e.record()
+            vox = x.B * x.D * x.H * x.W
+            self.records.append(("conv3d_head_split_kernel", 2.0 * 27 * x.C * vox, s, e, 4.0 * vox * (x.C + 1)))
+            return y
+        H.conv3d_up2_poly_split, H.conv3d_head_split = probed_polys, probed_heads
         H.conv3d_up2_poly, H.conv3d_up2_out_split = probed_poly, probed_up2s
         H.conv3d = probed
         H.conv3d_up2 = probed_up2

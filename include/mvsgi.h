@@ -299,6 +299,15 @@ int mvsgi_conv3d_rs_split(const void* x_split, const void* w_packed_rs, const fl
 int mvsgi_conv3d_up2_f32_out_split(const float* x, const void* w_packed, int w_layout, const float* scale, const float* shift,
                                    const float* res, void* y_split, int B, int Cin, int Dl, int Hl, int Wl, int Cout,
                                    float neg_slope, mvsgi_stream_t stream);   /* mvsgi_conv3d_up2_f32 writing a split-padded y */
+/* the polyphase layer with a split-padded result [B][2D+2][2H+2][2W+2][16], and the cost head (out_costs.1: Conv3d(Cin -> 1, k 3,
+ * bias), unet_regulator.py:61-68) reading that format: hi | lo fragments straight into the matrix cores, split-bf16 arithmetic.
+ * scale / shift of the head are passed by value (NoOp norm: 1 and the bias); neg_slope 1 = no activation. */
+int mvsgi_conv3d_up2_poly_split(const void* x_split, const void* plan_dev, const float* scale, const float* shift, void* y_split,
+                                int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream);
+size_t mvsgi_conv3d_head_split_packed_weight_bytes(int Cin);
+int mvsgi_conv3d_head_split_pack_weights(const float* w_oidhw, void* w_packed, int Cin, mvsgi_stream_t stream);
+int mvsgi_conv3d_head_split(const void* x_split, const void* w_packed, float scale, float shift, float* y, int B, int Cin,
+                            int D, int H, int W, float neg_slope, mvsgi_stream_t stream);
 size_t mvsgi_conv3d_up2_poly_plan_bytes(int D, int H, int W);
 int mvsgi_conv3d_up2_poly_plan(const float* w_oidhw_host, void* plan_host, int D, int H, int W);
 int mvsgi_conv3d_up2_poly_f32(const void* x_split, const void* plan_dev, const float* scale, const float* shift, float* y,

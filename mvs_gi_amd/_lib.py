@@ -73,6 +73,10 @@ SIGNATURES = {
     "mvsgi_conv3d_rs_pack_weights": (c_int, [_P, _P, c_int, c_int, _P]),
     "mvsgi_conv3d_rs_split": (c_int, [_P] * 6 + [c_int] * 7 + [c_float, _P]),
     "mvsgi_conv3d_up2_f32_out_split": (c_int, [_P, _P, c_int] + [_P] * 4 + [c_int] * 6 + [c_float, _P]),
+    "mvsgi_conv3d_up2_poly_split": (c_int, [_P] * 5 + [c_int] * 4 + [c_float, _P]),
+    "mvsgi_conv3d_head_split_packed_weight_bytes": (c_size_t, [c_int]),
+    "mvsgi_conv3d_head_split_pack_weights": (c_int, [_P, _P, c_int, _P]),
+    "mvsgi_conv3d_head_split": (c_int, [_P, _P, c_float, c_float, _P] + [c_int] * 5 + [c_float, _P]),
     "mvsgi_conv3d_up2_poly_plan_bytes": (c_size_t, [c_int] * 3),
     "mvsgi_conv3d_up2_poly_plan": (c_int, [_P, _P] + [c_int] * 3),
     "mvsgi_conv3d_up2_poly_f32": (c_int, [_P] * 5 + [c_int] * 4 + [c_float, _P]),

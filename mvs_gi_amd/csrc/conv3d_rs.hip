@@ -210,8 +210,9 @@ struct RsUnit {      // coordinates of a brick (wave-uniform)
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     using namespace rs;
-    constexpr bool OUTF32 = MODE != 0;
-    constexpr bool UP2 = MODE == 2;
+    constexpr bool OUTF32 = MODE == 1 || MODE == 2;
+    constexpr bool UP2 = MODE >= 2;                    // MODE 3: polyphase with a SPLIT-PADDED hi-res output [B][2D+2][2H+2][2W+2][64 B]
+    constexpr int OB = MODE == 3 ? 1 : 0;              // border of the polyphase output tensor
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -223,12 +224,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     const long long frame_bytes = (long long)(a.D + 2) * Hp * Wp * 128;
     const long long total_bytes = frame_bytes * a.B;
     // ---- polyphase role of this workgroup: blockIdx = (walker * R + role) * 8 + xcd ----
-    const int Hh = 2 * a.H, Wh = 2 * a.W;
+    const int Hh = 2 * a.H + 2 * OB, Wh = 2 * a.W + 2 * OB;       // rows / columns of the polyphase output tensor (border included)
     const int up_R = 4 * a.tiles_d;
     const int up_q = (int)blockIdx.x >> 3;
     const int up_role = UP2 ? up_q % up_R : 0, up_walker = UP2 ? up_q / up_R : 0;
     const int up_pd = (up_role >> 1) & 1, up_ph = up_role & 1, up_od = up_role >> 2;
-    const long long oframe_bytes = UP2 ? (long long)(2 * a.D) * Hh * Wh * 64 : (long long)a.D * a.H * a.W * 128;
+    const long long oframe_bytes = UP2 ? (long long)(2 * a.D + 2 * OB) * Hh * Wh * 64 : (long long)a.D * a.H * a.W * 128;
     if constexpr (UP2) {
         const int i_d = up_od * TD + pl;
         const int cls = a.D == 1 ? 3 : (i_d == 0 ? 0 : (i_d == a.D - 1 ? 2 : 1));
@@ -290,8 +291,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     unsigned voyo[2];     // the same for the OUTPUT tensor (fp32: unpadded, couts 4 kg .. 4 kg + 3 of the tile are 16 contiguous bytes)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-        voyo[i] = UP2 ? (unsigned)(((2 * pl * Hh + 2 * (2 * s + i)) * Wh) * 64 + col * 128 + kg * 16)       // cell -> hi-res voxel pair
+        voyo[i] = UP2 ? (unsigned)(((2 * pl * Hh + 2 * (2 * s + i)) * Wh) * 64 + col * 128 +               // cell -> hi-res voxel pair
+                                   (OUTF32 ? kg * 16 : (kg & 1) * 32 + (kg >> 1) * 16))
                       : (OUTF32 ? (unsigned)(((pl * a.H + 2 * s + i) * a.W + col) * 128 + kg * 16) : voy0[i]);
+    unsigned vocb[2];     // polyphase: where this lane READS its face correction (fp32 couts 4 kg .. 4 kg + 3 of the voxel's 64-byte record)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) vocb[i] = (unsigned)(((2 * pl * Hh + 2 * (2 * s + i)) * Wh) * 64 + col * 128 + kg * 16);
     int sp_rd = SCR + (wave ^ 2) * 4096 + lane * 16, sp_wr = SCR + 16384 + wave * 4096 + lane * 16;
 
     int total = a.total_units;
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 #define RS_DESC_OUT(U, VALID)                                                                                   \
     ({                                                                                                           \
         const long long off_ = (long long)(U).b * oframe_bytes +                                                 \
-            (UP2 ? ((long long)((2 * up_od * TD + up_pd) * Hh + 2 * (U).oh * TH + up_ph) * Wh + 2 * (U).ow * TW) * 64 \
+            (UP2 ? ((long long)((2 * up_od * TD + up_pd + OB) * Hh + 2 * (U).oh * TH + up_ph + OB) * Wh + 2 * (U).ow * TW + OB) * 64 \
                  : ((long long)((U).od * TD * a.H + (U).oh * TH) * a.W + (U).ow * TW) * 128);                    \
         const long long left_ = (long long)a.B * oframe_bytes - off_;                                            \
         const int rec_ = left_ > 0x7fffff00ll ? 0x7fffff00 : (int)left_;                                         \
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 #define RS_F_F32(...) if constexpr (OUTF32) { __VA_ARGS__ }
 #define RS_F_UP2(...) if constexpr (UP2) { __VA_ARGS__ }
 #define RS_F_NUP2(...) if constexpr (!UP2) { __VA_ARGS__ }
-#define RS_DSC_Y(U, VALID) (OUTF32 ? RS_DESC_OUT(U, VALID) : RS_DESC(a.y, U, VALID))
+#define RS_DSC_Y(U, VALID) ((OUTF32 || UP2) ? RS_DESC_OUT(U, VALID) : RS_DESC(a.y, U, VALID))
 // the "residual" descriptor: the residual tensor, or (polyphase mode) the OUTPUT tensor, whose face voxels hold the corrections
 #define RS_DSC_R(U, VALID) (UP2 ? RS_DESC_OUT(U, VALID) : RS_DESC(a.res, U, (int)(a.res != nullptr) & (int)(VALID)))
 #define RS_RES_OFF(I) (UP2 ? voc[I] : voy0[I])
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
             const int ih_ = c1.oh * TH + 2 * s + i;                                                  \
             const int face_ = wf_ | (int)(ih_ == 0) | (int)(ih_ == a.H - 1);                         \
-            voc[i] = (dok_ & face_ & (int)(ih_ < a.H) & (int)(iw_ < a.W)) ? voyo[i] : 0xffffff00u;   \
+            voc[i] = (dok_ & face_ & (int)(ih_ < a.H) & (int)(iw_ < a.W)) ? vocb[i] : 0xffffff00u;   \
         }                                                                                            \
     }
     // One code path per loop (a main / drain diamond inside one loop made hipcc park the accumulators in VGPRs at the
@@ -877,13 +882,13 @@ void rs32_pack_weights_host(const float* w, void* packed) {
                 }
 }
 
-int rs32_up2_launch(const void* x_split, const void* w_sets, const float* scale32, const float* shift32, float* y, int B, int D,
-                    int H, int W, float neg_slope, hipStream_t st) {
+int rs32_up2_launch(const void* x_split, const void* w_sets, const float* scale32, const float* shift32, void* y, int y_is_split,
+                    int B, int D, int H, int W, float neg_slope, hipStream_t st) {
     MVSGI_REQUIRE((long long)(D + 2) * (H + 2) * (W + 2) * 128 < (1ll << 31) && (long long)D * H * W * 512 < (1ll << 31),
                   "mvsgi_conv3d_up2_poly_f32: frame too large for 32-bit offsets");
     RsArgs a{};
     a.x = static_cast<const unsigned char*>(x_split);
-    a.y = reinterpret_cast<unsigned char*>(y);
+    a.y = static_cast<unsigned char*>(y);
     a.res = nullptr;
     a.wp = static_cast<const bf16x8*>(w_sets);
     a.scale = scale32;
@@ -897,9 +902,11 @@ int rs32_up2_launch(const void* x_split, const void* w_sets, const float* scale3
     MVSGI_REQUIRE(per_role < (1ll << 31), "mvsgi_conv3d_up2_poly_f32: too many units");
     a.total_units = (int)per_role;
     a.wp_set = (long long)(kRs32PackedBytes / 16);
-    static PersistentGeom geo_cache[kMaxDevices] = {};
+    MVSGI_REQUIRE((long long)(2 * D + 2) * (2 * H + 2) * (2 * W + 2) * 64 < (1ll << 31), "mvsgi_conv3d_up2_poly: output frame too large for 32-bit offsets");
+    static PersistentGeom geo_cache[2][kMaxDevices] = {};
     PersistentGeom geo;
-    if (persistent_geometry(conv3d_rs32_kernel<2>, 256, rs::LDS_BYTES, 1, geo_cache, "mvsgi_conv3d_up2_poly_f32", geo)) return 1;
+    auto kern = y_is_split ? conv3d_rs32_kernel<3> : conv3d_rs32_kernel<2>;
+    if (persistent_geometry(kern, 256, rs::LDS_BYTES, 1, geo_cache[y_is_split ? 1 : 0], "mvsgi_conv3d_up2_poly_f32", geo)) return 1;
     // grid = 8 XCDs x R roles x walkers; one workgroup per CU when the roles fit, never fewer than one walker per (XCD, role)
     const int R = 4 * a.tiles_d;
     long long walkers = geo.cus / (8 * R);
@@ -907,7 +914,7 @@ int rs32_up2_launch(const void* x_split, const void* w_sets, const float* scale3
     if (walkers > most) walkers = most;
     if (walkers < 1) walkers = 1;
     a.walkers = (int)walkers;
-    hipLaunchKernelGGL(conv3d_rs32_kernel<2>, dim3((unsigned)(8 * R * walkers)), dim3(256), rs::LDS_BYTES, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(8 * R * walkers)), dim3(256), rs::LDS_BYTES, st, a);
     return check_launch("mvsgi_conv3d_up2_poly_f32(main)");
 }
 

@@ -123,7 +123,9 @@ struct PolyHeader {
     int n_roles, n_edge_cells, n_groups, max_tpf;
     long long off_main, off_facew, off_roles, off_edgew, off_edgecells, total;
     int sum_tpf;        // 16-cell tiles per frame over all face roles
-    int pad[11];
+    int pad0;
+    long long off_roles_split;      // the same roles addressing a SPLIT-PADDED output [B][2D+2][2H+2][2W+2][64 B]
+    int pad[8];
 };
 static_assert(sizeof(PolyHeader) == 128, "header");
 
@@ -143,6 +145,8 @@ PolyHeader layout(int D, int H, int W) {
     h.off_facew = (long long)(o = align256(o));
     o += (size_t)h.n_roles * kFaceRoleWBytes;
     h.off_roles = (long long)(o = align256(o));
+    o += (size_t)h.n_roles * kRoleInts * 4;
+    h.off_roles_split = (long long)(o = align256(o));
     o += (size_t)h.n_roles * kRoleInts * 4;
     h.off_edgew = (long long)(o = align256(o));
     o += (size_t)ng * h.n_edge_cells * 8 * kEdgeSetFloats * 4;
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void up2_face_kernel(const unsigned char* _
 // thread = (b, plane, edge cell, phase, cout); writes (the H-face roles accumulate onto it afterwards).
 __global__ __launch_bounds__(256) void up2_edge_kernel(const unsigned char* __restrict__ x, const unsigned char* __restrict__ plan,
                                                        float* __restrict__ y, int B, int D, int H, int W, int n_cells, int n_groups,
-                                                       long long off_edgew, long long off_edgecells) {
+                                                       long long off_edgew, long long off_edgecells, int ob) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long n = (long long)B * D * n_cells * 128;
     if (idx >= n) return;
@@ -316,7 +320,8 @@ __global__ __launch_bounds__(256) void up2_edge_kernel(const unsigned char* __re
             }
         }
     const int pd = phase >> 2, ph = (phase >> 1) & 1, pw = phase & 1;
-    y[((((long long)b * 2 * D + 2 * i_d + pd) * 2 * H + 2 * i_h + ph) * 2 * W + 2 * i_w + pw) * 16 + co] = s;
+    // ob = 1: the output is the split-padded tensor (one-voxel border); the raw correction occupies the voxel's 64-byte record as fp32
+    y[((((long long)b * (2 * D + 2 * ob) + 2 * i_d + pd + ob) * (2 * H + 2 * ob) + 2 * i_h + ph + ob) * (2 * W + 2 * ob) + 2 * i_w + pw + ob) * 16 + co] = s;
 }
 
 }  // namespace
@@ -359,54 +364,64 @@ extern "C" int mvsgi_conv3d_up2_poly_plan(const float* w_oidhw_host, void* plan_
     int* roles = reinterpret_cast<int*>(P + h.off_roles);
     int r = 0;
     std::vector<float> w8(8 * 16 * 32 * 27);
-    auto emit = [&](const int* taps27, const int* tap_off, int x_base, int x_s0, int x_srun, int n0, int nrun, const int* yb, int y_s0,
-                    int y_srun, int m_first, int m_last) {
+    int* roles_split = reinterpret_cast<int*>(P + h.off_roles_split);
+    // a role is written twice: addressing the plain fp32 output (geometry 0) and the split-padded one (geometry 1: every voxel
+    // index + 1, rows of 2W + 2, planes of (2H + 2) rows); the weights are shared
+    auto emit = [&](const int* taps27, const int* tap_off, int x_base, int x_s0, int x_srun, int n0, int nrun, const int (*yb)[8],
+                    const int* y_s0, const int* y_srun, int m_first, int m_last) {
         pack_face_weights(w8.data(), taps27, reinterpret_cast<unsigned short*>(P + h.off_facew + (size_t)r * kFaceRoleWBytes));
-        int* R = roles + (size_t)r * kRoleInts;
-        R[R_WOFF] = (int)((size_t)r * kFaceRoleWBytes / 16);
-        R[R_NTAPS] = 9;
-        for (int t = 0; t < 9; ++t) R[R_TAP0 + t] = tap_off[t];
-        R[R_XBASE] = x_base; R[R_XS0] = x_s0; R[R_XSRUN] = x_srun; R[R_N0] = n0; R[R_NRUN] = nrun;
-        for (int p = 0; p < 8; ++p) R[R_YBASE0 + p] = yb[p];
-        R[R_YS0] = y_s0; R[R_YSRUN] = y_srun; R[R_MFIRST] = m_first; R[R_MLAST] = m_last;
+        for (int geo = 0; geo < 2; ++geo) {
+            int* R = (geo ? roles_split : roles) + (size_t)r * kRoleInts;
+            R[R_WOFF] = (int)((size_t)r * kFaceRoleWBytes / 16);
+            R[R_NTAPS] = 9;
+            for (int t = 0; t < 9; ++t) R[R_TAP0 + t] = tap_off[t];
+            R[R_XBASE] = x_base; R[R_XS0] = x_s0; R[R_XSRUN] = x_srun; R[R_N0] = n0; R[R_NRUN] = nrun;
+            for (int p = 0; p < 8; ++p) R[R_YBASE0 + p] = yb[geo][p];
+            R[R_YS0] = y_s0[geo]; R[R_YSRUN] = y_srun[geo]; R[R_MFIRST] = m_first; R[R_MLAST] = m_last;
+        }
         ++r;
     };
+    const int Hq[2] = {Hh, Hh + 2}, Wq[2] = {Wh, Wh + 2};      // rows / columns of the output tensor per geometry
     for (const Group& g : gs) {
         // H faces: (Md x delta_h x Mw_interior), taps (td, tw) at th = 1, run axis = w; the run ends are edge cells: the edge
         // kernel has written there, accumulate
         for (const Face& fh : fhs) {
-            int yb[8];
+            int yb[2][8], ys0[2], ysr[2];
             for (int p = 0; p < 8; ++p) {
                 const int pd = p >> 2, ph = (p >> 1) & 1, pw = p & 1;
                 fold(class_matrix(pd, g.cls), face_delta(ph, fh.cls), class_matrix(pw, INT), w, w8.data() + (size_t)p * 16 * 32 * 27);
-                yb[p] = ((2 * g.first + pd) * Hh + 2 * fh.idx + ph) * Wh * 64 + pw * 64;
+                for (int geo = 0; geo < 2; ++geo)
+                    yb[geo][p] = (((2 * g.first + pd + geo) * Hq[geo] + 2 * fh.idx + ph + geo) * Wq[geo] + geo) * 64 + pw * 64;
             }
+            for (int geo = 0; geo < 2; ++geo) { ys0[geo] = 2 * Hq[geo] * Wq[geo] * 64; ysr[geo] = 128; }
             int taps27[9], tap_off[9];
             for (int td = 0; td < 3; ++td)
                 for (int tw = 0; tw < 3; ++tw) {
                     taps27[td * 3 + tw] = td * 9 + 3 + tw;
                     tap_off[td * 3 + tw] = ((td - 1) * Hp * Wp + (tw - 1)) * 128;
                 }
-            emit(taps27, tap_off, (((g.first + 1) * Hp + fh.idx + 1) * Wp + 1) * 128, Hp * Wp * 128, 128, g.count, W, yb,
-                 2 * Hh * Wh * 64, 128, ST_RMW, ST_RMW);
+            emit(taps27, tap_off, (((g.first + 1) * Hp + fh.idx + 1) * Wp + 1) * 128, Hp * Wp * 128, 128, g.count, W, yb, ys0, ysr,
+                 ST_RMW, ST_RMW);
         }
         // W faces: (Md x Mh_interior x delta_w), taps (td, th) at tw = 1, run axis = h; the run ends belong to the edge kernel
         // (which applies the H CLASS matrix there): skipped
         for (const Face& fw : fws) {
-            int yb[8];
+            int yb[2][8], ys0[2], ysr[2];
             for (int p = 0; p < 8; ++p) {
                 const int pd = p >> 2, ph = (p >> 1) & 1, pw = p & 1;
                 fold(class_matrix(pd, g.cls), class_matrix(ph, INT), face_delta(pw, fw.cls), w, w8.data() + (size_t)p * 16 * 32 * 27);
-                yb[p] = (((2 * g.first + pd) * Hh + ph) * Wh + 2 * fw.idx + pw) * 64;
+                for (int geo = 0; geo < 2; ++geo)
+                    yb[geo][p] = (((2 * g.first + pd + geo) * Hq[geo] + ph + geo) * Wq[geo] + 2 * fw.idx + pw + geo) * 64;
             }
+            for (int geo = 0; geo < 2; ++geo) { ys0[geo] = 2 * Hq[geo] * Wq[geo] * 64; ysr[geo] = 2 * Wq[geo] * 64; }
             int taps27[9], tap_off[9];
             for (int td = 0; td < 3; ++td)
                 for (int th = 0; th < 3; ++th) {
                     taps27[td * 3 + th] = td * 9 + th * 3 + 1;
                     tap_off[td * 3 + th] = ((td - 1) * Hp + (th - 1)) * Wp * 128;
                 }
-            emit(taps27, tap_off, (((g.first + 1) * Hp + 1) * Wp + fw.idx + 1) * 128, Hp * Wp * 128, Wp * 128, g.count, H, yb,
-                 2 * Hh * Wh * 64, 2 * Wh * 64, ST_SKIP, ST_SKIP);
+            emit(taps27, tap_off, (((g.first + 1) * Hp + 1) * Wp + fw.idx + 1) * 128, Hp * Wp * 128, Wp * 128, g.count, H, yb, ys0, ysr,
+                 ST_SKIP, ST_SKIP);
         }
     }
     MVSGI_REQUIRE(r == h.n_roles, "mvsgi_conv3d_up2_poly_plan: internal role count mismatch");
@@ -434,60 +449,77 @@ extern "C" int mvsgi_conv3d_up2_poly_plan(const float* w_oidhw_host, void* plan_
     return 0;
 }
 
+namespace {
+
+// edges (writes), faces (the H-face roles accumulate on the edge cells), then the register-stationary main kernel; ob = 1: the
+// output is a split-padded tensor [B][2D+2][2H+2][2W+2][64 B] (the corrections use its voxel records as fp32 until the main
+// kernel overwrites them with the split result)
+int poly_launch(const void* x_split, const void* plan_dev, const float* scale, const float* shift, void* y, int ob, int B, int D, int H,
+                int W, float neg_slope, hipStream_t st) {
+    MVSGI_REQUIRE(x_split && plan_dev && scale && shift && y, "mvsgi_conv3d_up2_poly: null pointer");
+    MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_conv3d_up2_poly: bad dims");
+    MVSGI_REQUIRE(neg_slope >= 0.f && neg_slope <= 1.f, "mvsgi_conv3d_up2_poly: neg_slope %g not in [0, 1]", (double)neg_slope);
+    MVSGI_REQUIRE((long long)(D + 2) * (H + 2) * (W + 2) * 128 < (1ll << 31) &&
+                      (long long)(2 * D + 2) * (2 * H + 2) * (2 * W + 2) * 64 < (1ll << 31),
+                  "mvsgi_conv3d_up2_poly: frame too large for 32-bit offsets");
+    const PolyHeader h = layout(D, H, W);
+    const unsigned char* P = static_cast<const unsigned char*>(plan_dev);
+    const long long x_frame = (long long)(D + 2) * (H + 2) * (W + 2) * 128;
+    const long long y_frame = (long long)(2 * D + 2 * ob) * (2 * H + 2 * ob) * (2 * W + 2 * ob) * 64;
+    const long long n = (long long)B * D * h.n_edge_cells * 128;
+    MVSGI_REQUIRE(mvsgi::cdiv(n, 256) < (1ll << 31), "mvsgi_conv3d_up2_poly: too many edge threads");
+    hipLaunchKernelGGL(up2_edge_kernel, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, st, static_cast<const unsigned char*>(x_split), P,
+                       static_cast<float*>(y), B, D, H, W, h.n_edge_cells, h.n_groups, h.off_edgew, h.off_edgecells, ob);
+    if (mvsgi::check_launch("mvsgi_conv3d_up2_poly(edges)")) return 1;
+    // one workgroup per CU is resident (its LDS holds a role's weights): size the roles' workgroups so that all of them fit one round
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    static bool attr_set[mvsgi::kMaxDevices] = {};
+    if (dev >= 0 && dev < mvsgi::kMaxDevices && !attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(up2_face_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kFaceRoleWBytes);
+        MVSGI_REQUIRE(e == hipSuccess, "mvsgi_conv3d_up2_poly: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set[dev] = true;
+    }
+    MVSGI_REQUIRE(h.n_roles <= 12, "mvsgi_conv3d_up2_poly: internal: %d face roles", h.n_roles);
+    long long slots = (long long)cus - h.n_roles;     // every role rounds its share up
+    if (slots < 8) slots = 8;
+    long long tpw = mvsgi::cdiv((long long)B * h.sum_tpf, slots);
+    if (tpw < 8) tpw = 8;                             // at least one tile per wave
+    FaceGrid fg{};
+    fg.n_roles = h.n_roles;
+    {   // tiles per frame of every role, in the plan's role order (groups outermost; per group the H faces, then the W faces)
+        int r = 0, acc = 0;
+        for (const Group& g : groups_of(D)) {
+            const int nfh = (int)faces_of(H).size(), nfw = (int)faces_of(W).size();
+            for (int f = 0; f < nfh + nfw; ++f) {
+                const long long tpf = (long long)g.count * mvsgi::cdiv(f < nfh ? W : H, 16);
+                fg.first[r++] = acc;
+                acc += (int)mvsgi::cdiv((long long)B * tpf, tpw);
+            }
+        }
+        fg.first[r] = acc;
+    }
+    hipLaunchKernelGGL(up2_face_kernel, dim3((unsigned)fg.first[h.n_roles]), dim3(512), kFaceRoleWBytes, st,
+                       static_cast<const unsigned char*>(x_split), P, static_cast<unsigned char*>(y), B, x_frame, y_frame, h.off_facew,
+                       ob ? h.off_roles_split : h.off_roles, fg);
+    if (mvsgi::check_launch("mvsgi_conv3d_up2_poly(faces)")) return 1;
+    return mvsgi::rs32_up2_launch(x_split, P + h.off_main, scale, shift, y, ob, B, D, H, W, neg_slope, st);
+}
+
+}  // namespace
+
 // ResizeConv3d.forward (common_modules.py:332-355) for Cin = 32, Cout = 16, no skip: x split-padded [B][D+2][H+2][W+2][32]
 // (low resolution), y fp32 [B][2D][2H][2W][16] = act(conv(up2(x)) * scale + shift); plan_dev: the plan of
 // mvsgi_conv3d_up2_poly_plan(D, H, W) in device memory; neg_slope in [0, 1].
 extern "C" int mvsgi_conv3d_up2_poly_f32(const void* x_split, const void* plan_dev, const float* scale, const float* shift, float* y,
                                          int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream) {
-    MVSGI_REQUIRE(x_split && plan_dev && scale && shift && y, "mvsgi_conv3d_up2_poly_f32: null pointer");
-    MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_conv3d_up2_poly_f32: bad dims");
-    MVSGI_REQUIRE(neg_slope >= 0.f && neg_slope <= 1.f, "mvsgi_conv3d_up2_poly_f32: neg_slope %g not in [0, 1]", (double)neg_slope);
-    MVSGI_REQUIRE((long long)(D + 2) * (H + 2) * (W + 2) * 128 < (1ll << 31) && (long long)D * H * W * 512 < (1ll << 31),
-                  "mvsgi_conv3d_up2_poly_f32: frame too large for 32-bit offsets");
-    const PolyHeader h = layout(D, H, W);
-    hipStream_t st = mvsgi::as_stream(stream);
-    const unsigned char* P = static_cast<const unsigned char*>(plan_dev);
-    const long long x_frame = (long long)(D + 2) * (H + 2) * (W + 2) * 128, y_frame = (long long)D * H * W * 512;
-    {   // edge lines first (writes), then the faces (the H-face roles accumulate on the edge cells)
-        const long long n = (long long)B * D * h.n_edge_cells * 128;
-        MVSGI_REQUIRE(mvsgi::cdiv(n, 256) < (1ll << 31), "mvsgi_conv3d_up2_poly_f32: too many edge threads");
-        hipLaunchKernelGGL(up2_edge_kernel, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, st, static_cast<const unsigned char*>(x_split),
-                           P, y, B, D, H, W, h.n_edge_cells, h.n_groups, h.off_edgew, h.off_edgecells);
-        if (mvsgi::check_launch("mvsgi_conv3d_up2_poly_f32(edges)")) return 1;
-        // one workgroup per CU is resident (its LDS holds a role's weights): size the roles' workgroups so that all of them fit
-        // one round
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        static bool attr_set[mvsgi::kMaxDevices] = {};
-        if (dev >= 0 && dev < mvsgi::kMaxDevices && !attr_set[dev]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(up2_face_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)kFaceRoleWBytes);
-            MVSGI_REQUIRE(e == hipSuccess, "mvsgi_conv3d_up2_poly_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            attr_set[dev] = true;
-        }
-        MVSGI_REQUIRE(h.n_roles <= 12, "mvsgi_conv3d_up2_poly_f32: internal: %d face roles", h.n_roles);
-        long long slots = (long long)cus - h.n_roles;     // every role rounds its share up
-        if (slots < 8) slots = 8;
-        long long tpw = mvsgi::cdiv((long long)B * h.sum_tpf, slots);
-        if (tpw < 8) tpw = 8;                             // at least one tile per wave
-        FaceGrid fg{};
-        fg.n_roles = h.n_roles;
-        {   // tiles per frame of every role, in the plan's role order (groups outermost; per group the H faces, then the W faces)
-            int r = 0, acc = 0;
-            for (const Group& g : groups_of(D)) {
-                const int nfh = (int)faces_of(H).size(), nfw = (int)faces_of(W).size();
-                for (int f = 0; f < nfh + nfw; ++f) {
-                    const long long tpf = (long long)g.count * mvsgi::cdiv(f < nfh ? W : H, 16);
-                    fg.first[r++] = acc;
-                    acc += (int)mvsgi::cdiv((long long)B * tpf, tpw);
-                }
-            }
-            fg.first[r] = acc;
-        }
-        hipLaunchKernelGGL(up2_face_kernel, dim3((unsigned)fg.first[h.n_roles]), dim3(512), kFaceRoleWBytes, st,
-                           static_cast<const unsigned char*>(x_split), P, reinterpret_cast<unsigned char*>(y), B, x_frame, y_frame,
-                           h.off_facew, h.off_roles, fg);
-        if (mvsgi::check_launch("mvsgi_conv3d_up2_poly_f32(faces)")) return 1;
-    }
-    return mvsgi::rs32_up2_launch(x_split, P + h.off_main, scale, shift, y, B, D, H, W, neg_slope, st);
+    return poly_launch(x_split, plan_dev, scale, shift, y, 0, B, D, H, W, neg_slope, mvsgi::as_stream(stream));
+}
+
+// The same with the result in the split-padded format, [B][2D+2][2H+2][2W+2][16] (zero border, never written): the input of
+// mvsgi_conv3d_head_split (the cost head reads hi | lo fragments straight from it).
+extern "C" int mvsgi_conv3d_up2_poly_split(const void* x_split, const void* plan_dev, const float* scale, const float* shift, void* y_split,
+                                           int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream) {
+    return poly_launch(x_split, plan_dev, scale, shift, y_split, 1, B, D, H, W, neg_slope, mvsgi::as_stream(stream));
 }

@@ -42,7 +42,8 @@ _USE_V32 = os.environ.get("MVSGI_V32", "0") != "0"
 class ConvLaunch:
     """Device-resident launch arguments of one BaseConvBlk3d: PyTorch-layout weight, packed
     MFMA weight (or None), per-channel scale/shift (eval BatchNorm3d or bias), stride, slope."""
-    __slots__ = ("w", "wp", "wp_b3", "wp_c16", "wp_v32", "wp_rs", "wp_poly", "scale", "shift", "stride", "neg_slope", "cin", "cout", "key")
+    __slots__ = ("w", "wp", "wp_b3", "wp_c16", "wp_v32", "wp_rs", "wp_poly", "wp_head", "head_sc", "scale", "shift", "stride",
+                 "neg_slope", "cin", "cout", "key")
 
     def run(self, x_ndhwc: Tensor, res: Optional[Tensor] = None, impl: Optional[int] = None) -> Tensor:
         wp = self.wp
@@ -105,6 +106,20 @@ class ConvLaunch:
         if k not in self.wp_poly:
             self.wp_poly[k] = H.conv3d_up2_poly_plan(self.w, *k)
         return self.wp_poly[k]
+
+    def head_split_ok(self) -> bool:
+        """The split-bf16 cost head on a split-padded input (csrc/conv3d_headsplit.hip)."""
+        return H.get_conv_mode() == "bf16x3" and self.cout == 1 and self.cin % 16 == 0 and self.stride == 1
+
+    def run_head_split(self, x_split) -> Tensor:
+        if self.wp_head is None:
+            self.wp_head = H.pack_head_split_weights(self.w)
+            self.head_sc = (float(self.scale[0]), float(self.shift[0]))       # one host read at lowering time
+        return H.conv3d_head_split(x_split, self.wp_head, self.head_sc[0], self.head_sc[1], neg_slope=self.neg_slope)
+
+    def run_up2_poly_split(self, x_split, out) -> "H.SplitAct":
+        return H.conv3d_up2_poly_split(x_split, self._poly_plan(x_split.D, x_split.H, x_split.W), self.scale, self.shift, out=out,
+                                       neg_slope=self.neg_slope)
 
     def run_up2_poly(self, x_split, out=None) -> Tensor:
         return H.conv3d_up2_poly(x_split, self._poly_plan(x_split.D, x_split.H, x_split.W), self.scale, self.shift,
@@ -215,6 +230,8 @@ def lower_conv_block(blk) -> ConvLaunch:
     L.wp_v32 = None
     L.wp_rs = None
     L.wp_poly = None
+    L.wp_head = None
+    L.head_sc = None
     L.scale = scale.contiguous()
     L.shift = shift.contiguous()
     L.stride = int(conv.stride[0])

@@ -99,14 +99,16 @@ def down_block_ndhwc(blk, x: Tensor) -> Tensor:
 # MVSGI_POLY=0 keeps out_costs.0 on the streaming kernel with the upsample evaluated in its producers.  MVSGI_POLY_MIN_UNITS: minimum
 # 128-cell bricks (low resolution) per launch for the polyphase form
 _USE_POLY = os.environ.get("MVSGI_POLY", "1") != "0"
+_HEAD_SPLIT = os.environ.get("MVSGI_HEAD_SPLIT", "1") != "0"      # 0: polyphase out_costs.0 writes fp32 and the exact-fp32 head reads it
 # (measured on MI355X, G16V: 400 bricks per frame and role; B = 4: 2722 vs 2837 frames/s with / without, B = 8: 3714 vs 3742, B = 16:
 # 4335 vs 4291, B = 64: 5091 vs 4820 -- three launches and a prologue + two drain phases per workgroup need ~12 frames to pay)
 _POLY_MIN_UNITS = int(os.environ.get("MVSGI_POLY_MIN_UNITS", "4800"))
 
 
 def _poly_tail(self, x: Tensor, skip: Tensor):
-    """The last up block + out_costs.0 as (up block writing its result split-padded) -> (polyphase ResizeConv3d on the
-    register-stationary kernel), when the layer shapes allow it (32 -> 16 channels: the (16, 32) regulator); else None."""
+    """The last up block + out_costs as (up block writing its result split-padded) -> (polyphase ResizeConv3d on the
+    register-stationary kernel) -> (cost head), when the layer shapes allow it (32 -> 16 channels: the (16, 32) regulator);
+    returns costs [B, D, H, W, final_chs] or None."""
     if not (_USE_POLY and len(self.upBlks) > 0):
         return None
     up, oc = self.upBlks[len(self.upBlks) - 1], self.out_costs[0]
@@ -123,7 +125,14 @@ def _poly_tail(self, x: Tensor, skip: Tensor):
     if key not in bufs:
         bufs[key] = H.SplitAct(B, 2 * Dl, 2 * Hl, 2 * Wl, 32, x.device)
     xs = Lu.run_up2_split(x, skip, bufs[key])
-    return Lo.run_up2_poly(xs)
+    # the cost head reads split-padded fragments straight into the matrix cores: out_costs.0 then writes that format
+    Lh = cm.lower_conv_block(self.out_costs[1])
+    if _HEAD_SPLIT and Lh.head_split_ok() and Lh.cin == 16:
+        hkey = (B, 4 * Dl, 4 * Hl, 4 * Wl, "hi", x.device)
+        if hkey not in bufs:
+            bufs[hkey] = H.SplitAct(B, 4 * Dl, 4 * Hl, 4 * Wl, 16, x.device)
+        return Lh.run_head_split(Lo.run_up2_poly_split(xs, bufs[hkey]))
+    return Lh.run(Lo.run_up2_poly(xs))
 
 
 def regulator_forward_ndhwc(self, x: Tensor) -> Tensor:
@@ -138,9 +147,9 @@ def regulator_forward_ndhwc(self, x: Tensor) -> Tensor:
     n_up = len(self.upBlks)
     for i, up in enumerate(self.upBlks):
         if i == n_up - 1:
-            y = _poly_tail(self, x, skips[i])
+            y = _poly_tail(self, x, skips[i])          # ... -> out_costs.0 (polyphase) -> out_costs.1
             if y is not None:
-                return cm.lower_conv_block(self.out_costs[1]).run(y)
+                return y
         x = cm.resize_conv_ndhwc(up, x, res=skips[i])
     x = cm.resize_conv_ndhwc(self.out_costs[0], x)
     return cm.lower_conv_block(self.out_costs[1]).run(x)

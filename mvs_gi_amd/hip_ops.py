@@ -381,6 +381,39 @@ def conv3d_up2_poly(x: "SplitAct", plan: torch.Tensor, scale, shift, neg_slope=0
     return y
 
 
+def conv3d_up2_poly_split(x: "SplitAct", plan: torch.Tensor, scale, shift, out: "SplitAct", neg_slope=0.01) -> "SplitAct":
+    """conv3d_up2_poly with the result written split-padded into `out` (B, 2D, 2H, 2W, 16)."""
+    lib = _lib.load()
+    if x.C != 32 or scale.numel() != 16 or out.shape != (x.B, 2 * x.D, 2 * x.H, 2 * x.W, 16):
+        raise AssertionError(f"conv3d_up2_poly_split: input {x.shape}, output {out.shape}")
+    _lib.check(lib.mvsgi_conv3d_up2_poly_split(x.buf.data_ptr(), plan.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.buf.data_ptr(),
+                                               x.B, x.D, x.H, x.W, float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_up2_poly_split")
+    return out
+
+
+def pack_head_split_weights(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
+    """[1, Cin % 16 == 0, 3, 3, 3] -> the fragment layout of conv3d_head_split, or None when unsupported."""
+    lib = _lib.load()
+    w = _dev(w_oidhw, "conv weight")
+    if w.shape[0] != 1 or tuple(w.shape[2:]) != (3, 3, 3) or w.shape[1] % 16:
+        return None
+    wp = torch.empty(lib.mvsgi_conv3d_head_split_packed_weight_bytes(int(w.shape[1])), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.mvsgi_conv3d_head_split_pack_weights(w.data_ptr(), wp.data_ptr(), int(w.shape[1]), _stream_ptr(w)),
+               "mvsgi_conv3d_head_split_pack_weights")
+    return wp
+
+
+def conv3d_head_split(x: "SplitAct", w_packed, scale: float, shift: float, neg_slope=1.0, out=None) -> torch.Tensor:
+    """Cost head (Cout = 1) on a split-padded input -> fp32 [B, D, H, W, 1] = act(conv(x) * scale + shift)."""
+    lib = _lib.load()
+    y = out if out is not None else torch.empty((x.B, x.D, x.H, x.W, 1), device=x.buf.device, dtype=torch.float32)
+    if tuple(y.shape) != (x.B, x.D, x.H, x.W, 1) or not y.is_contiguous():
+        raise AssertionError(f"head output {tuple(y.shape)} does not match {(x.B, x.D, x.H, x.W, 1)}")
+    _lib.check(lib.mvsgi_conv3d_head_split(x.buf.data_ptr(), w_packed.data_ptr(), float(scale), float(shift), y.data_ptr(), x.B, x.C,
+                                           x.D, x.H, x.W, float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_head_split")
+    return y
+
+
 def conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, w_layout=CONV_BF16X3) -> str:
     lib = _lib.load()
     name = lib.mvsgi_conv3d_up2_variant_f32(B, Cin, Dl, Hl, Wl, Cout, w_layout)

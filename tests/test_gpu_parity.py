@@ -603,7 +603,7 @@ def test_bench_self_launches_its_ranks():
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["devices"] == [0, 0]
     assert d["value"] > 0 and d["scaling"] == "weak"
     hbm = {k: v for k, v in d["kernels"].items() if v.get("bound") == "hbm"}
-    assert any(k.startswith("sweep_std") for k in hbm) and any(k.startswith("softargmin") for k in hbm) and "conv3d_head_kernel" in hbm
+    assert any(k.startswith("sweep_std") for k in hbm) and any(k.startswith("softargmin") for k in hbm) and any(k.startswith("conv3d_head") for k in hbm)
     assert all(v["GBps"] > 0 for v in hbm.values())
     assert d["roofline"]["attributed_time_frac_of_step"] > 0.8
 
@@ -1309,3 +1309,40 @@ def test_regulator_polyphase_tail_matches_streaming_and_goldens(golden_dir):
     finally:
         H.set_conv_mode(old_mode)
         cr._USE_POLY, cr._POLY_MIN_UNITS = old_use, old_min
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 1, 1, 1), (1, 16, 3, 5, 7), (2, 16, 5, 9, 33), (1, 32, 4, 9, 33), (2, 48, 5, 8, 32), (3, 16, 16, 80, 320),
+                                   (70, 16, 2, 8, 32)])
+def test_cost_head_on_split_padded_input_vs_conv3d(shape):
+    """out_costs.1 (Conv3d(Cin -> 1, bias)) on a split-padded input, split-bf16 MFMA with the 27 taps as the M dimension, against
+    F.conv3d on the same 16-bit-split input: one to three channel slices, windows ragged in H and W, whole-depth and chunked marches."""
+    B, cin, d, h, w = shape
+    rng = np.random.default_rng(sum(shape))
+    x = _g(rng.standard_normal((B, d, h, w, cin), dtype=np.float32))
+    wt = (rng.standard_normal((1, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32)
+    bias = 0.37
+    xs = H.act_to_split(x)
+    y = H.conv3d_head_split(xs, H.pack_head_split_weights(_g(wt)), 1.0, bias)
+    xq = H.act_from_split(xs).cpu().permute(0, 4, 1, 2, 3).double()
+    ref = (F.conv3d(xq, torch.from_numpy(wt).double(), padding=1) + bias).permute(0, 2, 3, 4, 1).numpy()
+    assert tuple(y.shape) == (B, d, h, w, 1)
+    assert _rel(y.cpu().numpy(), ref) <= 1e-4
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (2, 2, 4, 16), (3, 5, 9, 33), (2, 8, 40, 160)])
+def test_polyphase_split_padded_output_is_the_split_of_its_fp32_output(shape):
+    """The polyphase layer writing split-padded (the cost head's input): bit for bit the split of its fp32 result, border zero."""
+    B, d, h, w = shape
+    rng = np.random.default_rng(sum(shape) + 1)
+    x = _g(rng.standard_normal((B, d, h, w, 32), dtype=np.float32))
+    wt = _g((rng.standard_normal((16, 32, 3, 3, 3)) / np.sqrt(27 * 32)).astype(np.float32))
+    sc, sh = _g(rng.uniform(0.5, 1.5, 16).astype(np.float32)), _g((rng.standard_normal(16) * 0.1).astype(np.float32))
+    xs = H.act_to_split(x)
+    plan = H.conv3d_up2_poly_plan(wt, d, h, w)
+    y = H.conv3d_up2_poly(xs, plan, sc, sh)
+    ys = H.SplitAct(B, 2 * d, 2 * h, 2 * w, 16, x.device)
+    ys.buf.fill_(0x7fc07fc0 - (1 << 32) if False else 0)           # (zero border: allocated zero-filled)
+    H.conv3d_up2_poly_split(xs, plan, sc, sh, out=ys)
+    assert torch.equal(ys.buf, H.act_to_split(y).buf)
+    H.conv3d_up2_poly_split(xs, plan, sc, sh, out=ys)              # a second call over its own output (corrections overwrite records first)
+    assert torch.equal(ys.buf, H.act_to_split(y).buf)
