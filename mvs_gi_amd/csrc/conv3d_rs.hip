@@ -735,8 +735,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
     for (; ph < n; ++ph) {
         const int nxt_img = (ph & 1) ? 0 : BUF1;
 #include "conv3d_rs16_phase_main.inc"
-        // all but the 4 youngest vector-memory operations (this phase's output stores): the next image has landed
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
     {

@@ -162,14 +162,6 @@ def build(with_pairs):
         if not with_pairs:
             lo = max(lo, 30)
         S.place(lo, 4, f"fin[{op}] = acc[{op}]; RS_PIN_V(fin[{op}])", end=hi + 1, cap=5.0)
-    # LDS-DMA of the next brick: 14 pieces per wave, FIRST in the phase (the image they fill was last read before the barrier):
-    # they get the whole phase to land, and the epilogue's four stores behind them are the youngest vector-memory operations at
-    # the phase's end -- s_waitcnt vmcnt(4) then waits for the staging only and the stores complete under the next phase (with
-    # the stores in front, every piece's completion also waited for the older stores' write acknowledgements)
-    if with_pairs:
-        s = 6
-        for m in range(14):
-            s = S.place(s, 2.0, f"RS_F_DMA(RS16_DMA({m}))") + 3
     # epilogue: scale / shift, LeakyReLU, fp32 store -- one instruction per statement
     s = 36
     ep_end = s
@@ -184,6 +176,12 @@ def build(with_pairs):
             if cost >= 2.0:
                 s += 1
         ep_end = s
+    # LDS-DMA of the next brick: 14 pieces per wave, after the epilogue's stores (the staging is then the youngest VMEM work)
+    if with_pairs:
+        s = ep_end + 2
+        step = max((n - 40 - s) // 14, 3)
+        for m in range(14):
+            s = S.place(s, 2.0, f"RS_F_DMA(RS16_DMA({m}))") + step
     # the read bases move to the other image once this phase's last reads are out; the walk moves on
     if with_pairs:
         for k, b in enumerate(("b_in", "b_2a", "b_2b")):
