@@ -299,7 +299,7 @@ enum Variant {
     V_DIRECT1, V_DIRECT4, V_HEAD,
     V_S1_N16_B256, V_S1_N32_B256, V_S1_N32_B64, V_S1_N64_B128, V_S1_N64_B64, V_S2_N32_B64, V_S2_N64_B64,
     // split-bf16 kernel: 16-wide bricks (conflict-free LDS reads); N = couts per workgroup
-    B3_N16, B3_N32, B3_N48, B3_N64, B3_N64_H5, B3_N32_B, B3_N32_H5, B3_N96, B3_N32_S, B3_N64_S, B3_N16_T, B3_N32_T, B3_S2_N32, B3_S2_N64,
+    B3_N16, B3_N32, B3_N48, B3_N64, B3_N64_H5, B3_N96, B3_N32_S, B3_N64_S, B3_N16_T, B3_N32_T, B3_S2_N32, B3_S2_N64,
     // split-bf16 kernel with the trilinear x2 upsample fused into its producers (even bricks only)
     B3U_N16, B3U_N32, B3U_N32_M, B3U_N48, B3U_N64, B3U_N96,
     // Cout == 16 plane schedule (weights from mvsgi_conv3d_pack_weights_bf16x3_c16), plain and fused-upsample
@@ -317,7 +317,6 @@ const char* const kVariantNames[V_COUNT] = {
     "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false>",
     "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, false, false, false>",
     "conv3d_bf16x3_kernel<2, 5, 2, 2, 2, 5, 16, 1, 3, false, false, false>",
-    "conv3d_bf16x3_kernel<1, 4, 2, 2, 2, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<1, 5, 2, 2, 2, 5, 16, 1, 3, false, false, false>",
     "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false>",
     "conv3d_bf16x3_kernel<2, 2, 2, 2, 1, 4, 16, 1, 3, false, false, false>",
     "conv3d_bf16x3_kernel<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false>",
@@ -412,24 +411,9 @@ int select_variant(const ConvArgs& a, int impl) {
         // planes whose height is a multiple of 5 but not of 4 (the 10 x 40 planes of UNet level 2): 2 x 5 x 16 bricks cover them
         // exactly where 2 x 4 x 16 ones pad 10 rows to 12 (17 % of the MFMAs) and stage 7 % more halo per voxel
         static const bool h5 = !getenv("MVSGI_NO_H5");
-        const bool use_h5 = h5 && a.Ho % 5 == 0 && a.Ho % 4 != 0;
-        const long long bricks = use_h5 ? (long long)a.B * mvsgi::cdiv(a.Do, 2) * (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16) : mid;
-        if (bricks * mvsgi::cdiv(CT, 4) >= 384) {
-            // 64 or 32 couts per workgroup: the persistent grid (two workgroups per CU) walks ceil(units / grid) rounds, and a
-            // launch whose unit count is 1.5 grids (UNet level 2 at 64 frames: 768 units on 512 workgroups) idles a quarter of
-            // the chip in its second round.  Half-size units (32 couts: twice the staging per MFMA, these layers have the
-            // producers to spare) take the finer grain when that saves rounds: 3 half rounds instead of 2 whole ones.
-            static const bool fine = !getenv("MVSGI_NO_FINE_UNITS");
-            static const long long grid = [] {
-                int dev = 0, cus = 256;
-                if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-                return (long long)(cus / 8 * 8) * 2;
-            }();
-            const long long u64 = bricks * mvsgi::cdiv(CT, 4), u32 = bricks * mvsgi::cdiv(CT, 2);
-            const bool half = fine && CT % 2 == 0 && mvsgi::cdiv(u32, grid) < 2 * mvsgi::cdiv(u64, grid);
-            if (use_h5) return half ? B3_N32_H5 : B3_N64_H5;
-            return half ? B3_N32_B : B3_N64;
-        }
+        if (h5 && a.Ho % 5 == 0 && a.Ho % 4 != 0 && (long long)a.B * mvsgi::cdiv(a.Do, 2) * (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16) * mvsgi::cdiv(CT, 4) >= 384)
+            return B3_N64_H5;
+        if (mid * mvsgi::cdiv(CT, 4) >= 384) return B3_N64;
         // a frame or two (latency path): 64-voxel bricks, and as few couts per workgroup as it takes to put a few hundred
         // workgroups on the chip -- each then walks Cin / 16 slices of 42 (16 couts) or 84 (32 couts) MFMAs per wave
         const long long tiny = (long long)a.B * a.Do * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
@@ -465,8 +449,6 @@ int launch_variant(int v, const ConvArgs& a, hipStream_t st) {
         case B3_N48: return launch_bf16x3<3, 4, 4, 1, 4, 4, 16, 1>(a, st);
         case B3_N64: return launch_bf16x3<2, 4, 2, 2, 2, 4, 16, 1>(a, st);
         case B3_N64_H5: return launch_bf16x3<2, 5, 2, 2, 2, 5, 16, 1>(a, st);
-        case B3_N32_B: return launch_bf16x3<1, 4, 2, 2, 2, 4, 16, 1>(a, st);
-        case B3_N32_H5: return launch_bf16x3<1, 5, 2, 2, 2, 5, 16, 1>(a, st);
         case B3_N96: return launch_bf16x3<3, 4, 2, 2, 2, 4, 16, 1>(a, st);
         case B3_N32_S: return launch_bf16x3<2, 1, 4, 1, 1, 4, 16, 1>(a, st);
         case B3_N64_S: return launch_bf16x3<2, 2, 2, 2, 1, 4, 16, 1>(a, st);

@@ -170,8 +170,6 @@ CONV_SHAPES = [
     (1, 64, 32, 5, 7, 9, 1, False, 1.0),        # identity activation
     (32, 128, 128, 2, 10, 40, 1, True, 0.01),   # UNet level 2 at 32 frames: the 2 x 5 x 16 brick variant (H a multiple of 5, not of 4)
     (32, 64, 64, 3, 15, 21, 1, True, 0.01),     # the same variant, ragged in D and W
-    (64, 128, 128, 2, 10, 40, 1, True, 0.01),   # UNet level 2 at 64 frames: 32-cout units (3 half rounds instead of 2 whole ones)
-    (36, 64, 64, 4, 20, 48, 1, True, 0.01),     # 32-cout units on 2 x 4 x 16 bricks
 ]
 
 
@@ -223,9 +221,6 @@ def test_conv3d_bf16x3_vs_oracle(shape):
     assert "bf16x3" in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3)
     if B == 32:
         assert "<2, 5, 2, 2, 2, 5, 16" in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3)
-    if B in (64, 36) and torch.cuda.get_device_properties(0).multi_processor_count == 256:
-        assert "<1, 5, 2, 2, 2, 5, 16" in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3) or \
-            "<1, 4, 2, 2, 2, 4, 16" in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3)
     y = H.conv3d(xg, wg, wp, _g(scale), _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3)
     err = _rel(_ncdhw(y), yref)
     assert err <= 1e-4, err
