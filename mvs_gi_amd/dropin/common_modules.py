@@ -21,6 +21,14 @@ from torch import nn, Tensor
 from .. import hip_ops as H
 
 
+def module_getstate(self):
+    """__getstate__ of the drop-in modules (and, in patch mode, of the reference's classes): the launch records, packed
+    weights, polyphase plans and module-owned activation buffers cached on a module under `_mvsgi_*` keys are derived data
+    -- they are rebuilt on the next forward and must not travel with a pickled module or a whole-module checkpoint
+    (Lightning's save_hyperparameters() pickles module OBJECTS, spherical_sweep_stereo.py:74)."""
+    return {k: v for k, v in self.__dict__.items() if not k.startswith("_mvsgi_")}
+
+
 class NoOp(nn.Identity):
     """Alias of nn.Identity, as in the reference (common_modules.py:13-16)."""
     def infer_size(self, in_size):
@@ -259,6 +267,8 @@ class BaseConvBlk3d(nn.Module):
                                     bias=bias_on, stride=stride)
         self.norm_layer = norm_layer
         self.activation = activation
+
+    __getstate__ = module_getstate
 
     def forward_ndhwc(self, x: Tensor, res: Optional[Tensor] = None) -> Tensor:
         return lower_conv_block(self).run(x, res)

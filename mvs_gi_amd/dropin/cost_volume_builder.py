@@ -28,6 +28,7 @@ _RIG_CACHE_ENV = os.environ.get("MVSGI_RIG_CACHE", "1") != "0"
 
 class _SweepBase(nn.Module):
     cache_rig_constants = True       # class attribute: unpickled reference modules get it too
+    __getstate__ = cm.module_getstate
 
     def __init__(self, num_cams: int, feat_chs: int, post_k_sz: int, norm_type: str = "batch",
                  relu_type: str = "leaky"):

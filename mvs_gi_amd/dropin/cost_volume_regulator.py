@@ -28,6 +28,8 @@ class UNetDownBlk(nn.Module):
             cm.ResConvBlk3d(out_chs, out_chs, kernel_size, activation=copy.deepcopy(activation),
                             norm_layer=copy.deepcopy(norm_layer)) for _ in range(width - 1)])
 
+    __getstate__ = cm.module_getstate
+
     def forward(self, x: Tensor) -> Tensor:
         return cm._to_ncdhw_view(down_block_ndhwc(self, H.as_ndhwc(x)))
 
@@ -194,6 +196,7 @@ class UNetCostVolumeRegulatorBase(nn.Module):
                              norm_layer=cm.NoOp()))
 
     forward = regulator_forward
+    __getstate__ = cm.module_getstate
 
 
 class UNetCostVolumeRegulator(nn.Module):
@@ -238,3 +241,4 @@ class UNetCostVolumeRegulator(nn.Module):
                              norm_layer=cm.NoOp()))
 
     forward = regulator_forward
+    __getstate__ = cm.module_getstate

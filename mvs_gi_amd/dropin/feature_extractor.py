@@ -18,7 +18,7 @@ from torch import nn, Tensor
 
 from .. import hip_ops as H
 from . import common_modules as cm
-from .common_modules import NoOp, NORM2D_TYPE, RELU_TYPE, _is_identity
+from .common_modules import module_getstate, NoOp, NORM2D_TYPE, RELU_TYPE, _is_identity
 
 
 _STEM_MFMA = os.environ.get("MVSGI_STEM_MFMA", "1") != "0"      # 0: the LDS-tiled VALU stem for uint8 images too
@@ -120,6 +120,8 @@ def _calc(in_size, k, stride, pad):
 
 
 class BaseConvBlk2d(nn.Module):
+    __getstate__ = module_getstate
+
     def __init__(self, in_chs: int, out_chs: int, kernel_size: int, stride: int = 1, out_pad: int = 0,
                  extra_pad: int = 0, bias_on: bool = False, norm_layer: nn.Module = NoOp(),
                  activation: nn.Module = NoOp()):
@@ -282,6 +284,7 @@ def sphere_conv_offsets(input_size, kernel_size, stride, padding, dilation, lat_
 class SphereConvEquirect2d(nn.Module):
     """common/common_modules.py:360-425: Conv2d whose taps follow the sphere; parameters `weight`
     [Cout, Cin/groups, Kh, Kw], optional `bias`, buffer `offset` (state-dict compatible)."""
+    __getstate__ = module_getstate
 
     def __init__(self, in_size, in_channels: int, out_channels: int, kernel_size, stride=1, padding=0, dilation=1,
                  groups: int = 1, bias: bool = True):

@@ -104,13 +104,14 @@ def _patch_reference():
     r = importlib.import_module("dsta_mvs.model.cost_volume_regulator.unet_regulator")
     d = importlib.import_module("dsta_mvs.model.distance_regressor.distance_regressor")
     c = importlib.import_module("dsta_mvs.model.common.common_modules")
-    rebind(b.SphericalSweepStdMasked, forward=_cvb.std_forward, sweep=_cvb.SphericalSweepStdMasked.sweep)
-    rebind(b.SphericalSweep, forward=_cvb.cat_forward, sweep=_cvb.SphericalSweep.sweep)
-    rebind(r.UNetCostVolumeRegulatorBase, forward=_reg.regulator_forward)
-    rebind(r.UNetCostVolumeRegulator, forward=_reg.regulator_forward)
-    rebind(r.UNetDownBlk, forward=_reg.UNetDownBlk.forward)
+    gs = _cm.module_getstate      # derived `_mvsgi_*` caches never travel with a pickled module
+    rebind(b.SphericalSweepStdMasked, forward=_cvb.std_forward, sweep=_cvb.SphericalSweepStdMasked.sweep, __getstate__=gs)
+    rebind(b.SphericalSweep, forward=_cvb.cat_forward, sweep=_cvb.SphericalSweep.sweep, __getstate__=gs)
+    rebind(r.UNetCostVolumeRegulatorBase, forward=_reg.regulator_forward, __getstate__=gs)
+    rebind(r.UNetCostVolumeRegulator, forward=_reg.regulator_forward, __getstate__=gs)
+    rebind(r.UNetDownBlk, forward=_reg.UNetDownBlk.forward, __getstate__=gs)
     rebind(d.DistanceRegressorWithFixedCandidates, forward=_dr.regressor_forward)
-    rebind(c.BaseConvBlk3d, forward=_cm.BaseConvBlk3d.forward)
+    rebind(c.BaseConvBlk3d, forward=_cm.BaseConvBlk3d.forward, __getstate__=gs)
     rebind(c.ResConvBlk3d, forward=_cm.ResConvBlk3d.forward)
     rebind(c.ResizeConv3d, forward=_cm.ResizeConv3d.forward)
     rebind(c.BaseConvBlk2d, forward=_fe.BaseConvBlk2d.forward)

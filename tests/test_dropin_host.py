@@ -154,3 +154,25 @@ def test_default_conv_mode_is_bf16x3():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, MVSGI_CONV_MODE="fp16"),
                        cwd=root, timeout=300)
     assert r.returncode != 0
+
+
+def test_pickled_modules_do_not_carry_derived_caches():
+    """Launch records, packed weights, polyphase plans and module-owned activation buffers live under `_mvsgi_*` keys of a
+    module's __dict__; a pickled module (Lightning pickles module OBJECTS: spherical_sweep_stereo.py:74) must not carry them."""
+    import io
+    import pickle
+    from mvs_gi_amd import dropin
+    reg = dropin.UNetCostVolumeRegulatorBase(in_chs=16, f_int_chs=32)
+    cvb = dropin.SphericalSweepStdMasked(num_cams=3, feat_chs=16, post_k_sz=3)
+    reg.__dict__["_mvsgi_poly_bufs"] = {"k": torch.zeros(4)}
+    reg.down_blks[0].__dict__["_mvsgi_rs_bufs"] = {"k": torch.zeros(4)}
+    reg.out_costs[1].__dict__["_mvsgi_launch"] = object()            # not even picklable on its own terms
+    cvb.__dict__["_mvsgi_rs_vol"] = {"k": torch.zeros(4)}
+    for m in (reg, cvb):
+        m2 = pickle.loads(pickle.dumps(m))
+        assert not [k for mod in m2.modules() for k in mod.__dict__ if k.startswith("_mvsgi_")]
+        sd, sd2 = m.state_dict(), m2.state_dict()
+        assert list(sd) == list(sd2) and all(torch.equal(sd[k], sd2[k]) for k in sd)
+    buf = io.BytesIO()
+    torch.save(reg, buf)
+    assert buf.tell() < 20 * 2 ** 20                                 # the 4 M-parameter regulator, nothing else
