@@ -492,6 +492,21 @@ __global__ __launch_bounds__(256) void sweep_std_nhwc_v_kernel(const float* __re
         }
         const bool ok = n > 1.0f;
         const float cnt = ok ? n : 1.0f;
+        // A camera that is not valid at this voxel contributes sv * 0 to the sum and is replaced by the mean in the variance
+        // (spherical_sweep_avg.py:114-119), and a voxel seen by fewer than two cameras is 0 whatever was sampled (:125): those
+        // texels are never needed.  Their tap offsets are sent out of the descriptor's range -- the loads return zeros and move no
+        // data (same bits out for finite features: +-0 instead of +-0; a non-finite feature under an invalid camera would have
+        // poisoned the reference's sum with NaN, here it is not read).  On the benchmark rig 35 % of the (voxel, camera) pairs.
+#ifndef MVSGI_SWEEP_GATHER_ALL
+#pragma unroll
+        for (int cam = 0; cam < NCAM; ++cam) {
+            const bool need = val[cam] & ok;
+            ft[cam].o00 = need ? ft[cam].o00 : (int)0x80000000;
+            ft[cam].o01 = need ? ft[cam].o01 : (int)0x80000000;
+            ft[cam].o10 = need ? ft[cam].o10 : (int)0x80000000;
+            ft[cam].o11 = need ? ft[cam].o11 : (int)0x80000000;
+        }
+#endif
         // RN(1 / cnt) for the camera counts there are: exactly what the division 1.0f / cnt returns
         const float inv = cnt == 2.0f ? 0.5f : cnt == 3.0f ? 0x1.555556p-2f : cnt == 4.0f ? 0.25f : 1.0f;
         const f32x2_t INV = {inv, inv}, NCNT = {-cnt, -cnt};
