@@ -30,8 +30,13 @@ wp1 = H.pack_conv_weights_rs(w1)
 s16, z16 = torch.ones(16, device=dev), torch.zeros(16, device=dev)
 raw = [H.SplitAct(k, D, Ho, Wo, 16, dev) for _ in range(2)]
 vol = torch.empty((B, D, Ho, Wo, 16), device=dev)
+ap2 = os.environ.get("PRIO", "1") == "1"
+# post_vol's persistent grid (one 240-register wave per SIMD) must get its CUs FIRST, the sweep's blocks then fill the rest of
+# the register file (two waves per SIMD beside it); the other way round five sweep waves per SIMD leave post_vol no room
+hi = torch.cuda.Stream(device=dev, priority=-1) if ap2 else torch.cuda.Stream(device=dev)
+torch.cuda.set_stream(hi)
 main = torch.cuda.current_stream(dev)
-side = torch.cuda.Stream(device=dev)
+side = torch.cuda.Stream(device=dev, priority=0)
 n = B // k
 
 
