@@ -218,6 +218,29 @@ int mvsgi_resblock2d_f32(const float* x, const void* w_packed1, const float* sca
                          const void* w_packed2, const float* scale2, const float* shift2, float* y,
                          int N, int H, int W, float neg_slope, mvsgi_stream_t stream);
 
+/* The same block on PRE-SPLIT activations (csrc/resblock2d_rs.hip): the extractor's chain of residual blocks hands its
+ * activations on in the 2-D split-padded format
+ *   [N][H + 4][W + 4][64 B],  pixel record = [hi(c 0-7) | hi(c 8-15) | lo(c 0-7) | lo(c 8-15)] bf16,  x = hi + lo,
+ * with a two-pixel zero border that no kernel writes (the caller zeroes a buffer once; mvsgi_split2d_bytes gives its size).
+ * Staging is then a pure copy (LDS-DMA), two workgroups share a CU, and the skip connection is read from LDS.
+ * w_packed1 / w_packed2 from mvsgi_resblock2d_split_pack_weights ([16][16][3][3] fp32 each, the per-channel scale folded
+ * in: y = act(conv2'(act(conv1'(x) + shift1)) + shift2 + x)).  y: the same format
+ * (y_is_split != 0) or plain fp32 [N][H][W][16] (the hand-over to a kernel that stages fp32).  x_split != y.
+ * mvsgi_conv2d_f32_out_split2d = mvsgi_conv2d_f32 writing that format (Cout == 16: the RGB stem and the split-bf16 3x3
+ * kernels); mvsgi_f32_to_split2d / mvsgi_split2d_to_f32 convert at module boundaries and in tests. */
+size_t mvsgi_split2d_bytes(int N, int H, int W);
+int mvsgi_f32_to_split2d(const float* x, void* y_split, int N, int H, int W, mvsgi_stream_t stream);
+int mvsgi_split2d_to_f32(const void* x_split, float* y, int N, int H, int W, mvsgi_stream_t stream);
+size_t mvsgi_resblock2d_split_packed_weight_bytes(void);
+int mvsgi_resblock2d_split_pack_weights(const float* w_oihw, const float* scale, void* w_packed, mvsgi_stream_t stream);
+int mvsgi_resblock2d_split(const void* x_split, const void* w_packed1, const float* shift1,
+                           const void* w_packed2, const float* shift2, void* y, int y_is_split,
+                           int N, int H, int W, float neg_slope, mvsgi_stream_t stream);
+int mvsgi_conv2d_f32_out_split2d(const float* x, const float* w_oihw, const void* w_packed,
+                                 const float* scale, const float* shift, const float* res, void* y_split,
+                                 int B, int Cin, int Hin, int Win, int Cout, int ksize, int stride,
+                                 float neg_slope, int impl, int in_nchw, mvsgi_stream_t stream);
+
 /* ---- sampling-grid generator ---------------------------------------
  * The closed forms of dsta_mvs/support/dataset/torch_cuda_sweep.py, composed as
  * MultiViewCameraModelDataset.make_sweep_grid_cuda does (support/dataset/multi_view_camera_model_dataset.py:474-521):

@@ -29,7 +29,17 @@ struct Conv2dArgs {
     float* y;
     int B, Cin, Hin, Win, Cout, Ho, Wo, k, stride, in_nchw;
     float neg_slope;
+    unsigned char* ys;   // stem kernels: when set, the output goes here in the 2-D split-padded format (resblock2d_rs.hip) instead of y
 };
+
+// 16 channels of one pixel as a 2-D split-padded record [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15]: couts 4 q .. 4 q + 3
+__device__ __forceinline__ void store_split2d_quad(unsigned char* ys, int b, int Ho, int Wo, int oy, int ox, int q, const f32x4 r) {
+    u32x2 hi, lo;
+    split_bf16x4(r, hi, lo);
+    unsigned char* p = ys + (((long long)b * (Ho + 4) + oy + 2) * (Wo + 4) + ox + 2) * 64 + (q >> 1) * 16 + (q & 1) * 8;
+    *reinterpret_cast<u32x2*>(p) = hi;
+    *reinterpret_cast<u32x2*>(p + 32) = lo;
+}
 
 // thread = (pixel, CO consecutive couts); weights are wave-uniform reads
 template <int CO>
@@ -128,7 +138,8 @@ __global__ __launch_bounds__(256) void conv2d_stem_kernel(Conv2dArgs a) {
         f32x4 r = acc[q] * *reinterpret_cast<const f32x4*>(a.scale + 4 * q) + *reinterpret_cast<const f32x4*>(a.shift + 4 * q);
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : r[e] * a.neg_slope;
-        *reinterpret_cast<f32x4*>(yp + 4 * q) = r;
+        if (a.ys) store_split2d_quad(a.ys, b, a.Ho, a.Wo, oy, ox, q, r);
+        else *reinterpret_cast<f32x4*>(yp + 4 * q) = r;
     }
 }
 
@@ -148,6 +159,7 @@ struct StemArgs {
     float* y;
     int B, Hin, Win, Ho, Wo;
     float neg_slope;
+    unsigned char* ys;         // 2-D split-padded output instead of y
 };
 
 constexpr int kStemRows = 8, kStemCols = 64, kStemRowDw = 100;
@@ -225,7 +237,8 @@ __global__ __launch_bounds__(256) void conv2d_stem_u8_mfma_kernel(StemArgs a) {
             f32x4 r = acc * sc + sh;
 #pragma unroll
             for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : r[e] * a.neg_slope;
-            *reinterpret_cast<f32x4*>(a.y + (((long long)b * a.Ho + oy) * a.Wo + ox) * 16 + 4 * g) = r;
+            if (a.ys) store_split2d_quad(a.ys, b, a.Ho, a.Wo, oy, ox, g, r);
+            else *reinterpret_cast<f32x4*>(a.y + (((long long)b * a.Ho + oy) * a.Wo + ox) * 16 + 4 * g) = r;
         }
     }
 }
@@ -306,11 +319,13 @@ extern "C" const char* mvsgi_conv2d_variant_f32(int Cin, int Cout, int ksize, in
     return v == D2_COUNT ? nullptr : kNames2d[v];
 }
 
-extern "C" int mvsgi_conv2d_f32(const float* x, const float* w_oihw, const void* w_packed, const float* scale,
-                                const float* shift, const float* res, float* y, int B, int Cin, int Hin, int Win,
-                                int Cout, int ksize, int stride, float neg_slope, int impl, int in_nchw,
-                                mvsgi_stream_t stream) {
-    MVSGI_REQUIRE(x && y && scale && shift, "mvsgi_conv2d_f32: null pointer");
+namespace {
+int conv2d_run(const float* x, const float* w_oihw, const void* w_packed, const float* scale,
+               const float* shift, const float* res, float* y, unsigned char* ys, int B, int Cin, int Hin, int Win,
+               int Cout, int ksize, int stride, float neg_slope, int impl, int in_nchw,
+               mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(x && (y || ys) && scale && shift, "mvsgi_conv2d_f32: null pointer");
+    MVSGI_REQUIRE(!ys || Cout == 16, "mvsgi_conv2d_f32_out_split2d: the 2-D split-padded format holds 16 channels, got Cout = %d", Cout);
     MVSGI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0, "mvsgi_conv2d_f32: bad dims");
     MVSGI_REQUIRE(ksize >= 1 && (ksize & 1) && ksize <= 7, "mvsgi_conv2d_f32: kernel size %d not odd in [1, 7]", ksize);
     MVSGI_REQUIRE(stride == 1 || stride == 2, "mvsgi_conv2d_f32: stride %d not in {1, 2}", stride);
@@ -320,12 +335,12 @@ extern "C" int mvsgi_conv2d_f32(const float* x, const float* w_oihw, const void*
     if (v == D2_COUNT) return 1;
     hipStream_t st = mvsgi::as_stream(stream);
     if (v == D2_DIRECT) {
-        Conv2dArgs a{x, w_oihw, scale, shift, res, y, B, Cin, Hin, Win, Cout, Ho, Wo, ksize, stride, in_nchw, neg_slope};
+        Conv2dArgs a{x, w_oihw, scale, shift, res, y, B, Cin, Hin, Win, Cout, Ho, Wo, ksize, stride, in_nchw, neg_slope, ys};
         if (ksize == 5 && stride == 2 && Cin == 3 && Cout == 16 && in_nchw && !res && B < 65536) {
             const dim3 grid((unsigned)mvsgi::cdiv(Wo, 16), (unsigned)mvsgi::cdiv(Ho, 16), (unsigned)B);
             if (in_nchw == 2 && w_packed && Win % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 3) == 0) {
                 StemArgs sa{reinterpret_cast<const unsigned char*>(x), reinterpret_cast<const bf16x8*>(w_packed), scale, shift, y,
-                            B, Hin, Win, Ho, Wo, neg_slope};
+                            B, Hin, Win, Ho, Wo, neg_slope, ys};
                 const dim3 gm((unsigned)mvsgi::cdiv(Wo, kStemCols), (unsigned)mvsgi::cdiv(Ho, kStemRows), (unsigned)B);
                 hipLaunchKernelGGL(conv2d_stem_u8_mfma_kernel, gm, dim3(256), 0, st, sa);
                 return mvsgi::check_launch("mvsgi_conv2d_f32(stem, matrix cores)");
@@ -337,6 +352,7 @@ extern "C" int mvsgi_conv2d_f32(const float* x, const float* w_oihw, const void*
             return mvsgi::check_launch("mvsgi_conv2d_f32(stem)");
         }
         MVSGI_REQUIRE(in_nchw != 2, "mvsgi_conv2d_f32: uint8 HWC input is implemented for the 5x5 stride-2 3->16 stem only");
+        MVSGI_REQUIRE(!ys, "mvsgi_conv2d_f32_out_split2d: not available on the direct kernel (stem and split-bf16 kernels only)");
         const long long total = (long long)B * Ho * Wo * mvsgi::cdiv(Cout, 4);
         hipLaunchKernelGGL((conv2d_direct_kernel<4>), dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0, st, a);
         return mvsgi::check_launch("mvsgi_conv2d_f32(direct)");
@@ -348,9 +364,13 @@ extern "C" int mvsgi_conv2d_f32(const float* x, const float* w_oihw, const void*
     a.scale = scale;
     a.shift = shift;
     a.res = res;
-    a.y = y;
+    a.y = ys ? reinterpret_cast<float*>(ys) : y;      // (never dereferenced when y_split is set)
+    a.y_split = ys;
+    a.ys_2d = ys != nullptr;
+    MVSGI_REQUIRE(!ys || v <= D2_S2_N64, "mvsgi_conv2d_f32_out_split2d: split-bf16 kernels only");
     // one volume of B planes while its byte offsets fit 32 bits, else B one-plane frames (64-bit frame bases)
-    const bool planes = (long long)B * Hin * Win * Cin < (1ll << 29) && (long long)B * Ho * Wo * Cout < (1ll << 31);
+    const bool planes = (long long)B * Hin * Win * Cin < (1ll << 29) && (long long)B * Ho * Wo * Cout < (1ll << 31) &&
+                        (!ys || (long long)(B + 2) * (Ho + 4) * (Wo + 4) * 64 < (1ll << 31));
     a.B = planes ? 1 : B;
     a.Cin = Cin;
     a.Din = planes ? B : 1;
@@ -373,6 +393,26 @@ extern "C" int mvsgi_conv2d_f32(const float* x, const float* w_oihw, const void*
         case D2_F32_S2: return launch_mfma<2, 1, 4, 1, 1, 4, 16, 2, 1>(a, st);
     }
     return mvsgi::fail("mvsgi_conv2d_f32: bad variant %d", v);
+}
+}  // namespace
+
+extern "C" int mvsgi_conv2d_f32(const float* x, const float* w_oihw, const void* w_packed, const float* scale,
+                                const float* shift, const float* res, float* y, int B, int Cin, int Hin, int Win,
+                                int Cout, int ksize, int stride, float neg_slope, int impl, int in_nchw,
+                                mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(y, "mvsgi_conv2d_f32: null pointer");
+    return conv2d_run(x, w_oihw, w_packed, scale, shift, res, y, nullptr, B, Cin, Hin, Win, Cout, ksize, stride, neg_slope, impl, in_nchw, stream);
+}
+
+// the same layer with the output in the 2-D split-padded format of resblock2d_rs.hip ([B][Ho+4][Wo+4][64 B], Cout == 16; the caller
+// zeroes the buffer once, only the interior is written): the RGB stem (either input layout) and the split-bf16 3x3 kernels.
+extern "C" int mvsgi_conv2d_f32_out_split2d(const float* x, const float* w_oihw, const void* w_packed, const float* scale,
+                                            const float* shift, const float* res, void* y_split, int B, int Cin, int Hin, int Win,
+                                            int Cout, int ksize, int stride, float neg_slope, int impl, int in_nchw,
+                                            mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(y_split, "mvsgi_conv2d_f32_out_split2d: null pointer");
+    return conv2d_run(x, w_oihw, w_packed, scale, shift, res, nullptr, static_cast<unsigned char*>(y_split), B, Cin, Hin, Win, Cout, ksize,
+                      stride, neg_slope, impl, in_nchw, stream);
 }
 
 // ResConvBlk2d.forward (common/common_modules.py:165-176) for 16 -> 16 channels, 3x3, stride 1, in one launch:

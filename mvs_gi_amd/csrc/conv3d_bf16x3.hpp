@@ -893,6 +893,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
             f32x4 esc[NW], esh[NW], rres[RPRE ? MW : 1][RPRE ? NW : 1];
             int eoff[MW];                  // in-frame element offset of (voxel, cout 4*kg) or -1 outside the volume
             int soff[MW];                  // split-padded output (a.y_split): in-frame byte offset of the voxel's record
+            const int ypd = a.ys_2d ? 0 : 1, ypp = a.ys_2d ? 2 : 1;   // borders of the split-padded output along D and along H / W
             // (requested in every slice, not only the last: loads under a run-time `if` make every later wait of the unit
             // assume they were never issued, i.e. wait for younger weight fragments than needed)
 #pragma unroll
@@ -906,7 +907,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                     const int od = od0 + tdv[i], oh = oh0 + thv[i], ow = ow0 + twv[i];
                     const bool inside = od < a.Do && oh < a.Ho && ow < a.Wo;
                     eoff[i] = inside ? ((od * a.Ho + oh) * a.Wo + ow) * a.Cout + kg * 4 : -1;
-                    soff[i] = ((((od + 1) * (a.Ho + 2) + oh + 1) * (a.Wo + 2) + ow + 1) * a.Cout) * 4 + (kg >> 1) * 16 + (kg & 1) * 8;
+                    soff[i] = ((((od + ypd) * (a.Ho + 2 * ypp) + oh + ypp) * (a.Wo + 2 * ypp) + ow + ypp) * a.Cout) * 4 + (kg >> 1) * 16 + (kg & 1) * 8;
                 }
             }
             if constexpr (PLANE) {
@@ -1039,7 +1040,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                             u32x2 hi, lo;
                             split_bf16x4(r, hi, lo);
                             if (eoff[i] >= 0 && ct0 + j < CT) {
-                                unsigned char* q = a.y_split + (long long)b_ * ((long long)(a.Do + 2) * (a.Ho + 2) * (a.Wo + 2) * a.Cout * 4) +
+                                unsigned char* q = a.y_split + (long long)b_ * ((long long)(a.Do + 2 * ypd) * (a.Ho + 2 * ypp) * (a.Wo + 2 * ypp) * a.Cout * 4) +
                                                    soff[i] + (ct0 + j) * 64;
                                 *reinterpret_cast<u32x2*>(q) = hi;
                                 *reinterpret_cast<u32x2*>(q + 32) = lo;
@@ -1092,7 +1093,7 @@ int launch_bf16x3(ConvArgs a, hipStream_t st) {
     MVSGI_REQUIRE(!UPS || (a.Din % 2 == 0 && a.Hin % 2 == 0 && a.Win % 2 == 0), "conv3d: fused upsample needs even sizes");
     MVSGI_REQUIRE(!UPS || (long long)(a.Hin / 2) * (a.Win / 2) * a.Cin < (1ll << 23), "conv3d: fused upsample: low-resolution plane too large for 24-bit strides");
     MVSGI_REQUIRE((long long)a.Do * a.Ho * a.Wo * a.Cout < (1ll << 31), "conv3d: output frame too large for 32-bit element offsets");
-    MVSGI_REQUIRE(!a.y_split || (!V32 && (long long)(a.Do + 2) * (a.Ho + 2) * (a.Wo + 2) * a.Cout * 4 < (1ll << 31)),
+    MVSGI_REQUIRE(!a.y_split || (!V32 && (long long)(a.Do + 2) * (a.Ho + 4) * (a.Wo + 4) * a.Cout * 4 < (1ll << 31)),
                   "conv3d: split-padded output not available for this kernel / size");
     a.total_units = (int)nb;
 #ifdef MVSGI_STAMPS

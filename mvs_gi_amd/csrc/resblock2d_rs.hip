@@ -1,0 +1,472 @@
+// K5: the feature extractor's residual block on pre-split activations ("register-stationary", as K2e is for the regulator):
+// ResConvBlk2d.forward (dsta_mvs/model/common/common_modules.py:165-176) for 16 -> 16 channels, 3x3, stride 1,
+//   r = LReLU(BN1(conv1(x)));  y = LReLU(BN2(conv2(r)) + x)
+// in ONE launch with r never leaving the CU -- the arithmetic of resblock2d_bf16x3.hpp, another schedule.
+//
+// Why a second schedule.  resblock2d_bf16x3_kernel gives half of its waves to splitting fp32 pixels into hi | lo for LDS and
+// needs 147 KB of LDS (80-byte pixels, two input windows): ONE workgroup per CU, whose four consumer waves run conv1 ->
+// epilogue -> barrier -> conv2 -> epilogue -> barrier back to back with nothing beside them: 35 % matrix-core time, 3.5 TB/s.
+// Here
+//   * activations travel between the blocks ALREADY SPLIT (format below): staging a brick's 18 x 34 input window is a pure
+//     copy and runs on the LDS-DMA path (buffer_load ... lds: no VGPR round trip, no VALU, no producer waves);
+//   * LDS pixels are 32 B in a HI and 32 B in a LO region (the DMA's contiguous KiB pieces), conflict-free for ds_read_b128
+//     because a lane group's two 8-lane halves read DIFFERENT channel halves of the same tap (k = tap-of-pair x 16 + channel:
+//     8 consecutive pixels x 2 chunks cover a 256-byte bank row once, whatever the row pitch);
+//   * one window + one conv1-result image = 81 KB: TWO workgroups of four waves per CU, so one workgroup's epilogues,
+//     barriers and DMA waits run under the other's MFMAs;
+//   * the residual comes from the window in LDS (x = hi + lo, what conv1 multiplied), not from HBM / L2 again;
+//   * the window of brick u + 1 is requested right after conv1 of brick u has released the image and lands under conv2.
+// Both weight sets stay in registers for the whole launch (80 VGPRs).
+//
+// 2-D split-padded activation format:  [N][H + 4][W + 4][64 B], pixel record = [hi(c 0-7) | hi(c 8-15) | lo(c 0-7) | lo(c 8-15)]
+// bf16, x = hi + lo, hi = bf16(x) (RNE), lo = bf16(x - hi) -- the 16-channel slice record of csrc/conv3d_rs.hip -- with a
+// TWO-pixel zero border that is never written: a brick's window (two pixels of halo: two stacked 3x3 convolutions) is a fixed
+// pattern of offsets from the brick's origin, always inside the tensor on the low side; past the tensor's end the buffer
+// range check returns zeros.
+#include "common.hpp"
+#ifdef MVSGI_RS_STAMPS
+#include <cstdio>
+#include <cstdlib>
+#endif
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split4(const f32x4 x, u32x2& hi, u32x2& lo) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const f32x2v v = {x[2 * p], x[2 * p + 1]};
+        const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+        const f32x2v hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        hi[p] = hb;
+        lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, bf16x2));
+    }
+}
+__device__ __forceinline__ f32x4 join4(const u32x2 hi, const u32x2 lo) {
+    f32x4 r;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        r[2 * p] = __builtin_bit_cast(float, hi[p] << 16) + __builtin_bit_cast(float, lo[p] << 16);
+        r[2 * p + 1] = __builtin_bit_cast(float, hi[p] & 0xffff0000u) + __builtin_bit_cast(float, lo[p] & 0xffff0000u);
+    }
+    return r;
+}
+
+// LeakyReLU for slopes in [0, 1] as mul + max (plain asm max: __builtin_fmaxf first canonicalises an MFMA result with a third op)
+__device__ __forceinline__ float lrelu(const float v, const float slope) {
+    const float m = v * slope;
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(m));
+    return r;
+}
+
+namespace rb {
+constexpr int PAD = 2;                        // border of the 2-D split-padded format
+constexpr int TOH = 14, TOW = 30;             // output brick
+constexpr int RH = TOH + 2, RW = TOW + 2;     // conv1 region 16 x 32 = 32 MFMA tiles of 16 pixels
+constexpr int IH = TOH + 4, IW = TOW + 4;     // input window 18 x 34
+constexpr int NPX = IH * IW;                  // 612 pixels
+constexpr int PIECES = (NPX + 31) / 32;       // 20 DMA pieces of 32 pixels x 32 B per region
+constexpr int REGION = PIECES * 1024;         // 20,480: HI region, then the LO region
+constexpr int IMGA = 2 * REGION;              // 40,960: the window
+constexpr int IMGB = REGION + NPX * 32;       // 40,064: the conv1 result (LO region at the same distance)
+constexpr int LDS_BYTES = IMGA + IMGB;        // 81,024: two workgroups per CU
+constexpr int DPW = 2 * PIECES / 4;           // 10 pieces per wave
+static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+static_assert(IMGA + REGION + (3 * IW + 16) * 32 < 65536, "fragment reads address both images with 16-bit immediates");
+}  // namespace rb
+
+// ---------------------------------------------------------------------------------------------
+// format conversion (module boundaries, tests): fp32 [N][H][W][16] <-> 2-D split-padded.  One thread per (pixel, 8 channels).
+// ---------------------------------------------------------------------------------------------
+__global__ void f32_to_split2d_kernel(const float* __restrict__ x, unsigned char* __restrict__ y, int N, int H, int W) {
+    const long long n = (long long)N * H * W * 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int g = (int)(idx & 1);
+    long long v = idx >> 1;
+    const int w = (int)(v % W);
+    v /= W;
+    const int h = (int)(v % H);
+    const int b = (int)(v / H);
+    const float* src = x + (((long long)b * H + h) * W + w) * 16 + g * 8;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+    u32x2 h0, l0, h1, l1;
+    split4(a0, h0, l0);
+    split4(a1, h1, l1);
+    unsigned char* dst = y + (((long long)b * (H + 2 * rb::PAD) + h + rb::PAD) * (W + 2 * rb::PAD) + w + rb::PAD) * 64 + g * 16;
+    *reinterpret_cast<u32x4*>(dst) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+    *reinterpret_cast<u32x4*>(dst + 32) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+}
+
+__global__ void split2d_to_f32_kernel(const unsigned char* __restrict__ x, float* __restrict__ y, int N, int H, int W) {
+    const long long n = (long long)N * H * W * 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int g = (int)(idx & 1);
+    long long v = idx >> 1;
+    const int w = (int)(v % W);
+    v /= W;
+    const int h = (int)(v % H);
+    const int b = (int)(v / H);
+    const unsigned char* src = x + (((long long)b * (H + 2 * rb::PAD) + h + rb::PAD) * (W + 2 * rb::PAD) + w + rb::PAD) * 64 + g * 16;
+    const u32x4 hi = *reinterpret_cast<const u32x4*>(src), lo = *reinterpret_cast<const u32x4*>(src + 32);
+    float* dst = y + (((long long)b * H + h) * W + w) * 16 + g * 8;
+    *reinterpret_cast<f32x4*>(dst) = join4(u32x2{hi[0], hi[1]}, u32x2{lo[0], lo[1]});
+    *reinterpret_cast<f32x4*>(dst + 4) = join4(u32x2{hi[2], hi[3]}, u32x2{lo[2], lo[3]});
+}
+
+// [Cout 16][Cin 16][3][3] x scale[Cout] -> [5 pairs][hi | lo][64 lanes][8 bf16]
+//   lane = (kg << 4) | i holds scale[i] * W[cout = i][cin = (kg & 1) * 8 + j][tap = 2 p + (kg >> 1)]  (tap 9 of pair 4: zeros)
+// The BatchNorm scale is folded into the weights here (fp32 product, then hi | lo) and the shift is the accumulators' initial
+// value: the epilogues have no scale / shift arithmetic left.
+__global__ void rb_pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale, bf16x8* __restrict__ wp) {
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= 5 * 64) return;
+    const int lane = idx & 63, p = idx >> 6;
+    const int kg = lane >> 4, co = lane & 15, ci = (kg & 1) * 8, tap = 2 * p + (kg >> 1);
+    bf16x8 hi, lo;
+    for (int j = 0; j < 8; ++j) {
+        const float v = tap < 9 ? w[(co * 16 + ci + j) * 9 + tap] * scale[co] : 0.f;
+        const __bf16 h = (__bf16)v;
+        hi[j] = h;
+        lo[j] = (__bf16)(v - (float)h);
+    }
+    wp[(p * 2) * 64 + lane] = hi;
+    wp[(p * 2 + 1) * 64 + lane] = lo;
+}
+
+struct RbArgs {
+    const unsigned char* x;    // 2-D split-padded [N][H+4][W+4][64]
+    unsigned char* y;          // the same geometry, or (OUTF32) plain fp32 [N][H][W][16]
+    const bf16x8* wp1;         // rb_pack_weights_kernel (scale folded in)
+    const bf16x8* wp2;
+    const float* shift1;
+    const float* shift2;
+    int N, H, W;
+    int tiles_h, tiles_w, total_units;
+    float neg_slope;
+    unsigned long long* dbg;   // MVSGI_RS_STAMPS diagnostic build only
+};
+
+__device__ __forceinline__ int rb_xcd_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// The epilogues are the kernel's VALU bill (two waves per SIMD share one issue port with the MFMAs), so everything that can
+// be is done elsewhere: scale in the weights, shift as the accumulators' start value, the skip connection as ONE more MFMA per
+// tile (A = [I | I]: hi + lo of the window's centre pixel, read as one 16-byte fragment while the window is still there),
+// stores through a per-brick buffer descriptor with per-launch lane offsets and scalar row offsets, border masks only in bricks that touch the image border.
+template <bool OUTF32>
+__global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
+    using namespace rb;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, kg = lane >> 4;
+    const int Hp = a.H + 2 * PAD, Wp = a.W + 2 * PAD;
+    const long long total_bytes = (long long)a.N * Hp * Wp * 64;
+    const long long out_bytes = OUTF32 ? (long long)a.N * a.H * a.W * 64 : total_bytes;
+    const int orow = (OUTF32 ? a.W : Wp) * 64;                       // bytes per output row
+    const int total = a.total_units, G = gridDim.x;
+    // bricks of this workgroup: logical ids remap(blockIdx) + k * (G / 8) -- XCD x walks a contiguous eighth of the bricks
+    const int nmine = (total - (int)blockIdx.x + G - 1) / G;
+    const int id0 = G == total ? (int)blockIdx.x : rb_xcd_remap((int)blockIdx.x, total);
+    const int idstep = G == total ? 0 : G >> 3;
+
+    // ---- both weight sets, resident ----
+    bf16x8 w1h[5], w1l[5], w2h[5], w2l[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        w1h[p] = a.wp1[(p * 2) * 64 + lane];
+        w1l[p] = a.wp1[(p * 2 + 1) * 64 + lane];
+        w2h[p] = a.wp2[(p * 2) * 64 + lane];
+        w2l[p] = a.wp2[(p * 2 + 1) * 64 + lane];
+    }
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.shift1 + kg * 4), b2 = *reinterpret_cast<const f32x4*>(a.shift2 + kg * 4);
+    // A = [I | I] over k = (hi c 0-15 | lo c 0-15): lane (m, kg) holds k = 8 kg + j, one where (8 kg + j) mod 16 == m
+    bf16x8 ident;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ident[j] = ((kg & 1) * 8 + j == col) ? (__bf16)1.0f : (__bf16)0.0f;
+
+    // ---- fragment read addresses: tile (i, hf) of this wave = region row 4 wave + i, columns 16 hf + col;
+    //      lane (col, kg) reads chunk kg & 1 of the pixel under tap 2 p + (kg >> 1) ----
+    int rbp[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const int tA = 2 * p, tB = 2 * p + 1 < 9 ? 2 * p + 1 : 2 * p;
+        const int t = (kg >> 1) ? tB : tA;
+        rbp[p] = ((4 * wave + t / 3) * IW + col + t % 3) * 32 + (kg & 1) * 16;
+    }
+    // skip connection: window pixel (r + 2, c + 2), 16-byte chunk kg & 1 of the HI (kg < 2) or LO region
+    const int rres = ((4 * wave + 2) * IW + col + 2) * 32 + (kg & 1) * 16 + (kg >> 1) * REGION;
+    // conv1 result -> image B: region pixel (r, c), this lane's channels 4 kg .. 4 kg + 3 (8 bytes of hi, 8 of lo)
+    const int wrb = IMGA + ((4 * wave) * IW + col) * 32 + kg * 8;
+    // ---- DMA plan: piece q = wave + 4 m fills LDS bytes [q * 1024, +1024) of the window: 32 pixels x 2 chunks of one region ----
+    unsigned voff[DPW];
+#pragma unroll
+    for (int m = 0; m < DPW; ++m) {
+        const int q = wave + 4 * m;
+        const int region = q >= PIECES ? 1 : 0, j = q - region * PIECES;
+        const int v = 32 * j + (lane >> 1), chunk = lane & 1;
+        const int wy = v / IW, wx = v - wy * IW;
+        voff[m] = v < NPX ? (unsigned)((wy * Wp + wx) * 64 + region * 32 + chunk * 16) : 0xffffff00u;   // beyond num_records: zeros
+    }
+    // ---- output: lane offsets from the brick's first output pixel, tile row i = + i * orow (scalar) ----
+    //      split: lanes kg and kg ^ 1 trade halves, kg even stores hi / lo of channels 8 (kg >> 1) .. + 7 (16 bytes)
+    unsigned vst[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+        vst[hf] = (unsigned)(4 * wave * orow + (16 * hf + col) * 64 + (OUTF32 ? kg * 16 : (kg & 1) * 32 + (kg >> 1) * 16));
+
+#define RB_DECODE(ID, N_, OH, OW)                                \
+    {                                                            \
+        int t_ = (ID);                                           \
+        OW = (t_ % a.tiles_w) * TOW;                             \
+        t_ /= a.tiles_w;                                         \
+        OH = (t_ % a.tiles_h) * TOH;                             \
+        N_ = t_ / a.tiles_h;                                     \
+    }
+    // window of brick (n, oh0, ow0): origin = padded pixel (oh0, ow0) = image pixel (oh0 - 2, ow0 - 2)
+#define RB_STAGE(N_, OH, OW)                                                                                     \
+    {                                                                                                            \
+        const long long off_ = (((long long)(N_) * Hp + (OH)) * Wp + (OW)) * 64;                                 \
+        const long long left_ = total_bytes - off_;                                                              \
+        const int rec_ = left_ > 0x7fffff00ll ? 0x7fffff00 : (int)left_;                                         \
+        const auto dsc_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.x) + off_, 0, rec_, 0x00020000); \
+        _Pragma("unroll") for (int m = 0; m < DPW; ++m)                                                          \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dsc_, (__attribute__((address_space(3))) void*)(lds + (wave + 4 * m) * 1024), \
+                                                     16, voff[m], 0, 0, 0);                                      \
+    }
+#define RB_READ(IMGOFF, HF, P, BUFI)                                                                             \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+            xh[BUFI][i] = *reinterpret_cast<const bf16x8*>(lds + rbp[P] + ((IMGOFF) + (i * IW + 16 * (HF)) * 32));          \
+            xl[BUFI][i] = *reinterpret_cast<const bf16x8*>(lds + rbp[P] + ((IMGOFF) + REGION + (i * IW + 16 * (HF)) * 32)); \
+        }                                                                                                        \
+    }
+// one convolution = 10 steps (2 column halves x 5 tap pairs) of 4 tiles x 3 products, fragments requested one step ahead
+#define RB_CONV(IMGOFF, WH, WL)                                                                                  \
+    {                                                                                                            \
+        bf16x8 xh[2][4], xl[2][4];                                                                               \
+        RB_READ(IMGOFF, 0, 0, 0)                                                                                 \
+        _Pragma("unroll") for (int st = 0; st < 10; ++st) {                                                      \
+            const int hf = st / 5, p = st % 5;                                                                   \
+            if (st + 1 < 10) RB_READ(IMGOFF, (st + 1) / 5, (st + 1) % 5, (st + 1) & 1)                           \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+                acc[hf][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WL[p], xh[st & 1][i], acc[hf][i], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+                acc[hf][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WH[p], xl[st & 1][i], acc[hf][i], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+                acc[hf][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WH[p], xh[st & 1][i], acc[hf][i], 0, 0, 0); \
+        }                                                                                                        \
+    }
+
+#ifdef MVSGI_RS_STAMPS   // diagnostic build (tools/rb_stamps.py): s_memtime stamps of workgroup 8, every wave
+    int nst = 0;
+#define STAMP()                                                                                     \
+    if (a.dbg && blockIdx.x == 8 && nst < 250) {                                                    \
+        unsigned long long t_;                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        if (lane == 0) a.dbg[wave * 256 + nst] = t_;                                                \
+        nst++;                                                                                      \
+    }
+#else
+#define STAMP()
+#endif
+    int n_, oh0, ow0;
+    RB_DECODE(id0, n_, oh0, ow0)
+    RB_STAGE(n_, oh0, ow0)
+    f32x4 acc[2][4];
+    for (int u = 0; u < nmine; ++u) {
+        int nn, noh, now;                          // the next brick (clamped: its request is skipped past the end)
+        RB_DECODE(id0 + (u + 1 < nmine ? u + 1 : u) * idstep, nn, noh, now)
+        // does the conv1 region (image rows oh0 - 1 .. oh0 + 14, columns ow0 - 1 .. ow0 + 30) leave the image?
+        const bool edge = oh0 == 0 || ow0 == 0 || oh0 + RH - 1 > a.H || ow0 + RW - 1 > a.W;
+        STAMP()
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        STAMP()
+        asm volatile("s_barrier" ::: "memory");   // window of brick u landed (every wave's pieces); conv1-result image free
+        // ---- phase A: conv1 on the 16 x 32 region, result -> image B (zero outside the image: conv2's padding) ----
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[hf][i] = b1;
+        STAMP()
+        RB_CONV(0, w1h, w1l)
+        STAMP()
+        bf16x8 xres[2][4];                         // skip connection: window pixel (r + 2, c + 2) as an MFMA operand
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = acc[hf][i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], a.neg_slope);
+                u32x2 hi, lo;
+                split4(v, hi, lo);
+                if (edge) {
+                    const int gh = oh0 - 1 + 4 * wave + i, gw = ow0 - 1 + 16 * hf + col;
+                    if (!(gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)) hi = lo = u32x2{0u, 0u};
+                }
+                *reinterpret_cast<u32x2*>(lds + wrb + (i * IW + 16 * hf) * 32) = hi;
+                *reinterpret_cast<u32x2*>(lds + wrb + (i * IW + 16 * hf) * 32 + REGION) = lo;
+                xres[hf][i] = *reinterpret_cast<const bf16x8*>(lds + rres + (i * IW + 16 * hf) * 32);
+            }
+        STAMP()
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // conv1 result complete; every wave is done with the window
+        if (u + 1 < nmine) RB_STAGE(nn, noh, now)  // lands under conv2
+        // ---- phase B: conv2 on the 14 x 30 brick (tile rows 14, 15 and columns 30, 31 are not stored) ----
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[hf][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ident, xres[hf][i], b2, 0, 0, 0);
+        STAMP()
+        RB_CONV(IMGA, w2h, w2l)
+        STAMP()
+        {
+            // output descriptor: base = the brick's first output pixel; lanes of columns >= 30 (or beyond the image) are masked
+            // (an out-of-range voffset is no substitute: the scalar row offset is added before the range check and wraps),
+            // rows >= 14 (or beyond the image) are skipped (wave-uniform)
+            const long long off_ = OUTF32 ? (((long long)n_ * a.H + oh0) * a.W + ow0) * 64
+                                          : (((long long)n_ * Hp + oh0 + PAD) * Wp + ow0 + PAD) * 64;
+            const long long left_ = out_bytes - off_;
+            const int rec_ = left_ > 0x7fffff00ll ? 0x7fffff00 : (int)left_;
+            const auto dsc_ = __builtin_amdgcn_make_buffer_rsrc(a.y + off_, 0, rec_, 0x00020000);
+            bool okc[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) okc[hf] = 16 * hf + col < TOW && ow0 + 16 * hf + col < a.W;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * wave + i;
+                    f32x4 v = acc[hf][i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], a.neg_slope);
+                    u32x4 o;
+                    if constexpr (OUTF32) {
+                        o = __builtin_bit_cast(u32x4, v);
+                    } else {
+                        u32x2 hi, lo;
+                        split4(v, hi, lo);
+                        const u32x2 sa = __builtin_amdgcn_permlane16_swap(hi[0], lo[0], false, false);
+                        const u32x2 sb = __builtin_amdgcn_permlane16_swap(hi[1], lo[1], false, false);
+                        o = u32x4{sa[0], sb[0], sa[1], sb[1]};
+                    }
+                    if (okc[hf] && r < TOH && oh0 + r < a.H) __builtin_amdgcn_raw_buffer_store_b128(o, dsc_, vst[hf], i * orow, 0);
+                }
+        }
+        n_ = nn; oh0 = noh; ow0 = now;
+    }
+#undef RB_DECODE
+#undef RB_STAGE
+#undef RB_READ
+#undef RB_CONV
+}
+
+template <bool OUTF32>
+int rb_launch(const RbArgs& a, hipStream_t st, const char* what) {
+    static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
+    mvsgi::PersistentGeom geo;
+    if (mvsgi::persistent_geometry(resblock2d_rs_kernel<OUTF32>, 256, rb::LDS_BYTES, 2, geo_cache, what, geo)) return 1;
+    long long resident = ((long long)geo.cus * geo.wgs_per_cu) / 8 * 8;
+    if (resident < 8) resident = 8;
+    const long long nb = a.total_units;
+#ifdef MVSGI_RS_STAMPS
+    RbArgs a2 = a;
+    {   // MVSGI_STAMP=1: record; =2: print the stamps of the previous launch
+        static unsigned long long* dbgbuf = nullptr;
+        const char* e_ = getenv("MVSGI_STAMP");
+        if (e_ && !dbgbuf) { (void)hipMalloc(&dbgbuf, 4 * 256 * 8); (void)hipMemset(dbgbuf, 0, 4 * 256 * 8); }
+        a2.dbg = e_ ? dbgbuf : nullptr;
+        if (e_ && atoi(e_) == 2 && dbgbuf) {
+            static unsigned long long h[4 * 256];
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(h, dbgbuf, sizeof(h), hipMemcpyDeviceToHost);
+            for (int w = 0; w < 4; ++w) {
+                fprintf(stderr, "rbwave %d:", w);
+                for (int i = 0; i < 250; ++i) fprintf(stderr, " %lld", (long long)(h[w * 256 + i] - h[0]));
+                fprintf(stderr, "\n");
+            }
+        }
+    }
+    hipLaunchKernelGGL(resblock2d_rs_kernel<OUTF32>, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), rb::LDS_BYTES, st, a2);
+#else
+    hipLaunchKernelGGL(resblock2d_rs_kernel<OUTF32>, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), rb::LDS_BYTES, st, a);
+#endif
+    return mvsgi::check_launch(what);
+}
+
+}  // namespace
+
+extern "C" size_t mvsgi_split2d_bytes(int N, int H, int W) {
+    return (size_t)N * (size_t)(H + 2 * rb::PAD) * (size_t)(W + 2 * rb::PAD) * 64;
+}
+
+// fp32 [N][H][W][16] -> 2-D split-padded (interior only: the caller zeroes the buffer once, the border is never written)
+extern "C" int mvsgi_f32_to_split2d(const float* x, void* y_split, int N, int H, int W, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(x && y_split, "mvsgi_f32_to_split2d: null pointer");
+    MVSGI_REQUIRE(N > 0 && H > 0 && W > 0, "mvsgi_f32_to_split2d: non-positive dimension");
+    const long long n = (long long)N * H * W * 2;
+    MVSGI_REQUIRE(mvsgi::cdiv(n, 256) < (1ll << 31), "mvsgi_f32_to_split2d: tensor too large");
+    hipLaunchKernelGGL(f32_to_split2d_kernel, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, mvsgi::as_stream(stream), x,
+                       static_cast<unsigned char*>(y_split), N, H, W);
+    return mvsgi::check_launch("mvsgi_f32_to_split2d");
+}
+
+extern "C" int mvsgi_split2d_to_f32(const void* x_split, float* y, int N, int H, int W, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(x_split && y, "mvsgi_split2d_to_f32: null pointer");
+    MVSGI_REQUIRE(N > 0 && H > 0 && W > 0, "mvsgi_split2d_to_f32: non-positive dimension");
+    const long long n = (long long)N * H * W * 2;
+    MVSGI_REQUIRE(mvsgi::cdiv(n, 256) < (1ll << 31), "mvsgi_split2d_to_f32: tensor too large");
+    hipLaunchKernelGGL(split2d_to_f32_kernel, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, mvsgi::as_stream(stream),
+                       static_cast<const unsigned char*>(x_split), y, N, H, W);
+    return mvsgi::check_launch("mvsgi_split2d_to_f32");
+}
+
+extern "C" size_t mvsgi_resblock2d_split_packed_weight_bytes(void) { return (size_t)5 * 2 * 64 * 16; }
+
+extern "C" int mvsgi_resblock2d_split_pack_weights(const float* w_oihw, const float* scale, void* w_packed, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(w_oihw && scale && w_packed, "mvsgi_resblock2d_split_pack_weights: null pointer");
+    hipLaunchKernelGGL(rb_pack_weights_kernel, dim3(5), dim3(64), 0, mvsgi::as_stream(stream), w_oihw, scale, static_cast<bf16x8*>(w_packed));
+    return mvsgi::check_launch("mvsgi_resblock2d_split_pack_weights");
+}
+
+// ResConvBlk2d.forward (common/common_modules.py:165-176), 16 -> 16 channels, 3x3, stride 1, on 2-D split-padded activations:
+//   y = act( conv2(act(conv1(x) * scale1 + shift1)) * scale2 + shift2 + x )
+// (scale1 / scale2 are folded into w_packed1 / w_packed2 by mvsgi_resblock2d_split_pack_weights.)
+// x_split [N][H+4][W+4][64 B]; y the same format (y_is_split, border untouched) or plain fp32 [N][H][W][16].
+extern "C" int mvsgi_resblock2d_split(const void* x_split, const void* w_packed1, const float* shift1,
+                                      const void* w_packed2, const float* shift2, void* y, int y_is_split,
+                                      int N, int H, int W, float neg_slope, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(x_split && w_packed1 && w_packed2 && shift1 && shift2 && y, "mvsgi_resblock2d_split: null pointer");
+    MVSGI_REQUIRE(N > 0 && H > 0 && W > 0, "mvsgi_resblock2d_split: non-positive dimension");
+    MVSGI_REQUIRE(neg_slope >= 0.f && neg_slope <= 1.f, "mvsgi_resblock2d_split: negative slope %g outside [0, 1]", (double)neg_slope);
+    MVSGI_REQUIRE((long long)(rb::IH + 1) * (W + 2 * rb::PAD) * 64 < 0x7fffff00ll, "mvsgi_resblock2d_split: rows too long for 32-bit window offsets");
+    MVSGI_REQUIRE(y_is_split || ((reinterpret_cast<uintptr_t>(y) & 15) == 0), "mvsgi_resblock2d_split: fp32 output must be 16-byte aligned");
+    MVSGI_REQUIRE(x_split != y, "mvsgi_resblock2d_split: in-place operation is not supported (bricks read their neighbours' inputs)");
+    RbArgs a{};
+    a.x = static_cast<const unsigned char*>(x_split);
+    a.y = static_cast<unsigned char*>(y);
+    a.wp1 = static_cast<const bf16x8*>(w_packed1);
+    a.wp2 = static_cast<const bf16x8*>(w_packed2);
+    a.shift1 = shift1; a.shift2 = shift2;
+    a.N = N; a.H = H; a.W = W; a.neg_slope = neg_slope;
+    a.tiles_h = (int)mvsgi::cdiv(H, rb::TOH);
+    a.tiles_w = (int)mvsgi::cdiv(W, rb::TOW);
+    const long long nb = (long long)N * a.tiles_h * a.tiles_w;
+    MVSGI_REQUIRE(nb < (1ll << 31), "mvsgi_resblock2d_split: too many bricks");
+    a.total_units = (int)nb;
+    hipStream_t st = mvsgi::as_stream(stream);
+    return y_is_split ? rb_launch<false>(a, st, "mvsgi_resblock2d_split") : rb_launch<true>(a, st, "mvsgi_resblock2d_split(fp32 out)");
+}

@@ -21,13 +21,14 @@ from . import common_modules as cm
 from .common_modules import module_getstate, NoOp, NORM2D_TYPE, RELU_TYPE, _is_identity
 
 
+_SPLIT_CHAIN = os.environ.get("MVSGI_EXTRACTOR_SPLIT", "1") != "0"  # 0: the round-2 chain (fp32 activations between all layers)
 _STEM_MFMA = os.environ.get("MVSGI_STEM_MFMA", "1") != "0"      # 0: the LDS-tiled VALU stem for uint8 images too
 
 
 class Conv2dLaunch:
-    __slots__ = ("w", "wp_b3", "wp_f32", "wp_stem", "scale", "shift", "stride", "neg_slope", "k", "cin", "cout", "key")
+    __slots__ = ("w", "wp_b3", "wp_f32", "wp_stem", "wp_rs", "scale", "shift", "stride", "neg_slope", "k", "cin", "cout", "key")
 
-    def run(self, x: Tensor, res: Optional[Tensor] = None, in_nchw: bool = False) -> Tensor:
+    def run(self, x: Tensor, res: Optional[Tensor] = None, in_nchw: bool = False, out_split: Optional[Tensor] = None) -> Tensor:
         impl, wp = H.CONV_AUTO, None
         if H.get_conv_mode() == "bf16x3" and self.k == 3 and self.cin % 16 == 0 and self.cout % 16 == 0 and not in_nchw:
             if self.wp_b3 is None:
@@ -42,7 +43,12 @@ class Conv2dLaunch:
                 self.wp_stem = H.pack_conv2d_stem_weights(self.w)
             wp = self.wp_stem
         return H.conv2d(x, self.w, wp, self.scale, self.shift, res=res, stride=self.stride,
-                        neg_slope=self.neg_slope, impl=impl, in_nchw=in_nchw)
+                        neg_slope=self.neg_slope, impl=impl, in_nchw=in_nchw, out_split=out_split)
+
+    def rs_weights(self) -> Tensor:
+        if self.wp_rs is None:
+            self.wp_rs = H.pack_resblock2d_split_weights(self.w, self.scale)
+        return self.wp_rs
 
 
 def lower_conv2d_block(blk) -> Conv2dLaunch:
@@ -89,7 +95,7 @@ def lower_conv2d_block(blk) -> Conv2dLaunch:
     else:
         raise NotImplementedError(f"activation {type(act).__name__} has no HIP implementation")
     L = Conv2dLaunch()
-    L.w, L.wp_b3, L.wp_f32, L.wp_stem = w, None, None, None
+    L.w, L.wp_b3, L.wp_f32, L.wp_stem, L.wp_rs = w, None, None, None, None
     L.scale, L.shift = scale.contiguous(), shift.contiguous()
     L.stride, L.neg_slope, L.k = int(conv.stride[0]), slope, int(k)
     L.cin, L.cout, L.key = int(w.shape[1]), int(cout), key
@@ -188,10 +194,76 @@ class ResConvBlk2d(nn.Module):
         return size[0] + 2 * self.out_pad, size[1] + 2 * self.out_pad
 
 
+def _fusable_resblock(blk) -> bool:
+    if not hasattr(blk, "blk1") or not _is_identity(blk.one_by_one) or getattr(blk, "out_pad", 0) != 0:
+        return False
+    L1, L2 = lower_conv2d_block(blk.blk1), lower_conv2d_block(blk.blk2)
+    return L1.k == 3 and L2.k == 3 and L1.stride == 1 and L2.stride == 1 and \
+        (L1.cin, L1.cout, L2.cin, L2.cout) == (16, 16, 16, 16) and L1.neg_slope == L2.neg_slope and 0.0 <= L1.neg_slope <= 1.0
+
+
+def _split2d_pair(self, N: int, Hh: int, W: int, device):
+    """Two zero-bordered 2-D split-padded buffers per resolution, owned by the module: the kernels write interiors only, so the
+    borders stay zero from one forward to the next."""
+    cache = self.__dict__.setdefault("_mvsgi_split2d", {})
+    key = (N, Hh, W, str(device))
+    if key not in cache:
+        if len(cache) >= 4:
+            cache.clear()
+        cache[key] = (H.split2d_buffer(N, Hh, W, device), H.split2d_buffer(N, Hh, W, device))
+    return cache[key]
+
+
+def _split_chain_forward(self, xin: Tensor, with_final: bool = True) -> Optional[Tensor]:
+    """The extractor with its residual blocks on pre-split activations (csrc/resblock2d_rs.hip): the layer in front of a run of
+    residual blocks writes the 2-D split-padded format, the blocks hand it on, the last block of a run writes fp32 for the
+    layer behind it.  None when this mode / recipe has no such run."""
+    if not (_SPLIT_CHAIN and H.get_conv_mode() == "bf16x3"):
+        return None
+    layers = [self.first] + list(self.blks) + ([self.final_layer] if with_final else [])
+    fus = [hasattr(m, "blk1") and _fusable_resblock(m) for m in layers]
+    y, nchw, idx = xin, True, 0
+    while idx < len(layers):
+        m = layers[idx]
+        if hasattr(m, "blk1"):                       # a residual block with no split-writing layer in front of it
+            y = res_block2d_nhwc(m, y)
+            idx += 1
+            continue
+        L = lower_conv2d_block(m)
+        j = idx + 1
+        while j < len(layers) and fus[j]:
+            j += 1
+        if nchw:
+            N, Hin, Win = (y.shape[0], y.shape[1], y.shape[2]) if y.dtype == torch.uint8 else (y.shape[0], y.shape[2], y.shape[3])
+            can = (L.k, L.stride, L.cin, L.cout) == (5, 2, 3, 16) and N < 65536
+        else:
+            N, Hin, Win = y.shape[0], y.shape[1], y.shape[2]
+            can = L.k == 3 and L.cin % 16 == 0 and L.cout == 16
+        if j > idx + 1 and can:
+            Ho, Wo = _calc((Hin, Win), L.k, L.stride, L.k // 2)
+            cur, other = _split2d_pair(self, N, Ho, Wo, y.device)
+            cur = L.run(y, in_nchw=nchw, out_split=cur)
+            for t in range(idx + 1, j):
+                L1, L2 = lower_conv2d_block(layers[t].blk1), lower_conv2d_block(layers[t].blk2)
+                last = t == j - 1
+                out = H.resblock2d_split(cur, L1.rs_weights(), L1.shift, L2.rs_weights(), L2.shift, L1.neg_slope,
+                                         out_split=None if last else other)
+                cur, other = out, cur
+            y, idx = cur, j
+        else:
+            y = L.run(y, in_nchw=nchw)
+            idx += 1
+        nchw = False
+    return y                                         # channels-last fp32
+
+
 def extractor_forward(self, x: Tensor) -> Tensor:
     """simple_feature_extractor.py:81-84.  The RGB stem reads the caller's NCHW fp32 images directly, or
     uint8 [M, H, W, 3] camera images (converted /255 in the kernel, api/inference_class.py:104-107)."""
     xin = x if x.dtype == torch.uint8 else H._dev(x, "imgs")
+    out = _split_chain_forward(self, xin)
+    if out is not None:
+        return _nchw_view(out)
     y = lower_conv2d_block(self.first).run(xin, in_nchw=True)
     for blk in self.blks:
         if hasattr(blk, "blk1"):
@@ -202,6 +274,8 @@ def extractor_forward(self, x: Tensor) -> Tensor:
 
 
 class SimpleFeatExtraction(nn.Module):
+    __getstate__ = module_getstate
+
     def __init__(self, in_size: Tuple[int, int], in_chs=3, chs: int = 8, k_sz: int = 3,
                  layers: Sequence[int] = [5, 10], norm_type: str = "batch", relu_type: str = "leaky"):
         super().__init__()
@@ -394,16 +468,20 @@ class SphereConvBlk(nn.Module):
 def sphere_extractor_forward(self, x: Tensor) -> Tensor:
     """SphereEquirectFeatExtraction.forward (feature_extractor/sphere_feature_extractor.py:80-83)."""
     xin = x if x.dtype == torch.uint8 else H._dev(x, "imgs")
-    y = lower_conv2d_block(self.first).run(xin, in_nchw=True)
-    for blk in self.blks:
-        if hasattr(blk, "blk1"):
-            y = res_block2d_nhwc(blk, y)
-        else:
-            y = lower_conv2d_block(blk).run(y)
+    y = _split_chain_forward(self, xin, with_final=False)
+    if y is None:
+        y = lower_conv2d_block(self.first).run(xin, in_nchw=True)
+        for blk in self.blks:
+            if hasattr(blk, "blk1"):
+                y = res_block2d_nhwc(blk, y)
+            else:
+                y = lower_conv2d_block(blk).run(y)
     return _nchw_view(sphere_blk_nhwc(self.final_layer, y))
 
 
 class SphereEquirectFeatExtraction(nn.Module):
+    __getstate__ = module_getstate
+
     """feature_extractor/sphere_feature_extractor.py:8-83: SimpleFeatExtraction whose final layer is a SphereConvBlk."""
 
     def __init__(self, in_size: Tuple[int, int], in_chs=3, chs: int = 8, k_sz: int = 3,

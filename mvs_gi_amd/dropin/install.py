@@ -114,14 +114,14 @@ def _patch_reference():
     rebind(c.BaseConvBlk3d, forward=_cm.BaseConvBlk3d.forward, __getstate__=gs)
     rebind(c.ResConvBlk3d, forward=_cm.ResConvBlk3d.forward)
     rebind(c.ResizeConv3d, forward=_cm.ResizeConv3d.forward)
-    rebind(c.BaseConvBlk2d, forward=_fe.BaseConvBlk2d.forward)
-    rebind(c.ResConvBlk2d, forward=_fe.ResConvBlk2d.forward)
+    rebind(c.BaseConvBlk2d, forward=_fe.BaseConvBlk2d.forward, __getstate__=gs)
+    rebind(c.ResConvBlk2d, forward=_fe.ResConvBlk2d.forward, __getstate__=gs)
     f = importlib.import_module("dsta_mvs.model.feature_extractor.simple_feature_extractor")
-    rebind(f.SimpleFeatExtraction, forward=_fe.extractor_forward)
+    rebind(f.SimpleFeatExtraction, forward=_fe.extractor_forward, __getstate__=gs)
     rebind(c.SphereConvEquirect2d, forward=_fe.SphereConvEquirect2d.forward)
     rebind(c.SphereConvBlk, forward=_fe.SphereConvBlk.forward)
     fs = importlib.import_module("dsta_mvs.model.feature_extractor.sphere_feature_extractor")
-    rebind(fs.SphereEquirectFeatExtraction, forward=_fe.sphere_extractor_forward)
+    rebind(fs.SphereEquirectFeatExtraction, forward=_fe.sphere_extractor_forward, __getstate__=gs)
     _state["saved"] = saved
 
 

@@ -576,8 +576,9 @@ def pack_conv2d_weights_f32(w_oihw: torch.Tensor) -> Optional[torch.Tensor]:
     return wp
 
 
-def conv2d(x, w_oihw, w_packed, scale, shift, res=None, stride=1, neg_slope=0.01, impl=CONV_AUTO, in_nchw=False):
-    """x [B, H, W, Cin] (or [B, Cin, H, W] with in_nchw) -> y [B, Ho, Wo, Cout] = act(conv(x)*scale + shift (+res))."""
+def conv2d(x, w_oihw, w_packed, scale, shift, res=None, stride=1, neg_slope=0.01, impl=CONV_AUTO, in_nchw=False, out_split=None):
+    """x [B, H, W, Cin] (or [B, Cin, H, W] with in_nchw) -> y [B, Ho, Wo, Cout] = act(conv(x)*scale + shift (+res)).
+    out_split: a zero-bordered 2-D split-padded buffer (split2d_buffer) that receives the output instead (Cout == 16)."""
     lib = _lib.load()
     layout = int(bool(in_nchw))
     if x.dtype == torch.uint8:                 # camera images [B, H, W, 3]: converted (/255) inside the stem kernel
@@ -597,6 +598,12 @@ def conv2d(x, w_oihw, w_packed, scale, shift, res=None, stride=1, neg_slope=0.01
         res = _dev(res, "res")
         if tuple(res.shape) != (B, Ho, Wo, Cout):
             raise AssertionError(f"residual {tuple(res.shape)} does not match output {(B, Ho, Wo, Cout)}")
+    if out_split is not None:
+        _check_split2d(out_split, B, Ho, Wo, x.device)
+        _lib.check(lib.mvsgi_conv2d_f32_out_split2d(x.data_ptr(), _ptr(w_oihw), _ptr(w_packed), scale.data_ptr(), shift.data_ptr(),
+                                                    _ptr(res), out_split.data_ptr(), B, Cin, Hin, Win, Cout, k, stride,
+                                                    float(neg_slope), impl, layout, _stream_ptr(x)), "mvsgi_conv2d_f32_out_split2d")
+        return out_split
     y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
     _lib.check(lib.mvsgi_conv2d_f32(x.data_ptr(), _ptr(w_oihw), _ptr(w_packed), scale.data_ptr(), shift.data_ptr(),
                                     _ptr(res), y.data_ptr(), B, Cin, Hin, Win, Cout, k, stride, float(neg_slope), impl,
@@ -710,6 +717,74 @@ def deform_conv2d(x_nhwc, offset, w_packed, scale, shift, kernel_size, stride=(1
                                            y.data_ptr(), N, Cin, Hh, W, Cout, Kh, Kw, stride[0], stride[1], padding[0],
                                            padding[1], dilation[0], dilation[1], float(neg_slope), _stream_ptr(x)),
                "mvsgi_deform_conv2d_f32")
+    return y
+
+
+# ---- the extractor's residual blocks on pre-split activations (csrc/resblock2d_rs.hip) ----
+def split2d_buffer(N: int, H: int, W: int, device) -> torch.Tensor:
+    """A zeroed 2-D split-padded activation buffer [N, H + 4, W + 4, 64] uint8 (the kernels write the interior only: the
+    two-pixel zero border is the convolutions' padding and stays as allocated)."""
+    return torch.zeros((N, H + 4, W + 4, 64), device=device, dtype=torch.uint8)
+
+
+def _check_split2d(t: torch.Tensor, N: int, H: int, W: int, device) -> None:
+    if t.dtype != torch.uint8 or tuple(t.shape) != (N, H + 4, W + 4, 64) or not t.is_contiguous() or t.device != device:
+        raise AssertionError(f"split-padded 2-D buffer {tuple(t.shape)} {t.dtype} {t.device} does not match {(N, H + 4, W + 4, 64)} uint8 on {device}")
+
+
+def f32_to_split2d(x_nhwc: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    x = _dev(x_nhwc, "x")
+    N, Hh, W, C = x.shape
+    if C != 16:
+        raise AssertionError(f"the 2-D split-padded format holds 16 channels, got {tuple(x.shape)}")
+    if out is None:
+        out = split2d_buffer(N, Hh, W, x.device)
+    _check_split2d(out, N, Hh, W, x.device)
+    _lib.check(lib.mvsgi_f32_to_split2d(x.data_ptr(), out.data_ptr(), N, Hh, W, _stream_ptr(x)), "mvsgi_f32_to_split2d")
+    return out
+
+
+def split2d_to_f32(x_split: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    N, Hp, Wp, _ = x_split.shape
+    _check_split2d(x_split, N, Hp - 4, Wp - 4, x_split.device)
+    y = torch.empty((N, Hp - 4, Wp - 4, 16), device=x_split.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_split2d_to_f32(x_split.data_ptr(), y.data_ptr(), N, Hp - 4, Wp - 4, _stream_ptr(x_split)), "mvsgi_split2d_to_f32")
+    return y
+
+
+def pack_resblock2d_split_weights(w_oihw: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """Lane-ordered split-bf16 weights of one conv of the block with the BatchNorm scale folded in."""
+    lib = _lib.load()
+    w = _dev(w_oihw, "w")
+    scale = _dev(scale, "scale")
+    if tuple(w.shape) != (16, 16, 3, 3) or scale.numel() != 16:
+        raise AssertionError(f"resblock2d_split is the 16 -> 16 channel 3x3 block, got weights {tuple(w.shape)}")
+    wp = torch.empty(lib.mvsgi_resblock2d_split_packed_weight_bytes(), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.mvsgi_resblock2d_split_pack_weights(w.data_ptr(), scale.data_ptr(), wp.data_ptr(), _stream_ptr(w)),
+               "mvsgi_resblock2d_split_pack_weights")
+    return wp
+
+
+def resblock2d_split(x_split, wp1, shift1, wp2, shift2, neg_slope=0.01, out_split=None) -> torch.Tensor:
+    """Fused 16 -> 16 residual block on a 2-D split-padded input [N, H + 4, W + 4, 64] uint8 (wp1 / wp2 carry the scales).
+    out_split: the split-padded buffer that receives the output (returned); None: the output is a plain fp32 [N, H, W, 16]
+    tensor."""
+    lib = _lib.load()
+    N, Hp, Wp, _ = x_split.shape
+    Hh, W = Hp - 4, Wp - 4
+    _check_split2d(x_split, N, Hh, W, x_split.device)
+    if shift1.numel() != 16 or shift2.numel() != 16:
+        raise AssertionError("resblock2d_split is the 16-channel block")
+    if out_split is not None:
+        _check_split2d(out_split, N, Hh, W, x_split.device)
+        y = out_split
+    else:
+        y = torch.empty((N, Hh, W, 16), device=x_split.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_resblock2d_split(x_split.data_ptr(), wp1.data_ptr(), shift1.data_ptr(), wp2.data_ptr(), shift2.data_ptr(),
+                                          y.data_ptr(), int(out_split is not None), N, Hh, W, float(neg_slope),
+                                          _stream_ptr(x_split)), "mvsgi_resblock2d_split")
     return y
 
 

@@ -938,6 +938,101 @@ def test_fused_resblock2d_vs_two_convs(shape):
     assert _rel(y.permute(0, 2, 3, 1).cpu().numpy(), two.cpu().numpy()) <= 2e-5
 
 
+# ------------------------------------------------- the residual block on pre-split activations (csrc/resblock2d_rs.hip)
+def _resblk_params(rng):
+    p = {}
+    for name in ("blk1", "blk2"):
+        p[f"{name}.conv_layer.weight"] = (rng.standard_normal((16, 16, 3, 3)) / 12).astype(np.float32)
+        p[f"{name}.norm_layer.weight"] = rng.uniform(0.5, 1.5, 16).astype(np.float32)
+        p[f"{name}.norm_layer.bias"] = rng.normal(0, 0.3, 16).astype(np.float32)
+        p[f"{name}.norm_layer.running_mean"] = rng.normal(0, 0.1, 16).astype(np.float32)
+        p[f"{name}.norm_layer.running_var"] = rng.uniform(0.5, 1.5, 16).astype(np.float32)
+    return p
+
+
+def test_split2d_format_round_trip_and_border():
+    rng = np.random.default_rng(5)
+    x = _g(rng.standard_normal((3, 5, 7, 16), dtype=np.float32) * 10)
+    s = H.f32_to_split2d(x)
+    assert tuple(s.shape) == (3, 9, 11, 64) and s.dtype == torch.uint8
+    back = H.split2d_to_f32(s)
+    assert float(((back - x).abs() / x.abs().clamp_min(1e-30)).max()) <= 2.0 ** -16      # hi + lo keeps 16-17 significant bits
+    border = s.clone()
+    border[:, 2:-2, 2:-2] = 0
+    assert int(border.count_nonzero()) == 0
+
+
+@pytest.mark.parametrize("shape", [(2, 30, 45), (1, 14, 30), (3, 64, 256), (1, 9, 100), (5, 29, 15), (1, 1, 1), (2, 15, 31), (9, 44, 91), (3, 200, 500)])
+def test_resblock2d_split_vs_oracle(shape):
+    """mvsgi_resblock2d_split (ResConvBlk2d in one launch on 2-D split-padded activations, LDS-DMA staging, skip from LDS) vs
+    the oracle's two conv blocks: images smaller / larger than a 14x30 brick, ragged edges, more bricks than resident
+    workgroups (3 x 200 x 500: a persistent walk of several bricks per workgroup); both output formats; the output buffer's zero border stays zero."""
+    N, Hh, W = shape
+    rng = np.random.default_rng(sum(shape) + 1)
+    p = _resblk_params(rng)
+    x = rng.standard_normal((N, 16, Hh, W)).astype(np.float32)
+    pt = {k_: torch.from_numpy(v) for k_, v in p.items()}
+    xt = torch.from_numpy(x)
+    ref = O.conv_block2d(O.conv_block2d(xt, pt, "blk1"), pt, "blk2", res=xt).permute(0, 2, 3, 1).numpy()
+    from mvs_gi_amd.dropin import feature_extractor as FE
+    blk = dropin.ResConvBlk2d(16, 16, 3, activation=torch.nn.LeakyReLU(), norm_layer=torch.nn.BatchNorm2d(16))
+    blk.load_state_dict(pt, strict=False)
+    blk = blk.eval().to(DEV)
+    L1, L2 = FE.lower_conv2d_block(blk.blk1), FE.lower_conv2d_block(blk.blk2)
+    w1, w2 = L1.rs_weights(), L2.rs_weights()
+    xs = H.f32_to_split2d(_g(x).permute(0, 2, 3, 1).contiguous())
+    y32 = H.resblock2d_split(xs, w1, L1.shift, w2, L2.shift, L1.neg_slope)
+    out = H.split2d_buffer(N, Hh, W, xs.device)
+    ys = H.resblock2d_split(xs, w1, L1.shift, w2, L2.shift, L1.neg_slope, out_split=out)
+    assert _rel(y32.cpu().numpy(), ref) <= 1e-4
+    assert _rel(H.split2d_to_f32(ys).cpu().numpy(), ref) <= 1e-4
+    border = ys.clone()
+    border[:, 2:-2, 2:-2] = 0
+    assert int(border.count_nonzero()) == 0
+    # a chain of two blocks through the split format = the same two blocks through fp32
+    y2 = H.resblock2d_split(ys, w1, L1.shift, w2, L2.shift, L1.neg_slope)
+    reft = torch.from_numpy(ref).permute(0, 3, 1, 2)
+    ref2 = O.conv_block2d(O.conv_block2d(reft, pt, "blk1"), pt, "blk2", res=reft).permute(0, 2, 3, 1).numpy()
+    assert _rel(y2.cpu().numpy(), ref2) <= 2e-4
+
+
+def test_conv2d_out_split2d_matches_fp32_output():
+    """The stem (fp32 NCHW and uint8 HWC images) and the stride-2 / stride-1 3x3 layers writing the 2-D split-padded format:
+    the same values as their fp32 outputs, split (hi + lo: 16-17 bits)."""
+    rng = np.random.default_rng(11)
+    from mvs_gi_amd.dropin import feature_extractor as FE
+    stem = dropin.BaseConvBlk2d(3, 16, 5, stride=2, activation=torch.nn.LeakyReLU(), norm_layer=torch.nn.BatchNorm2d(16)).eval().to(DEV)
+    mid = dropin.BaseConvBlk2d(16, 16, 3, stride=2, activation=torch.nn.LeakyReLU(), norm_layer=torch.nn.BatchNorm2d(16)).eval().to(DEV)
+    one = dropin.BaseConvBlk2d(16, 16, 3, stride=1, activation=torch.nn.LeakyReLU(), norm_layer=torch.nn.BatchNorm2d(16)).eval().to(DEV)
+    with torch.no_grad():
+        for m in (stem, mid, one):
+            m.norm_layer.running_mean.normal_(0, 0.1)
+            m.norm_layer.running_var.uniform_(0.5, 1.5)
+            m.norm_layer.bias.normal_(0, 0.3)
+    old_mode = H.get_conv_mode()
+    try:
+        H.set_conv_mode("bf16x3")
+        for imgs, nchw in ((_g(rng.random((2, 3, 36, 52), dtype=np.float32)), True),
+                           (torch.from_numpy(rng.integers(0, 256, (2, 36, 52, 3), dtype=np.uint8)).to(DEV), True)):
+            L = FE.lower_conv2d_block(stem)
+            y = L.run(imgs, in_nchw=nchw)
+            ys = L.run(imgs, in_nchw=nchw, out_split=H.split2d_buffer(2, 18, 26, imgs.device))
+            back = H.split2d_to_f32(ys)
+            assert float(((back - y).abs() / y.abs().clamp_min(1e-20)).max()) <= 2.0 ** -15
+        x = _g(rng.standard_normal((3, 37, 53, 16), dtype=np.float32))
+        for m, (ho, wo) in ((mid, (19, 27)), (one, (37, 53))):
+            L = FE.lower_conv2d_block(m)
+            y = L.run(x)
+            ys = L.run(x, out_split=H.split2d_buffer(3, ho, wo, x.device))
+            back = H.split2d_to_f32(ys)
+            assert float(((back - y).abs() / y.abs().clamp_min(1e-20)).max()) <= 2.0 ** -15
+            border = ys.clone()
+            border[:, 2:-2, 2:-2] = 0
+            assert int(border.count_nonzero()) == 0
+    finally:
+        H.set_conv_mode(old_mode)
+
+
 # ------------------------------------------------------------------------------ register-stationary conv (csrc/conv3d_rs.hip)
 def test_split_padded_format_round_trip_and_border():
     rng = np.random.default_rng(3)
