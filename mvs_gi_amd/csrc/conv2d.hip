@@ -233,12 +233,22 @@ __global__ __launch_bounds__(256) void conv2d_stem_u8_mfma_kernel(StemArgs a) {
             for (int pc = 2; pc >= 0; --pc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[ks][pc], xb, acc, 0, 0, 0);   // small pieces first
         }
         const int ox = ox0 + px, oy = oy0 + ry;
-        if (ox < a.Wo && oy < a.Ho) {
-            f32x4 r = acc * sc + sh;
+        f32x4 r = acc * sc + sh;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : r[e] * a.neg_slope;
-            if (a.ys) store_split2d_quad(a.ys, b, a.Ho, a.Wo, oy, ox, g, r);
-            else *reinterpret_cast<f32x4*>(a.y + (((long long)b * a.Ho + oy) * a.Wo + ox) * 16 + 4 * g) = r;
+        for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : r[e] * a.neg_slope;
+        if (a.ys) {
+            // lanes g and g ^ 1 trade halves (all 64 lanes take part): g even ends up with hi / lo of channels 8 (g >> 1) .. + 7,
+            // one 16-byte store per lane and a contiguous KiB per wave, as the fp32 form has
+            u32x2 hi, lo;
+            split_bf16x4(r, hi, lo);
+            typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+            const u32x2 sa = __builtin_amdgcn_permlane16_swap(hi[0], lo[0], false, false);
+            const u32x2 sb = __builtin_amdgcn_permlane16_swap(hi[1], lo[1], false, false);
+            if (ox < a.Wo && oy < a.Ho)
+                *reinterpret_cast<u32x4s*>(a.ys + (((long long)b * (a.Ho + 4) + oy + 2) * (a.Wo + 4) + ox + 2) * 64 + (g & 1) * 32 + (g >> 1) * 16) =
+                    u32x4s{sa[0], sb[0], sa[1], sb[1]};
+        } else if (ox < a.Wo && oy < a.Ho) {
+            *reinterpret_cast<f32x4*>(a.y + (((long long)b * a.Ho + oy) * a.Wo + ox) * 16 + 4 * g) = r;
         }
     }
 }
