@@ -212,14 +212,28 @@ class ConvProbe:
                                  4.0 * (x.numel() + out.B * out.D * out.H * out.W * Cout * (2 if res is not None else 1))))
             return y
 
-        def probed_rs16(x, w_packed_rs, scale, shift, neg_slope=0.01, out=None):
+        def probed_rs16(x, w_packed_rs, scale, shift, neg_slope=0.01, out=None, out_split=None):
             if not self.enabled:
-                return self.orig_rs16(x, w_packed_rs, scale, shift, neg_slope, out)
+                return self.orig_rs16(x, w_packed_rs, scale, shift, neg_slope, out, out_split)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            y = self.orig_rs16(x, w_packed_rs, scale, shift, neg_slope, out)
+            y = self.orig_rs16(x, w_packed_rs, scale, shift, neg_slope, out, out_split)
             e.record()
-            self.records.append(("conv3d_rs16_kernel", 2.0 * 27 * 16 * 16 * x.B * x.D * x.H * x.W, s, e, 4.0 * 32 * x.B * x.D * x.H * x.W))
+            self.records.append(("conv3d_rs16_kernel<%s>" % ("true" if out_split is not None else "false"),
+                                 2.0 * 27 * 16 * 16 * x.B * x.D * x.H * x.W, s, e, 4.0 * 32 * x.B * x.D * x.H * x.W))
+            return y
+
+        self.orig_s2rs = H.conv3d_s2rs
+
+        def probed_s2rs(x, w_packed, shift, out, neg_slope=0.01):
+            if not self.enabled:
+                return self.orig_s2rs(x, w_packed, shift, out, neg_slope)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = self.orig_s2rs(x, w_packed, shift, out, neg_slope)
+            e.record()
+            nvo = out.B * out.D * out.H * out.W
+            self.records.append(("conv3d_s2rs_kernel<4>", 2.0 * 27 * 16 * 32 * nvo, s, e, 4.0 * (16 * x.B * x.D * x.H * x.W + 32 * nvo)))
             return y
 
         orig_poly, orig_up2s = H.conv3d_up2_poly, H.conv3d_up2_out_split
@@ -280,6 +294,7 @@ class ConvProbe:
         H.conv3d = probed
         H.conv3d_up2 = probed_up2
         H.conv3d_rs16 = probed_rs16
+        H.conv3d_s2rs = probed_s2rs
         H.conv3d_rs = probed_rs
         H.conv3d_out_split = probed_os
 
@@ -345,6 +360,7 @@ class ConvProbe:
         self.H.conv3d_up2 = self.orig_up2
         self.H.conv3d_rs = self.orig_rs
         self.H.conv3d_rs16 = self.orig_rs16
+        self.H.conv3d_s2rs = self.orig_s2rs
         self.H.conv3d_out_split = self.orig_os
         for fname, orig in self.hbm_orig.items():
             setattr(self.H, fname, orig)

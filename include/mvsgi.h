@@ -298,6 +298,18 @@ int mvsgi_conv3d_f32_out_split(const float* x, const float* w_packed_b3, const f
  * mvsgi_conv3d_rs_pack_weights(16, 16) */
 int mvsgi_conv3d_rs16_split(const void* x_split, const void* w_packed_rs, const float* scale, const float* shift, float* y,
                             int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream);
+/* the same layer writing a split-padded [B][D+2][H+2][W+2][16] tensor (zero-bordered by the caller, interior written): the
+ * hand-over to mvsgi_conv3d_s2rs */
+int mvsgi_conv3d_rs16_split_out_split(const void* x_split, const void* w_packed_rs, const float* scale, const float* shift,
+                                      void* y_split, int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream);
+/* UNetDownBlk.first of level 0 (unet_regulator.py:286-303: BaseConvBlk3d 16 -> 32, 3x3x3, stride 2, padding 1 + BN + LeakyReLU)
+ * on split-padded activations (csrc/conv3d_s2rs.hip): x_split [B][D+2][H+2][W+2][64 B] -> y_split [B][Do+2][Ho+2][Wo+2][128 B],
+ * Do = (D - 1) / 2 + 1 (likewise Ho, Wo), y = act(conv(x) * scale + shift); the scale is folded into w_packed by
+ * mvsgi_conv3d_s2rs_pack_weights ([32][16][27] fp32 weights, scale[32]).  Staging by LDS-DMA: the layer is HBM-bound. */
+size_t mvsgi_conv3d_s2rs_packed_weight_bytes(void);
+int mvsgi_conv3d_s2rs_pack_weights(const float* w_oidhw, const float* scale, void* w_packed, mvsgi_stream_t stream);
+int mvsgi_conv3d_s2rs(const void* x_split, const void* w_packed, const float* shift, void* y_split,
+                      int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream);
 size_t mvsgi_conv3d_rs_packed_weight_bytes(int Cout, int Cin);
 int mvsgi_conv3d_rs_pack_weights(const float* w_oidhw, void* w_packed, int Cout, int Cin, mvsgi_stream_t stream);
 size_t mvsgi_act_split_bytes(int B, int C, int D, int H, int W);

@@ -76,6 +76,10 @@ SIGNATURES = {
     "mvsgi_act_split_to_f32": (c_int, [_P, _P] + [c_int] * 5 + [_P]),
     "mvsgi_conv3d_f32_out_split": (c_int, [_P] * 6 + [c_int] * 7 + [c_float, _P]),
     "mvsgi_conv3d_rs16_split": (c_int, [_P] * 5 + [c_int] * 4 + [c_float, _P]),
+    "mvsgi_conv3d_rs16_split_out_split": (c_int, [_P] * 5 + [c_int] * 4 + [c_float, _P]),
+    "mvsgi_conv3d_s2rs_packed_weight_bytes": (c_size_t, []),
+    "mvsgi_conv3d_s2rs_pack_weights": (c_int, [_P, _P, _P, _P]),
+    "mvsgi_conv3d_s2rs": (c_int, [_P] * 4 + [c_int] * 4 + [c_float, _P]),
     "mvsgi_conv3d_rs_packed_weight_bytes": (c_size_t, [c_int, c_int]),
     "mvsgi_conv3d_rs_pack_weights": (c_int, [_P, _P, c_int, c_int, _P]),
     "mvsgi_conv3d_rs_split": (c_int, [_P] * 6 + [c_int] * 7 + [c_float, _P]),

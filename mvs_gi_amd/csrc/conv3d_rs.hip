@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 // ---------------------------------------------------------------------------------------------
 struct Rs16Args {
     const unsigned char* x;    // split-padded [B][D+2][H+2][W+2][16] (64 B per voxel)
-    unsigned char* y;          // fp32 [B][D][H][W][16]
+    unsigned char* y;          // fp32 [B][D][H][W][16], or (OSPLIT) split-padded [B][D+2][H+2][W+2][16]
     const bf16x8* wp;          // mvsgi_conv3d_rs_pack_weights(16, 16): [5 in-plane pairs][3 kd][hi|lo][64 lanes]
     const float* scale;
     const float* shift;
@@ -591,6 +591,9 @@ __global__ void rs16_pack_weights_kernel(const float* __restrict__ w, bf16x8* __
     wp[o + 64] = lo;
 }
 
+// OSPLIT: the output goes to a split-padded tensor of the input's geometry (the hand-over to csrc/conv3d_s2rs.hip, which stages
+// pre-split voxels by LDS-DMA) instead of plain fp32 channels-last.
+template <bool OSPLIT>
 __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
     using namespace rs16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -639,7 +642,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
     const f32x4 esc = *reinterpret_cast<const f32x4*>(a.scale + kg * 4), esh = *reinterpret_cast<const f32x4*>(a.shift + kg * 4);
     unsigned voy0[4];      // this lane's 16 B (couts 4 kg .. 4 kg + 3) of its row's voxel in output plane o
 #pragma unroll
-    for (int o = 0; o < 4; ++o) voy0[o] = (unsigned)(((o * a.H + wave) * a.W + col) * 64 + kg * 16);
+    for (int o = 0; o < 4; ++o)
+        voy0[o] = OSPLIT ? (unsigned)((((o + 1) * Hp + wave + 1) * Wp + col + 1) * 64 + (kg & 1) * 32 + (kg >> 1) * 16)
+                         : (unsigned)(((o * a.H + wave) * a.W + col) * 64 + kg * 16);
 
     const int total = a.total_units, G = gridDim.x;
     const int n = (total - (int)blockIdx.x + G - 1) / G;
@@ -687,8 +692,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
     })
 #define RS16_DESC_OUT(U, VALID)                                                                                  \
     ({                                                                                                           \
-        const long long off_ = (long long)(U).b * oframe + ((long long)((U).od * TD * a.H + (U).oh * TH) * a.W + (U).ow * TW) * 64; \
-        const long long left_ = ototal - off_;                                                                   \
+        const long long off_ = OSPLIT ? (long long)(U).b * frame_bytes + ((long long)((U).od * TD * Hp + (U).oh * TH) * Wp + (U).ow * TW) * 64 \
+                                      : (long long)(U).b * oframe + ((long long)((U).od * TD * a.H + (U).oh * TH) * a.W + (U).ow * TW) * 64; \
+        const long long left_ = (OSPLIT ? total_bytes : ototal) - off_;                                          \
         const int rec_ = left_ > 0x7fffff00ll ? 0x7fffff00 : (int)left_;                                         \
         const int ok_ = (int)(VALID) & (int)(left_ > 0);                                                         \
         __builtin_amdgcn_make_buffer_rsrc(a.y + off_, 0, ok_ ? rec_ : 0, 0x00020000);                            \
@@ -709,8 +715,14 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
 #define RS_MF0(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG));
 #define RS_PIN_V(V) asm volatile("" : "+v"(V));
 #define RS_F_STORE16(V, D, O) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, V), D, O, 0, 0);
+#define RS16_F_SPL(...) if constexpr (OSPLIT) { __VA_ARGS__ }
+#define RS16_F_F32(...) if constexpr (!OSPLIT) { __VA_ARGS__ }
 
     __amdgpu_buffer_rsrc_t dsc_x, dsc_y;
+    u32x2 hb0, hb1, hb2, hb3, lb0, lb1, lb2, lb3, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+    f32x2v hf0, hf1, hf2, hf3;
+    hb0 = hb1 = hb2 = hb3 = lb0 = lb1 = lb2 = lb3 = sa0 = sa1 = sa2 = sa3 = sb0 = sb1 = sb2 = sb3 = u32x2{0u, 0u};
+    hf0 = hf1 = hf2 = hf3 = f32x2v{0.f, 0.f};
     unsigned voy[4] = {0xffffff00u, 0xffffff00u, 0xffffff00u, 0xffffff00u};
     dsc_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, 0, 0x00020000);
     {   // prologue: image 0 <- brick 0
@@ -734,12 +746,20 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
     int ph = 0;
     for (; ph < n; ++ph) {
         const int nxt_img = (ph & 1) ? 0 : BUF1;
+        if constexpr (OSPLIT) {
+#include "conv3d_rs16s_phase_main.inc"
+        } else {
 #include "conv3d_rs16_phase_main.inc"
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
     {
+        if constexpr (OSPLIT) {
+#include "conv3d_rs16s_phase_drain.inc"
+        } else {
 #include "conv3d_rs16_phase_drain.inc"
+        }
     }
 #undef RS16_STEP
 #undef RS16_DESC
@@ -750,6 +770,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
 #undef RS_MF0
 #undef RS_PIN_V
 #undef RS_F_STORE16
+#undef RS16_F_SPL
+#undef RS16_F_F32
 }
 
 }  // namespace
@@ -922,15 +944,17 @@ int rs32_up2_launch(const void* x_split, const void* w_sets, const float* scale3
 
 // BaseConvBlk3d.forward for Cin = Cout = 16, stride 1, no residual (post_vol, spherical_sweep_avg.py:30-36,165) on a
 // split-padded input, fp32 [B][D][H][W][16] output; w_packed_rs from mvsgi_conv3d_rs_pack_weights(16, 16).
-extern "C" int mvsgi_conv3d_rs16_split(const void* x, const void* w_packed_rs, const float* scale, const float* shift, float* y,
-                                       int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream) {
+namespace {
+int rs16_run(const void* x, const void* w_packed_rs, const float* scale, const float* shift, void* y, int y_is_split,
+             int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream) {
     MVSGI_REQUIRE(x && y && w_packed_rs && scale && shift, "mvsgi_conv3d_rs16_split: null pointer");
+    MVSGI_REQUIRE(x != y, "mvsgi_conv3d_rs16_split: in-place operation is not supported");
     MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_conv3d_rs16_split: bad dims");
     MVSGI_REQUIRE(neg_slope >= 0.f && neg_slope <= 1.f, "mvsgi_conv3d_rs16_split: neg_slope %g not in [0, 1]", (double)neg_slope);
     MVSGI_REQUIRE((long long)(D + 2) * (H + 2) * (W + 2) * 64 < (1ll << 31), "mvsgi_conv3d_rs16_split: frame too large for 32-bit offsets");
     Rs16Args a{};
     a.x = static_cast<const unsigned char*>(x);
-    a.y = reinterpret_cast<unsigned char*>(y);
+    a.y = static_cast<unsigned char*>(y);
     a.wp = static_cast<const bf16x8*>(w_packed_rs);
     a.scale = scale;
     a.shift = shift;
@@ -944,9 +968,28 @@ extern "C" int mvsgi_conv3d_rs16_split(const void* x, const void* w_packed_rs, c
     a.total_units = (int)nb;
     static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
-    if (mvsgi::persistent_geometry(conv3d_rs16_kernel, 256, rs16::LDS_BYTES, 1, geo_cache, "mvsgi_conv3d_rs16_split", geo)) return 1;
+    static mvsgi::PersistentGeom geo_cache_s[mvsgi::kMaxDevices] = {};
+    if (y_is_split ? mvsgi::persistent_geometry(conv3d_rs16_kernel<true>, 256, rs16::LDS_BYTES, 1, geo_cache_s, "mvsgi_conv3d_rs16_split", geo)
+                   : mvsgi::persistent_geometry(conv3d_rs16_kernel<false>, 256, rs16::LDS_BYTES, 1, geo_cache, "mvsgi_conv3d_rs16_split", geo))
+        return 1;
     const long long resident = (long long)geo.cus / 8 * 8 > 0 ? (long long)geo.cus / 8 * 8 : 8;
-    hipLaunchKernelGGL(conv3d_rs16_kernel, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), rs16::LDS_BYTES,
-                       mvsgi::as_stream(stream), a);
+    if (y_is_split)
+        hipLaunchKernelGGL(conv3d_rs16_kernel<true>, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), rs16::LDS_BYTES,
+                           mvsgi::as_stream(stream), a);
+    else
+        hipLaunchKernelGGL(conv3d_rs16_kernel<false>, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), rs16::LDS_BYTES,
+                           mvsgi::as_stream(stream), a);
     return mvsgi::check_launch("mvsgi_conv3d_rs16_split");
+}
+}  // namespace
+
+extern "C" int mvsgi_conv3d_rs16_split(const void* x, const void* w_packed_rs, const float* scale, const float* shift, float* y,
+                                       int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream) {
+    return rs16_run(x, w_packed_rs, scale, shift, y, 0, B, D, H, W, neg_slope, stream);
+}
+
+// the same layer writing a split-padded [B][D+2][H+2][W+2][16] tensor (zero-bordered by the caller, interior written)
+extern "C" int mvsgi_conv3d_rs16_split_out_split(const void* x, const void* w_packed_rs, const float* scale, const float* shift, void* y_split,
+                                                 int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream) {
+    return rs16_run(x, w_packed_rs, scale, shift, y_split, 1, B, D, H, W, neg_slope, stream);
 }

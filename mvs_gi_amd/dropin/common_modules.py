@@ -50,7 +50,7 @@ _USE_V32 = os.environ.get("MVSGI_V32", "0") != "0"
 class ConvLaunch:
     """Device-resident launch arguments of one BaseConvBlk3d: PyTorch-layout weight, packed
     MFMA weight (or None), per-channel scale/shift (eval BatchNorm3d or bias), stride, slope."""
-    __slots__ = ("w", "wp", "wp_b3", "wp_c16", "wp_v32", "wp_rs", "wp_poly", "wp_head", "head_sc", "scale", "shift", "stride",
+    __slots__ = ("w", "wp", "wp_b3", "wp_c16", "wp_v32", "wp_rs", "wp_s2", "wp_poly", "wp_head", "head_sc", "scale", "shift", "stride",
                  "neg_slope", "cin", "cout", "key")
 
     def run(self, x_ndhwc: Tensor, res: Optional[Tensor] = None, impl: Optional[int] = None) -> Tensor:
@@ -96,6 +96,15 @@ class ConvLaunch:
         if self.wp_rs is None:
             self.wp_rs = H.pack_conv_weights_rs(self.w)
         return self.wp_rs
+
+    def s2rs_ok(self) -> bool:
+        """The stride-2 16 -> 32 kernel on split-padded activations (csrc/conv3d_s2rs.hip) serves this layer."""
+        return H.get_conv_mode() == "bf16x3" and H.conv3d_s2rs_applies(self.cin, self.cout, self.stride, self.neg_slope)
+
+    def _wp_s2(self):
+        if self.wp_s2 is None:
+            self.wp_s2 = H.pack_conv_weights_s2rs(self.w, self.scale)
+        return self.wp_s2
 
     def _wp_v32(self):
         if self.wp_v32 is None:
@@ -237,6 +246,7 @@ def lower_conv_block(blk) -> ConvLaunch:
     L.wp_c16 = None
     L.wp_v32 = None
     L.wp_rs = None
+    L.wp_s2 = None
     L.wp_poly = None
     L.wp_head = None
     L.head_sc = None

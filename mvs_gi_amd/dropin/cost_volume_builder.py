@@ -113,28 +113,56 @@ _FRONT_CHUNK = int(os.environ.get("MVSGI_FRONT_CHUNK", "16"))
 _RS_MIN_UNITS = int(os.environ.get("MVSGI_RS_MIN_UNITS", "0"))      # measured faster down to one frame (B=1: 16.9 vs 24.2 us, 23.5 vs 32.2 us)
 
 
-def std_forward(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor) -> Tensor:
+def _std_front(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor, hand_over_split: bool):
+    """sweep -> split-padded vol_raw -> register-stationary post_vol (csrc/conv3d_rs.hip).  Returns the fp32 volume
+    [B, D, H, W, 16], or (hand_over_split) post_vol's output as a module-owned split-padded H.SplitAct -- the form the
+    regulator's stride-2 first layer stages by LDS-DMA (csrc/conv3d_s2rs.hip) -- or None when the layer shapes / mode do not
+    put post_vol on that kernel."""
     L = cm.lower_conv_block(self.post_vol)
-    if _USE_RS and H.get_conv_mode() == "bf16x3" and L.cin == 16 and L.cout == 16 and L.stride == 1 \
-            and 0.0 <= L.neg_slope <= 1.0 and feats.dim() == 5 and feats.shape[2] == 16 and grids.dim() == 6:
-        B, D, Ho, Wo = feats.shape[0], grids.shape[2], grids.shape[3], grids.shape[4]
-        if B * ((D + 3) // 4) * ((Ho + 3) // 4) * ((Wo + 15) // 16) >= _RS_MIN_UNITS and _rig_cache_usable(self, feats, grids):
-            # sweep -> split-padded vol_raw -> register-stationary post_vol (csrc/conv3d_rs.hip) -> fp32 vol
-            k = _FRONT_CHUNK
-            shared = all(t.dim() > 0 and t.shape[0] > 1 and t.stride(0) == 0 for t in (grids, grid_masks, masks))
-            if k > 0 and B > k and shared:
-                # frames in chunks of k: a chunk's split-padded vol_raw (k x 30 MB) is written by the sweep and read straight back
-                # by post_vol while much of it is still in the 256 MB memory-side cache; the buffer is k frames, not B
-                y = torch.empty((B, D, Ho, Wo, 16), device=feats.device, dtype=torch.float32)
-                for i in range(0, B, k):
-                    j = min(i + k, B)
-                    vs = std_sweep_ndhwc(feats[i:j], grids, grid_masks, masks, owner=self, split_out=True, buf_frames=k)    # the rig tensors whole: cache identity
-                    H.conv3d_rs16(vs, L._wp_rs(), L.scale, L.shift, neg_slope=L.neg_slope, out=y[i:j])
-                return cm._to_ncdhw_view(y)
-            vs = std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=self, split_out=True)
-            return cm._to_ncdhw_view(H.conv3d_rs16(vs, L._wp_rs(), L.scale, L.shift, neg_slope=L.neg_slope))
+    if not (_USE_RS and H.get_conv_mode() == "bf16x3" and L.cin == 16 and L.cout == 16 and L.stride == 1
+            and 0.0 <= L.neg_slope <= 1.0 and feats.dim() == 5 and feats.shape[2] == 16 and grids.dim() == 6):
+        return None
+    B, D, Ho, Wo = feats.shape[0], grids.shape[2], grids.shape[3], grids.shape[4]
+    if not (B * ((D + 3) // 4) * ((Ho + 3) // 4) * ((Wo + 15) // 16) >= _RS_MIN_UNITS and _rig_cache_usable(self, feats, grids)):
+        return None
+    xs = None
+    if hand_over_split:      # one buffer per shape, never replaced while the module lives (a captured hipGraph holds the address)
+        xs = _owned_split_buffer(self, "_mvsgi_rs_x0", (B, D, Ho, Wo, feats.device), lambda: H.SplitAct(B, D, Ho, Wo, 16, feats.device))
+    k = _FRONT_CHUNK
+    shared = all(t.dim() > 0 and t.shape[0] > 1 and t.stride(0) == 0 for t in (grids, grid_masks, masks))
+    if k > 0 and B > k and shared:
+        # frames in chunks of k: a chunk's split-padded vol_raw (k x 30 MB) is written by the sweep and read straight back
+        # by post_vol while much of it is still in the 256 MB memory-side cache; the buffer is k frames, not B
+        y = None if hand_over_split else torch.empty((B, D, Ho, Wo, 16), device=feats.device, dtype=torch.float32)
+        for i in range(0, B, k):
+            j = min(i + k, B)
+            vs = std_sweep_ndhwc(feats[i:j], grids, grid_masks, masks, owner=self, split_out=True, buf_frames=k)    # the rig tensors whole: cache identity
+            if hand_over_split:
+                H.conv3d_rs16(vs, L._wp_rs(), L.scale, L.shift, neg_slope=L.neg_slope,
+                              out_split=H.SplitAct(j - i, D, Ho, Wo, 16, feats.device, buf=xs.buf[i:j]))
+            else:
+                H.conv3d_rs16(vs, L._wp_rs(), L.scale, L.shift, neg_slope=L.neg_slope, out=y[i:j])
+        return xs if hand_over_split else y
+    vs = std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=self, split_out=True)
+    if hand_over_split:
+        return H.conv3d_rs16(vs, L._wp_rs(), L.scale, L.shift, neg_slope=L.neg_slope, out_split=xs)
+    return H.conv3d_rs16(vs, L._wp_rs(), L.scale, L.shift, neg_slope=L.neg_slope)
+
+
+def std_forward(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor) -> Tensor:
+    y = _std_front(self, feats, grids, grid_masks, masks, False)
+    if y is not None:
+        return cm._to_ncdhw_view(y)
+    L = cm.lower_conv_block(self.post_vol)
     vol_raw = std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=self)
     return cm._to_ncdhw_view(L.run(vol_raw))
+
+
+def std_forward_split(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor):
+    """forward() with the cost volume handed over as a split-padded H.SplitAct (module-owned, valid until the next call) instead
+    of an fp32 tensor, for a regulator that takes it (cost_volume_regulator.regulator_takes_split); None when this builder
+    configuration does not produce it -- the caller then uses forward()."""
+    return _std_front(self, feats, grids, grid_masks, masks, True)
 
 
 def cat_forward(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor) -> Tensor:
@@ -149,6 +177,7 @@ class SphericalSweepStdMasked(_SweepBase):
         return cm._to_ncdhw_view(std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=self))
 
     forward = std_forward
+    forward_split = std_forward_split
 
 
 class SphericalSweep(_SweepBase):

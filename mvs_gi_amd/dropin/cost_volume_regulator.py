@@ -75,7 +75,10 @@ def _down_block_rs(blk, x: Tensor, L0, chain, dims) -> Tensor:
     if key not in sets:
         sets[key] = [H.SplitAct(B, Do, Ho, Wo, 32, x.device) for _ in range(3)]
     b = sets[key]
-    H.conv3d_out_split(x, L0._wp_b3(), L0.scale, L0.shift, out=b[0], stride=L0.stride, neg_slope=L0.neg_slope)
+    if isinstance(x, H.SplitAct):      # the builder handed post_vol's output over split-padded: staged by LDS-DMA (csrc/conv3d_s2rs.hip)
+        H.conv3d_s2rs(x, L0._wp_s2(), L0.shift, out=b[0], neg_slope=L0.neg_slope)
+    else:
+        H.conv3d_out_split(x, L0._wp_b3(), L0.scale, L0.shift, out=b[0], stride=L0.stride, neg_slope=L0.neg_slope)
     cur, out = 0, None
     for i, (L1, L2) in enumerate(chain):
         r, y = (cur + 1) % 3, (cur + 2) % 3
@@ -88,10 +91,43 @@ def _down_block_rs(blk, x: Tensor, L0, chain, dims) -> Tensor:
     return out
 
 
-def down_block_ndhwc(blk, x: Tensor) -> Tensor:
+# MVSGI_S2RS=0: the builder -> regulator hand-over stays an fp32 tensor (the regulator's first layer on the streaming kernel).
+# MVSGI_S2RS_MIN_FRAMES: smallest batch for the split-padded hand-over
+_USE_S2RS = os.environ.get("MVSGI_S2RS", "1") != "0"
+_S2RS_MIN_FRAMES = int(os.environ.get("MVSGI_S2RS_MIN_FRAMES", "1"))
+
+
+class _Shape:
+    __slots__ = ("shape",)
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+def regulator_takes_split(self, shape) -> bool:
+    """True when forward_split_in() can take a split-padded cost volume of geometry `shape` = (B, D, H, W, C): the (16, 32)
+    regulator in split-bf16 mode, whose first layer (16 -> 32, stride 2) then stages pre-split voxels by LDS-DMA and whose
+    level-0 residual blocks run register-stationary."""
+    if not (_USE_S2RS and H.get_conv_mode() == "bf16x3" and len(self.down_blks) > 0 and len(shape) == 5 and shape[4] == 16
+            and shape[0] >= _S2RS_MIN_FRAMES):
+        return False
+    blk = self.down_blks[0]
+    return cm.lower_conv_block(blk.first).s2rs_ok() and _rs_chain(blk, _Shape(shape)) is not None
+
+
+def regulator_forward_split_in(self, xs) -> Tensor:
+    """forward() on the builder's split-padded cost volume (H.SplitAct, 16 channels); see regulator_takes_split."""
+    if not regulator_takes_split(self, xs.shape):
+        raise RuntimeError(f"this regulator does not take a split-padded volume of geometry {xs.shape}: call forward() with the fp32 tensor")
+    return cm._to_ncdhw_view(regulator_forward_ndhwc(self, xs))
+
+
+def down_block_ndhwc(blk, x) -> Tensor:
     rs = _rs_chain(blk, x)
     if rs is not None:
         return _down_block_rs(blk, x, *rs)
+    if isinstance(x, H.SplitAct):
+        raise RuntimeError("split-padded input needs the register-stationary level-0 chain (regulator_takes_split)")
     x = cm.lower_conv_block(blk.first).run(x)
     for rb in blk.blks:
         x = cm.res_block_ndhwc(rb, x)
@@ -196,6 +232,8 @@ class UNetCostVolumeRegulatorBase(nn.Module):
                              norm_layer=cm.NoOp()))
 
     forward = regulator_forward
+    takes_split = regulator_takes_split
+    forward_split_in = regulator_forward_split_in
     __getstate__ = cm.module_getstate
 
 
@@ -241,4 +279,6 @@ class UNetCostVolumeRegulator(nn.Module):
                              norm_layer=cm.NoOp()))
 
     forward = regulator_forward
+    takes_split = regulator_takes_split
+    forward_split_in = regulator_forward_split_in
     __getstate__ = cm.module_getstate

@@ -105,10 +105,13 @@ def _patch_reference():
     d = importlib.import_module("dsta_mvs.model.distance_regressor.distance_regressor")
     c = importlib.import_module("dsta_mvs.model.common.common_modules")
     gs = _cm.module_getstate      # derived `_mvsgi_*` caches never travel with a pickled module
-    rebind(b.SphericalSweepStdMasked, forward=_cvb.std_forward, sweep=_cvb.SphericalSweepStdMasked.sweep, __getstate__=gs)
+    rebind(b.SphericalSweepStdMasked, forward=_cvb.std_forward, forward_split=_cvb.std_forward_split,
+           sweep=_cvb.SphericalSweepStdMasked.sweep, __getstate__=gs)
     rebind(b.SphericalSweep, forward=_cvb.cat_forward, sweep=_cvb.SphericalSweep.sweep, __getstate__=gs)
-    rebind(r.UNetCostVolumeRegulatorBase, forward=_reg.regulator_forward, __getstate__=gs)
-    rebind(r.UNetCostVolumeRegulator, forward=_reg.regulator_forward, __getstate__=gs)
+    rebind(r.UNetCostVolumeRegulatorBase, forward=_reg.regulator_forward, takes_split=_reg.regulator_takes_split,
+           forward_split_in=_reg.regulator_forward_split_in, __getstate__=gs)
+    rebind(r.UNetCostVolumeRegulator, forward=_reg.regulator_forward, takes_split=_reg.regulator_takes_split,
+           forward_split_in=_reg.regulator_forward_split_in, __getstate__=gs)
     rebind(r.UNetDownBlk, forward=_reg.UNetDownBlk.forward, __getstate__=gs)
     rebind(d.DistanceRegressorWithFixedCandidates, forward=_dr.regressor_forward)
     rebind(c.BaseConvBlk3d, forward=_cm.BaseConvBlk3d.forward, __getstate__=gs)
@@ -122,6 +125,15 @@ def _patch_reference():
     rebind(c.SphereConvBlk, forward=_fe.SphereConvBlk.forward)
     fs = importlib.import_module("dsta_mvs.model.feature_extractor.sphere_feature_extractor")
     rebind(fs.SphereEquirectFeatExtraction, forward=_fe.sphere_extractor_forward, __getstate__=gs)
+    # the composition: the reference's own extract_features, then builder -> regulator with this package's hand-over
+    # (the mvs_model package pulls in the training stack -- cv2, lightning: where that does not import, the modules above are
+    # still patched and the volume crosses the boundary as the reference's fp32 tensor)
+    try:
+        mm = importlib.import_module("dsta_mvs.model.mvs_model.torch_only")
+    except Exception:
+        mm = None
+    if mm is not None:
+        rebind(mm.SphericalSweepStereoBase, forward=_to.reference_forward)
     _state["saved"] = saved
 
 

@@ -19,9 +19,28 @@ class SphericalSweepStereoBase(nn.Module):
         return feats.reshape(*lead, *feats.shape[1:])
 
     def hot_path(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor):
-        vol = self.cv_builder(feats, grids, grid_masks, masks)
-        costs = self.cv_regulator(vol)
-        return self.dist_regressor(costs)
+        return self.dist_regressor(build_and_regulate(self.cv_builder, self.cv_regulator, feats, grids, grid_masks, masks))
 
     def forward(self, imgs: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor):
         return self.hot_path(self.extract_features(imgs), grids, grid_masks, masks)
+
+
+def build_and_regulate(cv_builder: nn.Module, cv_regulator: nn.Module, feats: Tensor, grids: Tensor, grid_masks: Tensor,
+                       masks: Tensor) -> Tensor:
+    """costs = cv_regulator(cv_builder(...)) (torch_only.py:32-33).  When both modules are this package's and agree on it
+    (builder.forward_split / regulator.takes_split), the cost volume crosses the module boundary as a module-owned split-padded
+    buffer instead of an fp32 tensor: the regulator's stride-2 first layer then stages it by LDS-DMA (csrc/conv3d_s2rs.hip).
+    Each module's own forward() keeps the reference's tensor interface."""
+    fs, takes = getattr(cv_builder, "forward_split", None), getattr(cv_regulator, "takes_split", None)
+    if fs is not None and takes is not None and feats.dim() == 5 and grids.dim() == 6 and \
+            takes((feats.shape[0], grids.shape[2], grids.shape[3], grids.shape[4], 16)):
+        xs = fs(feats, grids, grid_masks, masks)
+        if xs is not None:
+            return cv_regulator.forward_split_in(xs)
+    return cv_regulator(cv_builder(feats, grids, grid_masks, masks))
+
+
+def reference_forward(self, imgs: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor):
+    """SphericalSweepStereoBase.forward (torch_only.py:30-36) for the patched reference class: its own extract_features."""
+    feats = self.extract_features(imgs)
+    return self.dist_regressor(build_and_regulate(self.cv_builder, self.cv_regulator, feats, grids, grid_masks, masks))

@@ -449,6 +449,10 @@ class SplitAct:
     def shape(self):
         return (self.B, self.D, self.H, self.W, self.C)
 
+    @property
+    def device(self):
+        return self.buf.device
+
 
 def act_to_split(x_ndhwc: torch.Tensor, out: Optional[SplitAct] = None) -> SplitAct:
     lib = _lib.load()
@@ -524,15 +528,51 @@ def conv3d_out_split(x, w_packed_b3, scale, shift, out: "SplitAct", res=None, st
     return out
 
 
-def conv3d_rs16(x: "SplitAct", w_packed_rs, scale, shift, neg_slope=0.01, out=None) -> torch.Tensor:
-    """Register-stationary 16 -> 16 conv (post_vol) on a split-padded volume -> fp32 [B, D, H, W, 16]."""
+def conv3d_rs16(x: "SplitAct", w_packed_rs, scale, shift, neg_slope=0.01, out=None, out_split: Optional["SplitAct"] = None):
+    """Register-stationary 16 -> 16 conv (post_vol) on a split-padded volume -> fp32 [B, D, H, W, 16], or (out_split) a
+    split-padded volume of the same geometry (the hand-over to conv3d_s2rs)."""
     lib = _lib.load()
     if x.C != 16 or scale.numel() != 16:
         raise AssertionError("conv3d_rs16 is the 16 -> 16 kernel")
+    if out_split is not None:
+        if out_split.shape != x.shape or out_split.buf.data_ptr() == x.buf.data_ptr():
+            raise AssertionError(f"split output {out_split.shape} must match the input {x.shape} and be another buffer")
+        _lib.check(lib.mvsgi_conv3d_rs16_split_out_split(x.buf.data_ptr(), w_packed_rs.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                         out_split.buf.data_ptr(), x.B, x.D, x.H, x.W, float(neg_slope),
+                                                         _stream_ptr(x.buf)), "mvsgi_conv3d_rs16_split_out_split")
+        return out_split
     y = out if out is not None else torch.empty((x.B, x.D, x.H, x.W, 16), device=x.buf.device, dtype=torch.float32)
     _lib.check(lib.mvsgi_conv3d_rs16_split(x.buf.data_ptr(), w_packed_rs.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(),
                                            x.B, x.D, x.H, x.W, float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_rs16_split")
     return y
+
+
+def conv3d_s2rs_applies(cin: int, cout: int, stride: int, neg_slope: float) -> bool:
+    return cin == 16 and cout == 32 and stride == 2 and 0.0 <= neg_slope <= 1.0
+
+
+def pack_conv_weights_s2rs(w_oidhw: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """[32, 16, 3, 3, 3] weights with the per-channel scale folded in, in the lane order of csrc/conv3d_s2rs.hip."""
+    lib = _lib.load()
+    w = _dev(w_oidhw, "w")
+    scale = _dev(scale, "scale")
+    if tuple(w.shape) != (32, 16, 3, 3, 3) or scale.numel() != 32:
+        raise AssertionError(f"conv3d_s2rs is the 16 -> 32 channel stride-2 layer, got weights {tuple(w.shape)}")
+    wp = torch.empty(lib.mvsgi_conv3d_s2rs_packed_weight_bytes(), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.mvsgi_conv3d_s2rs_pack_weights(w.data_ptr(), scale.data_ptr(), wp.data_ptr(), _stream_ptr(w)),
+               "mvsgi_conv3d_s2rs_pack_weights")
+    return wp
+
+
+def conv3d_s2rs(x: "SplitAct", w_packed, shift, out: "SplitAct", neg_slope=0.01) -> "SplitAct":
+    """16 -> 32 channel 3x3x3 stride-2 conv + scale / shift + LeakyReLU, split-padded in and out (LDS-DMA staging)."""
+    lib = _lib.load()
+    Do, Ho, Wo = (x.D - 1) // 2 + 1, (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
+    if x.C != 16 or out.shape != (x.B, Do, Ho, Wo, 32) or shift.numel() != 32:
+        raise AssertionError(f"conv3d_s2rs: input {x.shape} -> output {out.shape}, expected {(x.B, Do, Ho, Wo, 32)}")
+    _lib.check(lib.mvsgi_conv3d_s2rs(x.buf.data_ptr(), w_packed.data_ptr(), shift.data_ptr(), out.buf.data_ptr(), x.B, x.D, x.H, x.W,
+                                     float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_s2rs")
+    return out
 
 
 def conv3d_rs_applies(cin: int, cout: int, stride: int, neg_slope: float) -> bool:

@@ -12,6 +12,7 @@ import torch
 
 from .configs import PathConfig
 from . import dropin
+from .dropin.torch_only import build_and_regulate
 
 
 def build_modules(cfg: PathConfig, weights: Optional[Dict[str, Dict[str, np.ndarray]]] = None, device="cuda"):
@@ -55,9 +56,7 @@ class HotPath:
                 # frame 0's constants for every frame).  Otherwise replicated once.
                 self._rig_views = ((B, shared), *(exp if shared else [t.contiguous() for t in exp]))
             _, g, gm, m = self._rig_views          # the same objects every call: the rig cache hits by identity
-        vol = self.cv_builder(feats, g, gm, m)
-        costs = self.cv_regulator(vol)
-        return self.dist_regressor(costs)
+        return self.dist_regressor(build_and_regulate(self.cv_builder, self.cv_regulator, feats, g, gm, m))
 
     # ---- hipGraph replay: the ~35 launches of one forward captured once, replayed per batch ----
     def capture(self, feats: torch.Tensor) -> None:

@@ -605,7 +605,7 @@ def test_bench_self_launches_its_ranks():
     hbm = {k: v for k, v in d["kernels"].items() if v.get("bound") == "hbm"}
     assert any(k.startswith("sweep_std") for k in hbm) and any(k.startswith("softargmin") for k in hbm) and any(k.startswith("conv3d_head") for k in hbm)
     assert all(v["GBps"] > 0 for v in hbm.values())
-    assert d["roofline"]["attributed_time_frac_of_step"] > 0.8
+    assert d["roofline"]["attributed_time_frac_of_step"] > 0.7      # (two ranks share the card here: each rank's wall time holds the other's kernels)
 
 
 # ------------------------------------------------------------------------------ feature extractor (§8(f) rank 1)
@@ -1175,6 +1175,56 @@ def test_conv3d_rs16_vs_oracle(shape, slope):
     ref = F.conv3d(xq, torch.from_numpy(wt), padding=1) * torch.from_numpy(sc).view(1, -1, 1, 1, 1) + torch.from_numpy(sh).view(1, -1, 1, 1, 1)
     ref = torch.where(ref > 0, ref, ref * slope).permute(0, 2, 3, 4, 1).numpy()
     assert _rel(y, ref) <= 1e-4
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 4, 16), (2, 5, 7, 37), (3, 8, 16, 48), (3, 10, 30, 150)])
+def test_conv3d_rs16_split_output_is_the_split_of_the_fp32_output(shape):
+    """post_vol writing the split-padded format (the hand-over to the stride-2 kernel): bit for bit the split of what the fp32
+    variant writes, zero border untouched."""
+    B, d, h, w = shape
+    rng = np.random.default_rng(sum(shape) + 3)
+    x = _g(rng.standard_normal((B, d, h, w, 16), dtype=np.float32))
+    wt = (rng.standard_normal((16, 16, 3, 3, 3)) / np.sqrt(27 * 16)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, 16).astype(np.float32), (rng.standard_normal(16) * 0.1).astype(np.float32)
+    xs, wp = H.act_to_split(x), H.pack_conv_weights_rs(_g(wt))
+    y = H.conv3d_rs16(xs, wp, _g(sc), _g(sh), neg_slope=0.01)
+    ys = H.conv3d_rs16(xs, wp, _g(sc), _g(sh), neg_slope=0.01, out_split=H.SplitAct(B, d, h, w, 16, x.device))
+    assert torch.equal(ys.buf, H.act_to_split(y).buf)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 2, 16), (2, 4, 8, 32), (1, 5, 7, 19), (3, 2, 9, 33), (2, 16, 20, 40), (4, 16, 80, 320)])
+@pytest.mark.parametrize("th", [4, 2])
+def test_conv3d_s2rs_vs_reference_conv(shape, th):
+    """The stride-2 16 -> 32 layer on split-padded activations (LDS-DMA staging, even / odd column de-interleave) against
+    conv3d(stride 2, padding 1) + scale / shift + LeakyReLU in float64 on the same (16-bit-split) input: even and odd sizes,
+    ragged tiles, a launch with several bricks per workgroup (4 x 16 x 80 x 320: 3200 bricks); both brick heights; the output's
+    zero border untouched."""
+    B, d, h, w = shape
+    rng = np.random.default_rng(sum(shape) + th)
+    x = _g(rng.standard_normal((B, d, h, w, 16), dtype=np.float32))
+    wt = (rng.standard_normal((32, 16, 3, 3, 3)) / np.sqrt(27 * 16)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, 32).astype(np.float32), (rng.standard_normal(32) * 0.1).astype(np.float32)
+    xs = H.act_to_split(x)
+    do, ho, wo = (d - 1) // 2 + 1, (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = H.SplitAct(B, do, ho, wo, 32, x.device)
+    old = os.environ.get("MVSGI_S2RS_TH")
+    os.environ["MVSGI_S2RS_TH"] = str(th)              # read by the launcher on every call
+    try:
+        ys = H.conv3d_s2rs(xs, H.pack_conv_weights_s2rs(_g(wt), _g(sc)), _g(sh), out, neg_slope=0.01)
+    finally:
+        if old is None:
+            del os.environ["MVSGI_S2RS_TH"]
+        else:
+            os.environ["MVSGI_S2RS_TH"] = old
+    y = H.act_from_split(ys).cpu().numpy()
+    xq = H.act_from_split(xs).cpu().double().permute(0, 4, 1, 2, 3)
+    ref = F.conv3d(xq, torch.from_numpy(wt).double(), padding=1, stride=2) * torch.from_numpy(sc).double().view(1, -1, 1, 1, 1) \
+        + torch.from_numpy(sh).double().view(1, -1, 1, 1, 1)
+    ref = torch.where(ref > 0, ref, ref * 0.01).permute(0, 2, 3, 4, 1).numpy()
+    assert _rel(y, ref) <= 1e-4
+    border = ys.buf.clone()
+    border[:, 1:-1, 1:-1, 1:-1] = 0
+    assert int(border.count_nonzero()) == 0
 
 
 def test_sweep_split_padded_output_is_the_split_of_vol_raw(golden_dir):

@@ -117,7 +117,7 @@ class Sched:
         return s
 
 
-def build(with_pairs):
+def build(with_pairs, split=False):
     # phase stream: groups 13, 14 of the previous brick, then groups 0..12 of the current one
     mf, gstart, last_mfma = [], {}, {}
     touched = {0, 1, 2, 3}                      # groups 13, 14 continue the previous brick's accumulators
@@ -162,6 +162,12 @@ def build(with_pairs):
         if not with_pairs:
             lo = max(lo, 30)
         S.place(lo, 4, f"fin[{op}] = acc[{op}]; RS_PIN_V(fin[{op}])", end=hi + 1, cap=5.0)
+    # split-padded output: the epilogue is three times as long (split + lane exchange), so the next brick's LDS-DMA is spread
+    # over the same slots FIRST (one piece every 6th slot from slot 38) and the epilogue fills the rest; nothing orders the two
+    # (the phase ends with vmcnt(0)).  With the DMA behind the epilogue (slot 113 on) post_vol took 312 instead of 284 us.
+    if with_pairs and split:
+        for m in range(14):
+            S.place(38 + 6 * m, 2.0, f"RS_F_DMA(RS16_DMA({m}))")
     # epilogue: scale / shift, LeakyReLU, fp32 store -- one instruction per statement
     s = 36
     ep_end = s
@@ -170,14 +176,28 @@ def build(with_pairs):
         for e in range(4):
             items.append((1, f"u{op} = fin[{op}][{e}] * a.neg_slope;"))
             items.append((1, f"fin[{op}][{e}] = __builtin_fmaxf(fin[{op}][{e}], u{op});"))
-        items.append((2.0, f"RS_F_STORE16(fin[{op}], dsc_y, voy[{op}])"))
+        # split-padded output (the stride-2 kernel behind post_vol stages pre-split voxels by LDS-DMA): hi | lo, lanes kg and
+        # kg ^ 1 trade halves so that a lane stores 16 contiguous bytes of the voxel record
+        for p in range(2 if split else 0):
+            items.append((1, f"RS16_F_SPL(hb{op}[{p}] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{{fin[{op}][{2 * p}], fin[{op}][{2 * p + 1}]}}, bf16x2));)"))
+            items.append((1, f"RS16_F_SPL(hf{op}[0] = __builtin_bit_cast(float, hb{op}[{p}] << 16);)"))
+            items.append((1, f"RS16_F_SPL(hf{op}[1] = __builtin_bit_cast(float, hb{op}[{p}] & 0xffff0000u);)"))
+            items.append((1, f"RS16_F_SPL(hf{op}[0] = fin[{op}][{2 * p}] - hf{op}[0];)"))
+            items.append((1, f"RS16_F_SPL(hf{op}[1] = fin[{op}][{2 * p + 1}] - hf{op}[1];)"))
+            items.append((1, f"RS16_F_SPL(lb{op}[{p}] = __builtin_bit_cast(unsigned, __builtin_convertvector(hf{op}, bf16x2));)"))
+        if split:
+            items.append((2.0, f"RS16_F_SPL(sa{op} = __builtin_amdgcn_permlane16_swap(hb{op}[0], lb{op}[0], false, false);)"))
+            items.append((2.0, f"RS16_F_SPL(sb{op} = __builtin_amdgcn_permlane16_swap(hb{op}[1], lb{op}[1], false, false);)"))
+            items.append((2.0, f"RS16_F_SPL(RS_F_STORE16((u32x4{{sa{op}[0], sb{op}[0], sa{op}[1], sb{op}[1]}}), dsc_y, voy[{op}]))"))
+        else:
+            items.append((2.0, f"RS_F_STORE16(fin[{op}], dsc_y, voy[{op}])"))
         for cost, st in items:
             s = S.place(s, cost, f"RS_F_EPI({st})")
             if cost >= 2.0:
                 s += 1
         ep_end = s
     # LDS-DMA of the next brick: 14 pieces per wave, after the epilogue's stores (the staging is then the youngest VMEM work)
-    if with_pairs:
+    if with_pairs and not split:
         s = ep_end + 2
         step = max((n - 40 - s) // 14, 3)
         for m in range(14):
@@ -203,10 +223,11 @@ def build(with_pairs):
 
 def main():
     hdr = "// GENERATED by tools/gen_rs16_schedule.py -- do not edit; edit the generator and re-run it.\n"
-    for name, wp in (("main", True), ("drain", False)):
-        txt, n, mx, ep = build(wp)
-        open(os.path.join(OUT, f"conv3d_rs16_phase_{name}.inc"), "w").write(hdr + txt)
-        print(f"{name}: {n} slots, max slot load {mx:g}, epilogue ends at slot {ep}")
+    for split in (False, True):       # fp32 output / split-padded output (conv3d_rs16_kernel<OSPLIT>)
+        for name, wp in (("main", True), ("drain", False)):
+            txt, n, mx, ep = build(wp, split)
+            open(os.path.join(OUT, f"conv3d_rs16{'s' if split else ''}_phase_{name}.inc"), "w").write(hdr + txt)
+            print(f"{'split' if split else 'fp32'} {name}: {n} slots, max slot load {mx:g}, epilogue ends at slot {ep}")
 
 
 if __name__ == "__main__":
