@@ -86,7 +86,7 @@ constexpr int IMGB = REGION + NPX * 32;       // 40,064: the conv1 result (LO re
 constexpr int LDS_BYTES = IMGA + IMGB;        // 81,024: two workgroups per CU
 constexpr int DPW = 2 * PIECES / 4;           // 10 pieces per wave
 static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
-static_assert(IMGA + REGION + (3 * IW + 16) * 32 < 65536, "fragment reads address both images with 16-bit immediates");
+static_assert(REGION + 7 * 2 * IW * 32 < 65536, "a wave's tiles are 16-bit immediates from its base addresses");
 }  // namespace rb
 
 // ---------------------------------------------------------------------------------------------
@@ -204,19 +204,23 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) ident[j] = ((kg & 1) * 8 + j == col) ? (__bf16)1.0f : (__bf16)0.0f;
 
-    // ---- fragment read addresses: tile (i, hf) of this wave = region row 4 wave + i, columns 16 hf + col;
+    // ---- tiles of this wave: column half hf = wave & 1, region rows r0 + 2 k with r0 = wave >> 1: k = 0 .. 7 in conv1 (16 rows),
+    //      k = 0 .. 6 in conv2 (the 14 stored rows: no tile is computed for rows 14, 15), every offset between them an immediate.
     //      lane (col, kg) reads chunk kg & 1 of the pixel under tap 2 p + (kg >> 1) ----
-    int rbp[5];
+    const int hf = wave & 1, r0 = wave >> 1;
+    int rbp[5], rbq[5];           // window / conv1-result image (the latter's base does not fit the 16-bit immediates)
 #pragma unroll
     for (int p = 0; p < 5; ++p) {
         const int tA = 2 * p, tB = 2 * p + 1 < 9 ? 2 * p + 1 : 2 * p;
         const int t = (kg >> 1) ? tB : tA;
-        rbp[p] = ((4 * wave + t / 3) * IW + col + t % 3) * 32 + (kg & 1) * 16;
+        rbp[p] = ((r0 + t / 3) * IW + 16 * hf + col + t % 3) * 32 + (kg & 1) * 16;
+        rbq[p] = rbp[p] + IMGA;
     }
     // skip connection: window pixel (r + 2, c + 2), 16-byte chunk kg & 1 of the HI (kg < 2) or LO region
-    const int rres = ((4 * wave + 2) * IW + col + 2) * 32 + (kg & 1) * 16 + (kg >> 1) * REGION;
+    const int rres = ((r0 + 2) * IW + 16 * hf + col + 2) * 32 + (kg & 1) * 16 + (kg >> 1) * REGION;
     // conv1 result -> image B: region pixel (r, c), this lane's channels 4 kg .. 4 kg + 3 (8 bytes of hi, 8 of lo)
-    const int wrb = IMGA + ((4 * wave) * IW + col) * 32 + kg * 8;
+    const int wrb = IMGA + (r0 * IW + 16 * hf + col) * 32 + kg * 8;
+    constexpr int TSTEP = 2 * IW * 32;          // bytes between a wave's consecutive tiles (two rows)
     // ---- DMA plan: piece q = wave + 4 m fills LDS bytes [q * 1024, +1024) of the window: 32 pixels x 2 chunks of one region ----
     unsigned voff[DPW];
 #pragma unroll
@@ -227,17 +231,15 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
         const int wy = v / IW, wx = v - wy * IW;
         voff[m] = v < NPX ? (unsigned)((wy * Wp + wx) * 64 + region * 32 + chunk * 16) : 0xffffff00u;   // beyond num_records: zeros
     }
-    // ---- output: lane offsets from the brick's first output pixel, tile row i = + i * orow (scalar) ----
+    // ---- output: lane offset from the brick's first output pixel, tile k = + 2 k * orow (scalar) ----
     //      split: lanes kg and kg ^ 1 trade halves, kg even stores hi / lo of channels 8 (kg >> 1) .. + 7 (16 bytes)
-    unsigned vst[2];
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-        vst[hf] = (unsigned)(4 * wave * orow + (16 * hf + col) * 64 + (OUTF32 ? kg * 16 : (kg & 1) * 32 + (kg >> 1) * 16));
+    const unsigned vst = (unsigned)(r0 * orow + (16 * hf + col) * 64 + (OUTF32 ? kg * 16 : (kg & 1) * 32 + (kg >> 1) * 16));
 
     // brick order: an image is cut into PATCHES of patch x patch bricks, ids run patch by patch (ragged patches at the right /
     // bottom edges are smaller): the 64 workgroups of an XCD, walking 64 consecutive ids at a time, then work on one compact
     // patch whose inner halos (2 x 4 of 18 rows, 2 x 4 of 34 columns per brick) come from that XCD's L2 instead of HBM again
-    // -- in row-major order a brick's vertical neighbours are a round away and the measured fetch was 1.40 x the tensor.
+    // -- in row-major order a brick's vertical neighbours are a round away and the measured fetch was 1.40 x the tensor
+    // (1.24 x in patches of 8 x 8).
 #define RB_DECODE(ID, N_, OH, OW)                                                        \
     {                                                                                    \
         const int per_img_ = a.tiles_h * a.tiles_w;                                      \
@@ -265,27 +267,29 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(dsc_, (__attribute__((address_space(3))) void*)(lds + (wave + 4 * m) * 1024), \
                                                      16, voff[m], 0, 0, MVSGI_RB_LD_AUX);                        \
     }
-#define RB_READ(IMGOFF, HF, P, BUFI)                                                                             \
+// fragments of tiles 4 G .. 4 G + NT - 1 under tap pair P
+#define RB_READ(RB, G, NT, P, BUFI)                                                                              \
     {                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
-            xh[BUFI][i] = *reinterpret_cast<const bf16x8*>(lds + rbp[P] + ((IMGOFF) + (i * IW + 16 * (HF)) * 32));          \
-            xl[BUFI][i] = *reinterpret_cast<const bf16x8*>(lds + rbp[P] + ((IMGOFF) + REGION + (i * IW + 16 * (HF)) * 32)); \
+        _Pragma("unroll") for (int i = 0; i < (NT); ++i) {                                                       \
+            xh[BUFI][i] = *reinterpret_cast<const bf16x8*>(lds + RB[P] + (4 * (G) + i) * TSTEP);                 \
+            xl[BUFI][i] = *reinterpret_cast<const bf16x8*>(lds + RB[P] + (4 * (G) + i) * TSTEP + REGION);        \
         }                                                                                                        \
     }
-// one convolution = 10 steps (2 column halves x 5 tap pairs) of 4 tiles x 3 products, fragments requested one step ahead
-#define RB_CONV(IMGOFF, WH, WL)                                                                                  \
+// one convolution = 10 steps (2 groups of tiles x 5 tap pairs) of up to 4 tiles x 3 products, fragments requested one step
+// ahead; NT1 = tiles of the second group (4: conv1's 8 tiles, 3: conv2's 7)
+#define RB_CONV(RB, WH, WL, NT1)                                                                                 \
     {                                                                                                            \
         bf16x8 xh[2][4], xl[2][4];                                                                               \
-        RB_READ(IMGOFF, 0, 0, 0)                                                                                 \
+        RB_READ(RB, 0, 4, 0, 0)                                                                                  \
         _Pragma("unroll") for (int st = 0; st < 10; ++st) {                                                      \
-            const int hf = st / 5, p = st % 5;                                                                   \
-            if (st + 1 < 10) RB_READ(IMGOFF, (st + 1) / 5, (st + 1) % 5, (st + 1) & 1)                           \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
-                acc[hf][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WL[p], xh[st & 1][i], acc[hf][i], 0, 0, 0); \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
-                acc[hf][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WH[p], xl[st & 1][i], acc[hf][i], 0, 0, 0); \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
-                acc[hf][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WH[p], xh[st & 1][i], acc[hf][i], 0, 0, 0); \
+            const int g = st / 5, p = st % 5, nt = g ? (NT1) : 4;                                                \
+            if (st + 1 < 10) RB_READ(RB, (st + 1) / 5, ((st + 1) / 5 ? (NT1) : 4), (st + 1) % 5, (st + 1) & 1)   \
+            _Pragma("unroll") for (int i = 0; i < nt; ++i)                                                       \
+                acc[4 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WL[p], xh[st & 1][i], acc[4 * g + i], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < nt; ++i)                                                       \
+                acc[4 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WH[p], xl[st & 1][i], acc[4 * g + i], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < nt; ++i)                                                       \
+                acc[4 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WH[p], xh[st & 1][i], acc[4 * g + i], 0, 0, 0); \
         }                                                                                                        \
     }
 
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
     int n_, oh0, ow0;
     RB_DECODE(id0, n_, oh0, ow0)
     RB_STAGE(n_, oh0, ow0)
-    f32x4 acc[2][4];
+    f32x4 acc[8];
     for (int u = 0; u < nmine; ++u) {
         int nn, noh, now;                          // the next brick (clamped: its request is skipped past the end)
         RB_DECODE(id0 + (u + 1 < nmine ? u + 1 : u) * idstep, nn, noh, now)
@@ -318,73 +322,62 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
         asm volatile("s_barrier" ::: "memory");   // window of brick u landed (every wave's pieces); conv1-result image free
         // ---- phase A: conv1 on the 16 x 32 region, result -> image B (zero outside the image: conv2's padding) ----
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[hf][i] = b1;
+        for (int k = 0; k < 8; ++k) acc[k] = b1;
         STAMP()
-        RB_CONV(0, w1h, w1l)
+        RB_CONV(rbp, w1h, w1l, 4)
         STAMP()
-        bf16x8 xres[2][4];                         // skip connection: window pixel (r + 2, c + 2) as an MFMA operand
+        bf16x8 xres[7];                            // skip connection: window pixel (r + 2, c + 2) as an MFMA operand
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
+        for (int k = 0; k < 8; ++k) {
+            f32x4 v = acc[k];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 v = acc[hf][i];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], a.neg_slope);
-                u32x2 hi, lo;
-                split4(v, hi, lo);
-                if (edge) {
-                    const int gh = oh0 - 1 + 4 * wave + i, gw = ow0 - 1 + 16 * hf + col;
-                    if (!(gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)) hi = lo = u32x2{0u, 0u};
-                }
-                *reinterpret_cast<u32x2*>(lds + wrb + (i * IW + 16 * hf) * 32) = hi;
-                *reinterpret_cast<u32x2*>(lds + wrb + (i * IW + 16 * hf) * 32 + REGION) = lo;
-                xres[hf][i] = *reinterpret_cast<const bf16x8*>(lds + rres + (i * IW + 16 * hf) * 32);
+            for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], a.neg_slope);
+            u32x2 hi, lo;
+            split4(v, hi, lo);
+            if (edge) {
+                const int gh = oh0 - 1 + r0 + 2 * k, gw = ow0 - 1 + 16 * hf + col;
+                if (!(gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)) hi = lo = u32x2{0u, 0u};
             }
+            *reinterpret_cast<u32x2*>(lds + wrb + k * TSTEP) = hi;
+            *reinterpret_cast<u32x2*>(lds + wrb + k * TSTEP + REGION) = lo;
+            if (k < 7) xres[k] = *reinterpret_cast<const bf16x8*>(lds + rres + k * TSTEP);
+        }
         STAMP()
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // conv1 result complete; every wave is done with the window
         if (u + 1 < nmine) RB_STAGE(nn, noh, now)  // lands under conv2
-        // ---- phase B: conv2 on the 14 x 30 brick (tile rows 14, 15 and columns 30, 31 are not stored) ----
+        // ---- phase B: conv2 on the 14 x 30 brick: 7 tiles per wave (columns 30, 31 of the right half are not stored) ----
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[hf][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ident, xres[hf][i], b2, 0, 0, 0);
+        for (int k = 0; k < 7; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ident, xres[k], b2, 0, 0, 0);
         STAMP()
-        RB_CONV(IMGA, w2h, w2l)
+        RB_CONV(rbq, w2h, w2l, 3)
         STAMP()
         {
             // output descriptor: base = the brick's first output pixel; lanes of columns >= 30 (or beyond the image) are masked
             // (an out-of-range voffset is no substitute: the scalar row offset is added before the range check and wraps),
-            // rows >= 14 (or beyond the image) are skipped (wave-uniform)
+            // rows beyond the image are skipped (wave-uniform)
             const long long off_ = OUTF32 ? (((long long)n_ * a.H + oh0) * a.W + ow0) * 64
                                           : (((long long)n_ * Hp + oh0 + PAD) * Wp + ow0 + PAD) * 64;
             const long long left_ = out_bytes - off_;
             const int rec_ = left_ > 0x7fffff00ll ? 0x7fffff00 : (int)left_;
             const auto dsc_ = __builtin_amdgcn_make_buffer_rsrc(a.y + off_, 0, rec_, 0x00020000);
-            bool okc[2];
+            const bool okc = 16 * hf + col < TOW && ow0 + 16 * hf + col < a.W;
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) okc[hf] = 16 * hf + col < TOW && ow0 + 16 * hf + col < a.W;
+            for (int k = 0; k < 7; ++k) {
+                f32x4 v = acc[k];
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 4 * wave + i;
-                    f32x4 v = acc[hf][i];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], a.neg_slope);
-                    u32x4 o;
-                    if constexpr (OUTF32) {
-                        o = __builtin_bit_cast(u32x4, v);
-                    } else {
-                        u32x2 hi, lo;
-                        split4(v, hi, lo);
-                        const u32x2 sa = __builtin_amdgcn_permlane16_swap(hi[0], lo[0], false, false);
-                        const u32x2 sb = __builtin_amdgcn_permlane16_swap(hi[1], lo[1], false, false);
-                        o = u32x4{sa[0], sb[0], sa[1], sb[1]};
-                    }
-                    if (okc[hf] && r < TOH && oh0 + r < a.H) __builtin_amdgcn_raw_buffer_store_b128(o, dsc_, vst[hf], i * orow, MVSGI_RB_ST_AUX);
+                for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], a.neg_slope);
+                u32x4 o;
+                if constexpr (OUTF32) {
+                    o = __builtin_bit_cast(u32x4, v);
+                } else {
+                    u32x2 hi, lo;
+                    split4(v, hi, lo);
+                    const u32x2 sa = __builtin_amdgcn_permlane16_swap(hi[0], lo[0], false, false);
+                    const u32x2 sb = __builtin_amdgcn_permlane16_swap(hi[1], lo[1], false, false);
+                    o = u32x4{sa[0], sb[0], sa[1], sb[1]};
                 }
+                if (okc && oh0 + r0 + 2 * k < a.H) __builtin_amdgcn_raw_buffer_store_b128(o, dsc_, vst, 2 * k * orow, MVSGI_RB_ST_AUX);
+            }
         }
         n_ = nn; oh0 = noh; ow0 = now;
     }

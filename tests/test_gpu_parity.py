@@ -1122,6 +1122,51 @@ def test_regulator_register_stationary_chain_matches_streaming_and_goldens(golde
         cr._RS_MIN_UNITS, cr._USE_RS = old_min, old_use
 
 
+def test_split_padded_hand_over_between_builder_and_regulator(golden_dir):
+    """The cost volume crossing the builder -> regulator boundary as a module-owned split-padded buffer (post_vol writes it, the
+    regulator's stride-2 first layer stages it by LDS-DMA) against the fp32-tensor boundary and the reference goldens; the
+    modules' own forward() keep the tensor interface; a batch of 3 with the hand-over equals the frames one by one."""
+    from mvs_gi_amd.dropin import cost_volume_regulator as cr
+    from mvs_gi_amd.dropin.torch_only import build_and_regulate
+    import parity_log
+    name = "std_d16_rand"
+    case = SMALL_CASES[name]
+    cfg, z = case["cfg"], _load(golden_dir, name)
+    inp = synth.make_inputs(cfg, seed=case["seed"], batch=case["batch"], grid_kind=case["grid_kind"],
+                            grid_mask_dtype=case["grid_mask_dtype"])
+    feats = _g(inp["feats"])
+    old_mode, old_use = H.get_conv_mode(), cr._USE_S2RS
+    try:
+        H.set_conv_mode("bf16x3")
+        for gain in case["gains"]:
+            w = synth.make_weights(cfg, seed=case["seed"], gain=gain)
+            outs = {}
+            for use in (False, True):
+                cr._USE_S2RS = use
+                hp = HotPath(cfg, w, inp, device=DEV)
+                outs[use] = hp(feats)[0].cpu().numpy()
+                assert ("_mvsgi_rs_x0" in hp.cv_builder.__dict__) == use             # the hand-over really ran / did not
+            ref = z[f"inv_dist_g{gain:g}"]
+            err = _rel(outs[True], ref)
+            parity_log.record(name + "(split hand-over)", "bf16x3", gain, err, _l1(outs[True], ref), "golden")
+            assert err <= 1e-3 and _rel(outs[True], outs[False]) <= 5e-4
+        cr._USE_S2RS = True
+        hp = HotPath(cfg, w, inp, device=DEV)
+        g, gm, m = hp.grids, hp.grid_masks, hp.masks
+        vol = hp.cv_builder(feats, g, gm, m)                      # the modules' tensor interface is unchanged
+        assert isinstance(vol, torch.Tensor) and vol.dtype == torch.float32 and vol.shape[1] == 16
+        costs_t = hp.cv_regulator(vol)
+        costs_s = build_and_regulate(hp.cv_builder, hp.cv_regulator, feats, g, gm, m)
+        assert _rel(costs_s.cpu().numpy(), costs_t.cpu().numpy()) <= 5e-4
+        f3 = torch.cat([feats, feats.flip(1), feats * 0.5], 0)
+        b3 = hp(f3)[0]
+        for i in range(3):
+            assert _rel(b3[i:i + 1].cpu().numpy(), hp(f3[i:i + 1].contiguous())[0].cpu().numpy()) <= 1e-5
+    finally:
+        H.set_conv_mode(old_mode)
+        cr._USE_S2RS = old_use
+
+
 def test_full_size_batch8_register_stationary_path_vs_reference_golden(golden_dir):
     """G16V at full size with 8 frames per launch: the batch at which bench.py's path (register-stationary level-0 convs)
     is active; every frame must reproduce the single-frame reference golden."""
