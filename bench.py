@@ -885,6 +885,18 @@ def run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, 
             hp(f.reshape(1, N, *f.shape[1:]))
         e1l = timed_steps(e1, sync, 100, 10, 1, False, dev)
         r["b1_ms"] = round(e1l / 100 * 1e3, 4)
+        # the same chain as ONE hipGraph replay (InferencePipeline.capture / replay do this for a deployment)
+        g1 = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            e1()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        with torch.cuda.graph(g1):
+            e1()
+        g1l = timed_steps(g1.replay, sync, 100, 10, 1, False, dev)
+        r["b1_graph_replay_ms"] = round(g1l / 100 * 1e3, 4)
+        del g1
         # host feed: uint8 frames in pinned memory, double-buffered H2D on a side stream overlapped with compute
         nbuf = 3
         host = [torch.from_numpy(rng.integers(0, 256, (B * N, 4 * Hi, 4 * Wi, 3), dtype=np.uint8)).pin_memory()

@@ -120,9 +120,55 @@ class InferencePipeline:
         imgs = input_dict["imgs"]
         if isinstance(imgs, list):
             imgs = np.stack(imgs, axis=0)                          # [N, H, W, 3] uint8 (one frame)
-        t = torch.from_numpy(np.ascontiguousarray(imgs)).to(self.hot.device)
+        t = torch.from_numpy(np.ascontiguousarray(imgs))
         if t.dtype != torch.uint8:
             raise TypeError("InferencePipeline expects uint8 HWC camera images")
-        f = self.feature_extractor(t)                              # [N, C, Hi, Wi], channels-last storage
+        g = getattr(self, "_graph", None)
+        if g is not None and tuple(t.shape) == tuple(self._static_imgs.shape):
+            self._static_imgs.copy_(t, non_blocking=True)          # the upload lands in the graph's input buffer
+            g.replay()
+            return self._static_inv.squeeze(0).squeeze(0).cpu().numpy()
+        return self.forward_device(t.to(self.hot.device)).squeeze(0).squeeze(0).cpu().numpy()
+
+    @torch.no_grad()
+    def forward_device(self, imgs_u8: torch.Tensor) -> torch.Tensor:
+        """uint8 [N, H, W, 3] images of one frame on the device -> inv_dist / bf [1, 1, H, W] on the device."""
+        f = self.feature_extractor(imgs_u8)                        # [N, C, Hi, Wi], channels-last storage
         inv, _ = self.hot(f.unsqueeze(0))
-        return inv.squeeze(0).squeeze(0).cpu().numpy()
+        return inv
+
+    # ---- hipGraph replay of the whole chain for one frame (the robot's operating point: one frame at a time) ----
+    @torch.no_grad()
+    def capture(self, imgs_u8: torch.Tensor) -> None:
+        """Capture extractor -> sweep -> regulator -> soft-argmin for images of this shape (uint8 [N, H, W, 3] on the device)
+        into one hipGraph: the ~80 launches of a frame are then one submission.  __call__ replays it for inputs of that
+        shape (the upload goes straight into the graph's input buffer); replay() is the device-side form."""
+        if imgs_u8.dtype != torch.uint8 or not imgs_u8.is_cuda:
+            raise TypeError("InferencePipeline.capture expects uint8 HWC camera images on the device")
+        dev = self.hot.device
+        self._graph = None
+        self._static_imgs = imgs_u8.clone()
+        self.forward_device(self._static_imgs)          # warm-up: weight packing, kernel attributes, module-owned buffers
+        torch.cuda.synchronize(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self.forward_device(self._static_imgs)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._static_inv = self.forward_device(self._static_imgs)
+        self._graph = graph
+
+    @torch.no_grad()
+    def replay(self, imgs_u8: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Replay the captured chain; returns the graph's static output (valid until the next replay)."""
+        if getattr(self, "_graph", None) is None:
+            raise RuntimeError("InferencePipeline.replay() before capture()")
+        if imgs_u8 is not None and imgs_u8.data_ptr() != self._static_imgs.data_ptr():
+            if tuple(imgs_u8.shape) != tuple(self._static_imgs.shape) or imgs_u8.dtype != torch.uint8:
+                raise ValueError(f"InferencePipeline.replay(): captured for images {tuple(self._static_imgs.shape)} uint8, got "
+                                 f"{tuple(imgs_u8.shape)} {imgs_u8.dtype}; capture() again")
+            self._static_imgs.copy_(imgs_u8, non_blocking=True)
+        self._graph.replay()
+        return self._static_inv

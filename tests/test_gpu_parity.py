@@ -749,6 +749,14 @@ def test_inference_pipeline_uint8_in_metric_out(golden_dir, conv_mode):
     err = _rel(out, z["inv_dist_over_bf"])
     print(f"pipeline u8 [{conv_mode}]: max-rel {err:.3e}")
     assert err <= 1e-3
+    # the whole chain as one hipGraph: the same numbers, also for other images of that shape, and through __call__
+    imgs = torch.from_numpy(np.stack(list(z["imgs_u8"]), 0)).to(DEV)
+    pipe.capture(imgs)
+    assert np.array_equal(pipe.replay(imgs).squeeze().cpu().numpy(), out)
+    other = imgs.flip(0).contiguous()
+    eager = pipe.forward_device(other).squeeze().cpu().numpy()
+    assert np.array_equal(pipe.replay(other).squeeze().cpu().numpy(), eager)
+    assert np.array_equal(pipe({"imgs": [im for im in z["imgs_u8"]]}), out)
 
 
 def test_inference_pipeline_with_sphere_extractor(conv_mode):
