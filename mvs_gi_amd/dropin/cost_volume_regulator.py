@@ -138,9 +138,10 @@ def down_block_ndhwc(blk, x) -> Tensor:
 # 128-cell bricks (low resolution) per launch for the polyphase form
 _USE_POLY = os.environ.get("MVSGI_POLY", "1") != "0"
 _HEAD_SPLIT = os.environ.get("MVSGI_HEAD_SPLIT", "1") != "0"      # 0: polyphase out_costs.0 writes fp32 and the exact-fp32 head reads it
-# (measured on MI355X, G16V: 400 bricks per frame and role; B = 4: 2722 vs 2837 frames/s with / without, B = 8: 3714 vs 3742, B = 16:
-# 4335 vs 4291, B = 64: 5091 vs 4820 -- three launches and a prologue + two drain phases per workgroup need ~12 frames to pay)
-_POLY_MIN_UNITS = int(os.environ.get("MVSGI_POLY_MIN_UNITS", "4800"))
+# (measured on MI355X, G16V, 400 bricks per frame and role, one hipGraph replay per step: 1 frame 0.506 vs 0.497 ms with / without,
+# 2 frames 0.779 vs 0.766, 4 frames 1.150 vs 1.167, 64 frames 12.57 vs 13.28 -- three launches and a prologue + two drain phases
+# per workgroup need ~4 frames to pay)
+_POLY_MIN_UNITS = int(os.environ.get("MVSGI_POLY_MIN_UNITS", "1600"))
 
 
 def _poly_tail(self, x: Tensor, skip: Tensor):
