@@ -162,12 +162,16 @@ def build(with_pairs, split=False):
         if not with_pairs:
             lo = max(lo, 30)
         S.place(lo, 4, f"fin[{op}] = acc[{op}]; RS_PIN_V(fin[{op}])", end=hi + 1, cap=5.0)
-    # split-padded output: the epilogue is three times as long (split + lane exchange), so the next brick's LDS-DMA is spread
-    # over the same slots FIRST (one piece every 6th slot from slot 38) and the epilogue fills the rest; nothing orders the two
-    # (the phase ends with vmcnt(0)).  With the DMA behind the epilogue (slot 113 on) post_vol took 312 instead of 284 us.
-    if with_pairs and split:
+    # The next brick's LDS-DMA goes FIRST: one piece every 10th slot from slot 6 (the image it lands in was released at the
+    # barrier), the epilogue fills the slots around it; nothing orders the two (the phase ends with vmcnt(0)).  The kernel has
+    # ONE window in flight per CU and a phase is about as long as a loaded HBM round trip, so every slot the requests go out
+    # earlier is time the phase's end does not wait: split-padded output 312 us with the DMA behind the epilogue (slot 113 on),
+    # 288 from slot 38, 265 from slot 6.
+    dma_start, dma_step = int(os.environ.get("RS16_DMA_START", "6")), int(os.environ.get("RS16_DMA_STEP", "10"))
+    early = os.environ.get("RS16_DMA_EARLY_F32", "1") == "1"
+    if with_pairs and (split or early):
         for m in range(14):
-            S.place(38 + 6 * m, 2.0, f"RS_F_DMA(RS16_DMA({m}))")
+            S.place(dma_start + dma_step * m, 2.0, f"RS_F_DMA(RS16_DMA({m}))")
     # epilogue: scale / shift, LeakyReLU, fp32 store -- one instruction per statement
     s = 36
     ep_end = s
@@ -197,7 +201,7 @@ def build(with_pairs, split=False):
                 s += 1
         ep_end = s
     # LDS-DMA of the next brick: 14 pieces per wave, after the epilogue's stores (the staging is then the youngest VMEM work)
-    if with_pairs and not split:
+    if with_pairs and not split and not early:
         s = ep_end + 2
         step = max((n - 40 - s) // 14, 3)
         for m in range(14):
