@@ -420,8 +420,11 @@ __device__ __forceinline__ Bilin quad_bcast(const Bilin& m) {
 // walks `dchunk` candidates, fetching the NEXT candidate's grid point and validity byte before the
 // 12 texel gathers of the current one, so a voxel costs one exposed memory round trip instead of
 // three.  Logical block order (b, ho, d-chunk, w-tile), XCD-contiguous (see sweep_xcd_remap).
+#ifndef MVSGI_SWEEP_WAVES
+#define MVSGI_SWEEP_WAVES 5      // waves per SIMD the register allocation aims at (experiment knob; 92 registers -> 5)
+#endif
 template <int NCAM, bool C16>
-__global__ __launch_bounds__(256) void sweep_std_nhwc_v_kernel(const float* __restrict__ feats,
+__global__ __launch_bounds__(256, MVSGI_SWEEP_WAVES) void sweep_std_nhwc_v_kernel(const float* __restrict__ feats,
                                                                const float* __restrict__ grids,
                                                                const unsigned char* __restrict__ vmask,
                                                                float* __restrict__ vol, SweepDims s, int dchunk,
