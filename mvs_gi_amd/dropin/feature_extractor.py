@@ -203,13 +203,12 @@ def _fusable_resblock(blk) -> bool:
 
 
 def _split2d_pair(self, N: int, Hh: int, W: int, device):
-    """Two zero-bordered 2-D split-padded buffers per resolution, owned by the module: the kernels write interiors only, so the
-    borders stay zero from one forward to the next."""
+    """Two zero-bordered 2-D split-padded buffers per (image count, resolution), owned by the module and NEVER replaced or freed
+    while it lives: the kernels write interiors only, so the borders stay zero from one forward to the next, and a captured
+    hipGraph (InferencePipeline.capture) holds their addresses."""
     cache = self.__dict__.setdefault("_mvsgi_split2d", {})
     key = (N, Hh, W, str(device))
     if key not in cache:
-        if len(cache) >= 4:
-            cache.clear()
         cache[key] = (H.split2d_buffer(N, Hh, W, device), H.split2d_buffer(N, Hh, W, device))
     return cache[key]
 
