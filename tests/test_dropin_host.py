@@ -176,3 +176,48 @@ def test_pickled_modules_do_not_carry_derived_caches():
     buf = io.BytesIO()
     torch.save(reg, buf)
     assert buf.tell() < 20 * 2 ** 20                                 # the 4 M-parameter regulator, nothing else
+
+
+def test_build_and_regulate_hand_over_decision():
+    """dropin/torch_only.py:build_and_regulate: the split-padded hand-over is used only when BOTH modules offer it, the regulator
+    takes the geometry and the builder produces the buffer; every other combination goes through the tensor interface."""
+    import torch
+    from mvs_gi_amd.dropin.torch_only import build_and_regulate
+    feats = torch.zeros(2, 3, 16, 4, 8)
+    grids = torch.zeros(2, 3, 5, 6, 7, 2)
+    calls = []
+
+    class Builder(torch.nn.Module):
+        def __init__(self, split, gives):
+            super().__init__()
+            if split:
+                self.forward_split = lambda *a: (calls.append("forward_split"), "XS" if gives else None)[1]
+
+        def forward(self, f, g, gm, m):
+            calls.append("builder")
+            return "VOL"
+
+    class Regulator(torch.nn.Module):
+        def __init__(self, split, takes):
+            super().__init__()
+            if split:
+                self.takes_split = lambda shape: (calls.append(("takes", tuple(shape))), takes)[1]
+                self.forward_split_in = lambda xs: (calls.append(("split_in", xs)), "COSTS_S")[1]
+
+        def forward(self, vol):
+            calls.append(("regulator", vol))
+            return "COSTS_T"
+
+    def run(bs, bg, rs, rt):
+        calls.clear()
+        return build_and_regulate(Builder(bs, bg), Regulator(rs, rt), feats, grids, None, None), list(calls)
+
+    out, c = run(True, True, True, True)
+    assert out == "COSTS_S" and c == [("takes", (2, 5, 6, 7, 16)), "forward_split", ("split_in", "XS")]
+    out, c = run(True, False, True, True)                    # the builder configuration does not produce the buffer
+    assert out == "COSTS_T" and c[-2:] == ["builder", ("regulator", "VOL")]
+    out, c = run(True, True, True, False)                    # the regulator does not take this geometry
+    assert out == "COSTS_T" and "forward_split" not in c
+    for bs, rs in ((False, True), (True, False), (False, False)):     # a foreign module on either side
+        out, c = run(bs, True, rs, True)
+        assert out == "COSTS_T" and c == ["builder", ("regulator", "VOL")]
