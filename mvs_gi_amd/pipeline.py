@@ -71,9 +71,12 @@ class HotPath:
         with torch.cuda.stream(side):
             self(self._static_in)
         torch.cuda.current_stream(self.device).wait_stream(side)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        graph = torch.cuda.CUDAGraph()
+        # thread-local error mode: another thread's CUDA calls (a process group's watchdog polling its events) must not
+        # invalidate this capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             self._static_out = self(self._static_in)
+        self._graph = graph
 
     def replay(self, feats: Optional[torch.Tensor] = None):
         """Replay the captured forward; returns the graph's static output tensors
@@ -156,7 +159,7 @@ class InferencePipeline:
             self.forward_device(self._static_imgs)
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             self._static_inv = self.forward_device(self._static_imgs)
         self._graph = graph
 
