@@ -1041,6 +1041,53 @@ def test_conv2d_out_split2d_matches_fp32_output():
         H.set_conv_mode(old_mode)
 
 
+def test_resblock2d_split_at_bench_size_matches_round2_block():
+    """K5 at the end-to-end bench's size (192 images of 256 x 1024: 3.3 GB tensors, byte offsets beyond 2^31, 127 680 bricks on a
+    persistent grid) against the round-2 fused block on fp32 activations, both output formats."""
+    N, Hh, W = 192, 256, 1024
+    g = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn((N, Hh, W, 16), device=DEV, generator=g)
+    w1 = torch.randn((16, 16, 3, 3), device=DEV, generator=g) / 12
+    w2 = torch.randn((16, 16, 3, 3), device=DEV, generator=g) / 12
+    sc1, sh1 = torch.rand(16, device=DEV, generator=g) + 0.5, torch.randn(16, device=DEV, generator=g) * 0.3
+    sc2, sh2 = torch.rand(16, device=DEV, generator=g) + 0.5, torch.randn(16, device=DEV, generator=g) * 0.3
+    ref = H.resblock2d(x, H.pack_conv2d_weights_bf16x3(w1), sc1, sh1, H.pack_conv2d_weights_bf16x3(w2), sc2, sh2, 0.01)
+    q1, q2 = H.pack_resblock2d_split_weights(w1, sc1), H.pack_resblock2d_split_weights(w2, sc2)
+    xs = H.f32_to_split2d(x)
+    del x
+    scale = float(ref.abs().max())
+    y = H.resblock2d_split(xs, q1, sh1, q2, sh2, 0.01)
+    assert float((y - ref).abs().max()) / scale <= 1e-4
+    del y
+    ys = H.resblock2d_split(xs, q1, sh1, q2, sh2, 0.01, out_split=H.split2d_buffer(N, Hh, W, DEV))
+    back = H.split2d_to_f32(ys)
+    assert float((back - ref).abs().max()) / scale <= 1e-4
+    assert int(ys[:, :2].count_nonzero()) == 0 and int(ys[:, -2:].count_nonzero()) == 0
+    assert int(ys[:, :, :2].count_nonzero()) == 0 and int(ys[:, :, -2:].count_nonzero()) == 0
+
+
+def test_conv2d_out_split2d_per_image_frames_at_bench_size():
+    """The stride-2 extractor layer at the end-to-end bench's size (192 images of 256 x 1024 x 16: beyond the one-volume 32-bit
+    offsets, so the launcher runs the images as frames): split-padded output == the split of the fp32 output, border zero."""
+    from mvs_gi_amd.dropin import feature_extractor as FE
+    mid = dropin.BaseConvBlk2d(16, 16, 3, stride=2, activation=torch.nn.LeakyReLU(), norm_layer=torch.nn.BatchNorm2d(16)).eval().to(DEV)
+    N, Hh, W = 192, 256, 1024
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn((N, Hh, W, 16), device=DEV, generator=g)
+    old_mode = H.get_conv_mode()
+    try:
+        H.set_conv_mode("bf16x3")
+        L = FE.lower_conv2d_block(mid)
+        y = L.run(x)
+        ys = L.run(x, out_split=H.split2d_buffer(N, Hh // 2, W // 2, x.device))
+    finally:
+        H.set_conv_mode(old_mode)
+    back = H.split2d_to_f32(ys)
+    assert float(((back - y).abs() / y.abs().clamp_min(1e-20)).max()) <= 2.0 ** -15
+    assert int(ys[:, :2].count_nonzero()) == 0 and int(ys[:, -2:].count_nonzero()) == 0
+    assert int(ys[:, :, :2].count_nonzero()) == 0 and int(ys[:, :, -2:].count_nonzero()) == 0
+
+
 # ------------------------------------------------------------------------------ register-stationary conv (csrc/conv3d_rs.hip)
 def test_split_padded_format_round_trip_and_border():
     rng = np.random.default_rng(3)
