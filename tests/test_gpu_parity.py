@@ -1253,6 +1253,22 @@ def test_full_size_batch8_register_stationary_path_vs_reference_golden(golden_di
             parity_log.record(f"full_G16V(B=8,rs)[{f}]", "bf16x3", gain, err, _l1(got[f:f + 1], ref), "golden")
             assert err <= 1e-3
         assert np.array_equal(got[0], got[7])
+        # bench.py's batch: 64 frames per launch (front end in chunks of 16, split-padded hand-over, hipGraph replay), every
+        # 8th frame scaled so that the frames differ: frames 0 and 63 reproduce the golden, a scaled frame its own single run
+        f64 = _g(inp["feats"]).expand(64, -1, -1, -1, -1).contiguous()
+        f64[5::8] *= 0.5
+        inv64 = hp(f64)[0]
+        g64 = inv64.cpu().numpy()
+        for f in (0, 63):
+            err = _rel(g64[f:f + 1], ref)
+            parity_log.record(f"full_G16V(B=64)[{f}]", "bf16x3", gain, err, _l1(g64[f:f + 1], ref), "golden")
+            assert err <= 1e-3
+        # equal inputs -> equal bits wherever the frame sits in the batch (chunks of 16, persistent walks); the scaled frames differ.
+        # (A batch of 4 or 1 takes other kernel variants -- other fp32 summation orders -- and lands 1.4e-4 away: not compared.)
+        assert np.array_equal(g64[0], g64[8]) and np.array_equal(g64[0], g64[63]) and np.array_equal(g64[5], g64[61])
+        assert not np.array_equal(g64[5], g64[0])
+        hp.capture(f64)
+        assert torch.equal(hp.replay()[0], inv64)
     finally:
         H.set_conv_mode(old)
         torch.cuda.empty_cache()
