@@ -74,6 +74,10 @@ __device__ __forceinline__ f32x4 s2_mfma(const bf16x8 a, const bf16x8 b, const f
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+#ifndef MVSGI_S2RS_DMA_SPREAD
+#define MVSGI_S2RS_DMA_SPREAD 1
+#endif
+
 namespace s2 {
 constexpr int TW = 16;                         // outputs per tile (one row)
 constexpr int IW = 2 * TW + 1;                 // 33 input columns: 17 even, then 16 odd, per LDS row
@@ -209,8 +213,14 @@ __global__ __launch_bounds__(256, (TH == 4 && NBUF == 2) ? 1 : 2) void conv3d_s2
         S2_DECODE(id0 + (u + 1 < nmine ? u + 1 : u) * idstep, nb, nod, noh, now)
         const int img = NBUF == 2 ? (u & 1) * IMG : 0;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");    // window u landed; every wave is done with window u - 1
-        if constexpr (NBUF == 2)
-            if (u + 1 < nmine) S2_STAGE(IMG - img, nb, nod, noh, now)                // lands under this brick's MFMAs and the next wait
+        // NBUF == 2: the window of brick u + 1 lands under this brick's MFMAs and the next wait.  Its pieces go out one per tap
+        // pair (DPW == kPairs for TH == 4) instead of in a burst behind the barrier, where the workgroup's 56 requests queue up in
+        // the CU's address path in front of the MFMAs (MVSGI_S2RS_DMA_SPREAD=0 restores the burst)
+        const bool more = u + 1 < nmine;
+        const auto dsc_n = s2_desc(a.x, (long long)nb * frame_bytes + (((long long)(2 * nod) * Hp + 2 * noh) * Wp + 2 * now) * 64, total_bytes);
+        constexpr bool SPREAD = NBUF == 2 && MVSGI_S2RS_DMA_SPREAD && DPW <= kPairs;
+        if constexpr (NBUF == 2 && !SPREAD)
+            if (more) { _Pragma("unroll") for (int m = 0; m < DPW; ++m) s2_dma_piece(dsc_n, lds + (IMG - img) + (wave + 4 * m) * 1024, voff[m]); }
         f32x4 acc[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) acc[i] = bsh;
@@ -225,6 +235,13 @@ __global__ __launch_bounds__(256, (TH == 4 && NBUF == 2) ? 1 : 2) void conv3d_s2
         S2_READ(0, 0)
 #pragma unroll
         for (int p = 0; p < kPairs; ++p) {
+            if constexpr (SPREAD) {
+                if (p < DPW) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) s2_dma_piece(dsc_n, lds + (IMG - img) + (wave + 4 * p) * 1024, voff[p]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             if (p + 1 < kPairs) S2_READ(p + 1, (p + 1) & 1)
 #pragma unroll
             for (int i = 0; i < TPW; ++i) acc[i] = s2_mfma(wl[p], xh[p & 1][i], acc[i]);

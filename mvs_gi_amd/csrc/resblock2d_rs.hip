@@ -69,6 +69,9 @@ __device__ __forceinline__ float lrelu(const float v, const float slope) {
 #ifndef MVSGI_RB_ST_AUX
 #define MVSGI_RB_ST_AUX 2     // cache policy bits of the output stores: nt (never re-read by this launch; 9.37 -> 9.22 ms per 32 frames)
 #endif
+#ifndef MVSGI_RB_DMA_SPREAD
+#define MVSGI_RB_DMA_SPREAD 2     // 0: all 10 pieces behind the barrier; 1: two per step over conv2's first five steps; 2: one per step
+#endif
 #ifndef MVSGI_RB_LD_AUX
 #define MVSGI_RB_LD_AUX 0     // cache policy bits of the window DMA (nt measured slower: the halos are re-read from L2)
 #endif
@@ -257,15 +260,20 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
         OW = (a.patch * C_ + px_) * TOW;                                                 \
     }
     // window of brick (n, oh0, ow0): origin = padded pixel (oh0, ow0) = image pixel (oh0 - 2, ow0 - 2)
-#define RB_STAGE(N_, OH, OW)                                                                                     \
-    {                                                                                                            \
+#define RB_DESC(N_, OH, OW)                                                                                      \
+    ({                                                                                                           \
         const long long off_ = (((long long)(N_) * Hp + (OH)) * Wp + (OW)) * 64;                                 \
         const long long left_ = total_bytes - off_;                                                              \
         const int rec_ = left_ > 0x7fffff00ll ? 0x7fffff00 : (int)left_;                                         \
-        const auto dsc_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.x) + off_, 0, rec_, 0x00020000); \
-        _Pragma("unroll") for (int m = 0; m < DPW; ++m)                                                          \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(dsc_, (__attribute__((address_space(3))) void*)(lds + (wave + 4 * m) * 1024), \
-                                                     16, voff[m], 0, 0, MVSGI_RB_LD_AUX);                        \
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.x) + off_, 0, rec_, 0x00020000);          \
+    })
+#define RB_PIECE(DSC, M)                                                                                         \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(DSC, (__attribute__((address_space(3))) void*)(lds + (wave + 4 * (M)) * 1024), \
+                                             16, voff[M], 0, 0, MVSGI_RB_LD_AUX);
+#define RB_STAGE(N_, OH, OW)                                                                                     \
+    {                                                                                                            \
+        const auto dsc_ = RB_DESC(N_, OH, OW);                                                                   \
+        _Pragma("unroll") for (int m = 0; m < DPW; ++m) RB_PIECE(dsc_, m)                                        \
     }
 // fragments of tiles 4 G .. 4 G + NT - 1 under tap pair P
 #define RB_READ(RB, G, NT, P, BUFI)                                                                              \
@@ -277,12 +285,14 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
     }
 // one convolution = 10 steps (2 groups of tiles x 5 tap pairs) of up to 4 tiles x 3 products, fragments requested one step
 // ahead; NT1 = tiles of the second group (4: conv1's 8 tiles, 3: conv2's 7)
-#define RB_CONV(RB, WH, WL, NT1)                                                                                 \
+#define RB_NOHOOK(ST)
+#define RB_CONV(RB, WH, WL, NT1, HOOK)                                                                           \
     {                                                                                                            \
         bf16x8 xh[2][4], xl[2][4];                                                                               \
         RB_READ(RB, 0, 4, 0, 0)                                                                                  \
         _Pragma("unroll") for (int st = 0; st < 10; ++st) {                                                      \
             const int g = st / 5, p = st % 5, nt = g ? (NT1) : 4;                                                \
+            HOOK(st)                                                                                             \
             if (st + 1 < 10) RB_READ(RB, (st + 1) / 5, ((st + 1) / 5 ? (NT1) : 4), (st + 1) % 5, (st + 1) & 1)   \
             _Pragma("unroll") for (int i = 0; i < nt; ++i)                                                       \
                 acc[4 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WL[p], xh[st & 1][i], acc[4 * g + i], 0, 0, 0); \
@@ -324,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] = b1;
         STAMP()
-        RB_CONV(rbp, w1h, w1l, 4)
+        RB_CONV(rbp, w1h, w1l, 4, RB_NOHOOK)
         STAMP()
         bf16x8 xres[7];                            // skip connection: window pixel (r + 2, c + 2) as an MFMA operand
 #pragma unroll
@@ -344,12 +354,35 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
         }
         STAMP()
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // conv1 result complete; every wave is done with the window
-        if (u + 1 < nmine) RB_STAGE(nn, noh, now)  // lands under conv2
+        // the window of brick u + 1 lands under conv2.  Its 10 pieces per wave go out one per step of conv2 (MVSGI_RB_DMA_SPREAD):
+        // issued in one burst behind the barrier, the workgroup's 40 requests queue up in the CU's address path and every wave
+        // sits ~2000 cycles in that segment (tools/rb_stamps.py): 8.95 ms per 32 frames in a burst, 8.70 two per step, 8.66 one
+        const bool more = u + 1 < nmine;
+        const auto dsc_n = RB_DESC(nn, noh, now);
+#if !MVSGI_RB_DMA_SPREAD
+        if (more) { _Pragma("unroll") for (int m = 0; m < DPW; ++m) RB_PIECE(dsc_n, m) }
+#define RB_DMAHOOK(ST)
+#elif MVSGI_RB_DMA_SPREAD == 2
+#define RB_DMAHOOK(ST)                                                                                           \
+            {                                                                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                if (more) { RB_PIECE(dsc_n, (ST)) }                                                              \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+            }
+#else
+#define RB_DMAHOOK(ST)                                                                                           \
+            if ((ST) < DPW / 2) {                                                                                \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                if (more) { RB_PIECE(dsc_n, 2 * (ST)) RB_PIECE(dsc_n, 2 * (ST) + 1) }                            \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+            }
+#endif
         // ---- phase B: conv2 on the 14 x 30 brick: 7 tiles per wave (columns 30, 31 of the right half are not stored) ----
 #pragma unroll
         for (int k = 0; k < 7; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ident, xres[k], b2, 0, 0, 0);
         STAMP()
-        RB_CONV(rbq, w2h, w2l, 3)
+        RB_CONV(rbq, w2h, w2l, 3, RB_DMAHOOK)
+#undef RB_DMAHOOK
         STAMP()
         {
             // output descriptor: base = the brick's first output pixel; lanes of columns >= 30 (or beyond the image) are masked
@@ -383,6 +416,9 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
     }
 #undef RB_DECODE
 #undef RB_STAGE
+#undef RB_DESC
+#undef RB_PIECE
+#undef RB_NOHOOK
 #undef RB_READ
 #undef RB_CONV
 }
