@@ -221,9 +221,14 @@ __global__ __launch_bounds__(256, (TH == 4 && NBUF == 2) ? 1 : 2) void conv3d_s2
         constexpr bool SPREAD = NBUF == 2 && MVSGI_S2RS_DMA_SPREAD && DPW <= kPairs;
         if constexpr (NBUF == 2 && !SPREAD)
             if (more) { _Pragma("unroll") for (int m = 0; m < DPW; ++m) s2_dma_piece(dsc_n, lds + (IMG - img) + (wave + 4 * m) * 1024, voff[m]); }
-        f32x4 acc[TPW];
+        // three accumulators per tile, one per product term: a tile's consecutive MFMAs then never wait for each other (with one
+        // accumulator per tile a wave has two dependent chains and the matrix pipe idles half of the time)
+        f32x4 acc[TPW], acc1[TPW], acc2[TPW];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) acc[i] = bsh;
+        for (int i = 0; i < TPW; ++i) {
+            acc[i] = bsh;
+            acc1[i] = acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         bf16x8 xh[2][TPW], xl[2][TPW];
 #define S2_READ(P, BUFI)                                                                                         \
     {                                                                                                            \
@@ -244,9 +249,9 @@ __global__ __launch_bounds__(256, (TH == 4 && NBUF == 2) ? 1 : 2) void conv3d_s2
             }
             if (p + 1 < kPairs) S2_READ(p + 1, (p + 1) & 1)
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) acc[i] = s2_mfma(wl[p], xh[p & 1][i], acc[i]);
+            for (int i = 0; i < TPW; ++i) acc1[i] = s2_mfma(wl[p], xh[p & 1][i], acc1[i]);
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) acc[i] = s2_mfma(wh[p], xl[p & 1][i], acc[i]);
+            for (int i = 0; i < TPW; ++i) acc2[i] = s2_mfma(wh[p], xl[p & 1][i], acc2[i]);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) acc[i] = s2_mfma(wh[p], xh[p & 1][i], acc[i]);
         }
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(256, (TH == 4 && NBUF == 2) ? 1 : 2) void conv3d_s2
             const bool okc = ow0 + col < a.Wo;
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                f32x4 v = acc[i];
+                f32x4 v = acc[i] + (acc1[i] + acc2[i]);          // the small terms first
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], a.neg_slope);
                 const u32x4 o = s2_pack_split(v);
