@@ -233,7 +233,7 @@ class ConvProbe:
             y = self.orig_s2rs(x, w_packed, shift, out, neg_slope)
             e.record()
             nvo = out.B * out.D * out.H * out.W
-            self.records.append(("conv3d_s2rs_kernel<4>", 2.0 * 27 * 16 * 32 * nvo, s, e, 4.0 * (16 * x.B * x.D * x.H * x.W + 32 * nvo)))
+            self.records.append(("conv3d_s2rs_kernel<4, 2>", 2.0 * 27 * 16 * 32 * nvo, s, e, 4.0 * (16 * x.B * x.D * x.H * x.W + 32 * nvo)))
             return y
 
         orig_poly, orig_up2s = H.conv3d_up2_poly, H.conv3d_up2_out_split
