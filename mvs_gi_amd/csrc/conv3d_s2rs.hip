@@ -215,7 +215,8 @@ __global__ __launch_bounds__(256, (TH == 4 && NBUF == 2) ? 1 : 2) void conv3d_s2
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");    // window u landed; every wave is done with window u - 1
         // NBUF == 2: the window of brick u + 1 lands under this brick's MFMAs and the next wait.  Its pieces go out one per tap
         // pair (DPW == kPairs for TH == 4) instead of in a burst behind the barrier, where the workgroup's 56 requests queue up in
-        // the CU's address path in front of the MFMAs (MVSGI_S2RS_DMA_SPREAD=0 restores the burst)
+        // the CU's address path in front of the MFMAs (MVSGI_S2RS_DMA_SPREAD=0 restores the burst: 559 vs 486 us per 64 frames).
+        // Four different issue points inside a pair for the four waves instead of one: 501 vs 493 us -- not kept
         const bool more = u + 1 < nmine;
         const auto dsc_n = s2_desc(a.x, (long long)nb * frame_bytes + (((long long)(2 * nod) * Hp + 2 * noh) * Wp + 2 * now) * 64, total_bytes);
         constexpr bool SPREAD = NBUF == 2 && MVSGI_S2RS_DMA_SPREAD && DPW <= kPairs;
