@@ -236,6 +236,10 @@ int mvsgi_resblock2d_split_pack_weights(const float* w_oihw, const float* scale,
 int mvsgi_resblock2d_split(const void* x_split, const void* w_packed1, const float* shift1,
                            const void* w_packed2, const float* shift2, void* y, int y_is_split,
                            int N, int H, int W, float neg_slope, mvsgi_stream_t stream);
+/* BaseConvBlk2d 16 -> 16, 3x3, stride 2 between two runs of residual blocks, split-padded in and out (w_packed from
+ * mvsgi_resblock2d_split_pack_weights): y_split [N][Ho+4][Wo+4][64 B], Ho = (H - 1) / 2 + 1 */
+int mvsgi_conv2d_s2_split(const void* x_split, const void* w_packed, const float* shift, void* y_split,
+                          int N, int H, int W, float neg_slope, mvsgi_stream_t stream);
 int mvsgi_conv2d_f32_out_split2d(const float* x, const float* w_oihw, const void* w_packed,
                                  const float* scale, const float* shift, const float* res, void* y_split,
                                  int B, int Cin, int Hin, int Win, int Cout, int ksize, int stride,

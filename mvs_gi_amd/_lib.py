@@ -61,6 +61,7 @@ SIGNATURES = {
     "mvsgi_resblock2d_split_packed_weight_bytes": (c_size_t, []),
     "mvsgi_resblock2d_split_pack_weights": (c_int, [_P, _P, _P, _P]),
     "mvsgi_resblock2d_split": (c_int, [_P] * 6 + [c_int] * 4 + [c_float, _P]),
+    "mvsgi_conv2d_s2_split": (c_int, [_P] * 4 + [c_int] * 3 + [c_float, _P]),
     "mvsgi_conv2d_f32_out_split2d": (c_int, [_P] * 7 + [c_int] * 7 + [c_float, c_int, c_int, _P]),
     "mvsgi_resize_trilinear_f32": (c_int, [_P, _P] + [c_int] * 8 + [_P]),
     "mvsgi_softargmin_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),

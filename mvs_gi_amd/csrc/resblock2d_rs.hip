@@ -456,7 +456,206 @@ int rb_launch(const RbArgs& a, hipStream_t st, const char* what) {
     return mvsgi::check_launch(what);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The extractor's stride-2 layer between its two runs of residual blocks (BaseConvBlk2d 16 -> 16, 3x3, stride 2, padding 1 +
+// BatchNorm + LeakyReLU; simple_feature_extractor.py:60-66) on the same format: the 3-D kernel of csrc/conv3d_s2rs.hip in two
+// dimensions.  A brick = 8 output rows x 16 columns, its window 17 x 33 input pixels, de-interleaved into even and odd columns by
+// the DMA's per-lane source addresses (a tile's 16 outputs then read unit-stride pixels for every tap); double-buffered windows
+// (72 KB: two workgroups per CU), one DMA piece in front of each MFMA group; wave w owns output rows 2 w, 2 w + 1; weights in
+// rb_pack_weights_kernel's order (scale folded in), shift = the accumulators' start value.  The layer is HBM-bound (reads the
+// full-resolution tensor once): with it the last block of the first run hands on split activations instead of fp32.
+// ---------------------------------------------------------------------------------------------
+namespace c2s {
+constexpr int TH = 8, TW = 16;                 // output brick
+constexpr int IHt = 2 * TH + 1, IW = 2 * TW + 1;   // window 17 x 33
+constexpr int NPX = IHt * IW;                  // 561
+constexpr int PIECES = (NPX + 31) / 32;        // 18 per region
+constexpr int REGION = PIECES * 1024;
+constexpr int IMG = 2 * REGION;                // 36,864
+constexpr int LDS_BYTES = 2 * IMG;
+constexpr int DPW = 2 * PIECES / 4;            // 9 pieces per wave
+static_assert(2 * PIECES % 4 == 0 && 2 * LDS_BYTES <= 160 * 1024, "geometry");
+}  // namespace c2s
+
+struct C2sArgs {
+    const unsigned char* x;    // [N][H+4][W+4][64]
+    unsigned char* y;          // [N][Ho+4][Wo+4][64]
+    const bf16x8* wp;
+    const float* shift;
+    int N, H, W, Ho, Wo;
+    int tiles_h, tiles_w, total_units;
+    float neg_slope;
+};
+
+__device__ __forceinline__ void c2s_dma_piece(const __amdgpu_buffer_rsrc_t dsc, unsigned char* lds_dst, const unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(dsc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void conv2d_s2rs_kernel(C2sArgs a) {
+    using namespace c2s;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, kg = lane >> 4;
+    const int Hp = a.H + 2 * rb::PAD, Wp = a.W + 2 * rb::PAD, Hop = a.Ho + 2 * rb::PAD, Wop = a.Wo + 2 * rb::PAD;
+    const long long total_bytes = (long long)a.N * Hp * Wp * 64, ototal_bytes = (long long)a.N * Hop * Wop * 64;
+    const int total = a.total_units, G = gridDim.x;
+    const int nmine = (total - (int)blockIdx.x + G - 1) / G;
+    const int id0 = G == total ? (int)blockIdx.x : rb_xcd_remap((int)blockIdx.x, total);
+    const int idstep = G == total ? 0 : G >> 3;
+
+    bf16x8 wh[5], wl[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        wh[p] = a.wp[(p * 2) * 64 + lane];
+        wl[p] = a.wp[(p * 2 + 1) * 64 + lane];
+    }
+    const f32x4 bsh = *reinterpret_cast<const f32x4*>(a.shift + kg * 4);
+    // tile i of this wave = output row 2 wave + i; lane (col, kg) reads chunk kg & 1 of window pixel (2 row + kh, 2 col + kw) under
+    // tap 2 p + (kg >> 1); a window row holds its 17 even columns, then its 16 odd ones
+    int rbp[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const int tA = 2 * p, tB = 2 * p + 1 < 9 ? 2 * p + 1 : 2 * p;
+        const int t = (kg >> 1) ? tB : tA;
+        const int kh = t / 3, kw = t % 3;
+        rbp[p] = ((4 * wave + kh) * IW + (kw & 1) * (TW + 1) + col + (kw >> 1)) * 32 + (kg & 1) * 16;
+    }
+    unsigned voff[DPW];
+#pragma unroll
+    for (int m = 0; m < DPW; ++m) {
+        const int q = wave + 4 * m;
+        const int region = q >= PIECES ? 1 : 0, j = q - region * PIECES;
+        const int v = 32 * j + (lane >> 1), chunk = lane & 1;
+        const int row = v / IW, e = v - row * IW;
+        const int c = e <= TW ? 2 * e : 2 * (e - TW - 1) + 1;
+        voff[m] = v < NPX ? (unsigned)((row * Wp + c) * 64 + region * 32 + chunk * 16) : 0xffffff00u;
+    }
+    const unsigned vst = (unsigned)((2 * wave * Wop + col) * 64 + (kg & 1) * 32 + (kg >> 1) * 16);
+
+#define C2S_DECODE(ID, N_, OH, OW)                               \
+    {                                                            \
+        int t_ = (ID);                                           \
+        OW = (t_ % a.tiles_w) * TW;                              \
+        t_ /= a.tiles_w;                                         \
+        OH = (t_ % a.tiles_h) * TH;                              \
+        N_ = t_ / a.tiles_h;                                     \
+    }
+    // window of brick (n, oh0, ow0): origin = padded input pixel (2 oh0 + 1, 2 ow0 + 1) = image pixel (2 oh0 - 1, 2 ow0 - 1)
+#define C2S_DESC(N_, OH, OW)                                                                                     \
+    ({                                                                                                           \
+        const long long off_ = (((long long)(N_) * Hp + 2 * (OH) + 1) * Wp + 2 * (OW) + 1) * 64;                 \
+        const long long left_ = total_bytes - off_;                                                              \
+        const int rec_ = left_ > 0x7fffff00ll ? 0x7fffff00 : (int)left_;                                         \
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.x) + off_, 0, rec_, 0x00020000);          \
+    })
+    int n_, oh0, ow0;
+    C2S_DECODE(id0, n_, oh0, ow0)
+    {
+        const auto d0_ = C2S_DESC(n_, oh0, ow0);
+#pragma unroll
+        for (int m = 0; m < DPW; ++m) c2s_dma_piece(d0_, lds + (wave + 4 * m) * 1024, voff[m]);
+    }
+    for (int u = 0; u < nmine; ++u) {
+        int nn, noh, now;
+        C2S_DECODE(id0 + (u + 1 < nmine ? u + 1 : u) * idstep, nn, noh, now)
+        const int img = (u & 1) * IMG;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");    // window u landed; every wave is done with window u - 1
+        const bool more = u + 1 < nmine;
+        const auto dsc_n = C2S_DESC(nn, noh, now);
+        f32x4 acc[2], acc1[2], acc2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            acc[i] = bsh;
+            acc1[i] = acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        bf16x8 xh[2][2], xl[2][2];
+#define C2S_READ(P, BUFI)                                                                                        \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
+            xh[BUFI][i] = *reinterpret_cast<const bf16x8*>(lds + img + rbp[P] + (2 * i * IW) * 32);              \
+            xl[BUFI][i] = *reinterpret_cast<const bf16x8*>(lds + img + rbp[P] + (2 * i * IW) * 32 + REGION);     \
+        }                                                                                                        \
+    }
+// the next window's pieces: one in front of each group of MFMAs (three groups per tap pair), never a burst
+#define C2S_DMA(K)                                                                                               \
+    if ((K) < DPW) {                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        if (more) c2s_dma_piece(dsc_n, lds + (IMG - img) + (wave + 4 * (K)) * 1024, voff[K]);                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }
+        C2S_READ(0, 0)
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            if (p + 1 < 5) C2S_READ(p + 1, (p + 1) & 1)
+            C2S_DMA(2 * p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[p], xh[p & 1][i], acc1[i], 0, 0, 0);
+            C2S_DMA(2 * p + 1)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[p], xl[p & 1][i], acc2[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[p], xh[p & 1][i], acc[i], 0, 0, 0);
+        }
+#undef C2S_READ
+#undef C2S_DMA
+        {
+            const long long off_ = (((long long)n_ * Hop + oh0 + rb::PAD) * Wop + ow0 + rb::PAD) * 64;
+            const long long left_ = ototal_bytes - off_;
+            const int rec_ = left_ > 0x7fffff00ll ? 0x7fffff00 : (int)left_;
+            const auto dsc_ = __builtin_amdgcn_make_buffer_rsrc(a.y + off_, 0, rec_, 0x00020000);
+            const bool okc = ow0 + col < a.Wo;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x4 v = acc[i] + (acc1[i] + acc2[i]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], a.neg_slope);
+                u32x2 hi, lo;
+                split4(v, hi, lo);
+                const u32x2 sa = __builtin_amdgcn_permlane16_swap(hi[0], lo[0], false, false);
+                const u32x2 sb = __builtin_amdgcn_permlane16_swap(hi[1], lo[1], false, false);
+                if (okc && oh0 + 2 * wave + i < a.Ho)
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{sa[0], sb[0], sa[1], sb[1]}, dsc_, vst, i * Wop * 64, MVSGI_RB_ST_AUX);
+            }
+        }
+        n_ = nn; oh0 = noh; ow0 = now;
+    }
+#undef C2S_DECODE
+#undef C2S_DESC
+}
+
 }  // namespace
+
+// BaseConvBlk2d 16 -> 16, 3x3, stride 2, padding 1 (+ scale folded into w_packed by mvsgi_resblock2d_split_pack_weights, + shift,
+// LeakyReLU) on 2-D split-padded activations: x_split [N][H+4][W+4][64 B] -> y_split [N][Ho+4][Wo+4][64 B], Ho = (H - 1) / 2 + 1.
+extern "C" int mvsgi_conv2d_s2_split(const void* x_split, const void* w_packed, const float* shift, void* y_split, int N, int H, int W,
+                                     float neg_slope, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(x_split && w_packed && shift && y_split, "mvsgi_conv2d_s2_split: null pointer");
+    MVSGI_REQUIRE(N > 0 && H > 0 && W > 0, "mvsgi_conv2d_s2_split: non-positive dimension");
+    MVSGI_REQUIRE(neg_slope >= 0.f && neg_slope <= 1.f, "mvsgi_conv2d_s2_split: negative slope %g outside [0, 1]", (double)neg_slope);
+    MVSGI_REQUIRE((long long)(c2s::IHt + 1) * (W + 2 * rb::PAD) * 64 < 0x7fffff00ll, "mvsgi_conv2d_s2_split: rows too long for 32-bit window offsets");
+    C2sArgs a{};
+    a.x = static_cast<const unsigned char*>(x_split);
+    a.y = static_cast<unsigned char*>(y_split);
+    a.wp = static_cast<const bf16x8*>(w_packed);
+    a.shift = shift;
+    a.N = N; a.H = H; a.W = W;
+    a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
+    a.neg_slope = neg_slope;
+    a.tiles_h = (int)mvsgi::cdiv(a.Ho, c2s::TH);
+    a.tiles_w = (int)mvsgi::cdiv(a.Wo, c2s::TW);
+    const long long nb = (long long)N * a.tiles_h * a.tiles_w;
+    MVSGI_REQUIRE(nb < (1ll << 31), "mvsgi_conv2d_s2_split: too many bricks");
+    a.total_units = (int)nb;
+    static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
+    mvsgi::PersistentGeom geo;
+    if (mvsgi::persistent_geometry(conv2d_s2rs_kernel, 256, c2s::LDS_BYTES, 2, geo_cache, "mvsgi_conv2d_s2_split", geo)) return 1;
+    long long resident = ((long long)geo.cus * geo.wgs_per_cu) / 8 * 8;
+    if (resident < 8) resident = 8;
+    hipLaunchKernelGGL(conv2d_s2rs_kernel, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), c2s::LDS_BYTES,
+                       mvsgi::as_stream(stream), a);
+    return mvsgi::check_launch("mvsgi_conv2d_s2_split");
+}
 
 extern "C" size_t mvsgi_split2d_bytes(int N, int H, int W) {
     return (size_t)N * (size_t)(H + 2 * rb::PAD) * (size_t)(W + 2 * rb::PAD) * 64;

@@ -213,15 +213,26 @@ def _split2d_pair(self, N: int, Hh: int, W: int, device):
     return cache[key]
 
 
+def _s2_split_ok(L) -> bool:
+    return L.k == 3 and L.stride == 2 and (L.cin, L.cout) == (16, 16) and 0.0 <= L.neg_slope <= 1.0
+
+
 def _split_chain_forward(self, xin: Tensor, with_final: bool = True) -> Optional[Tensor]:
     """The extractor with its residual blocks on pre-split activations (csrc/resblock2d_rs.hip): the layer in front of a run of
-    residual blocks writes the 2-D split-padded format, the blocks hand it on, the last block of a run writes fp32 for the
-    layer behind it.  None when this mode / recipe has no such run."""
+    residual blocks writes the 2-D split-padded format, the blocks hand it on, a stride-2 layer between two runs reads and
+    writes it (mvsgi_conv2d_s2_split), the last block in front of any other layer writes fp32.  None when this mode / recipe
+    has no such run."""
     if not (_SPLIT_CHAIN and H.get_conv_mode() == "bf16x3"):
         return None
     layers = [self.first] + list(self.blks) + ([self.final_layer] if with_final else [])
     fus = [hasattr(m, "blk1") and _fusable_resblock(m) for m in layers]
-    y, nchw, idx = xin, True, 0
+
+    def run_end(i):                                    # first index behind the run of fusable blocks that starts at i
+        while i < len(layers) and fus[i]:
+            i += 1
+        return i
+    y, nchw, idx = xin, True, 0                        # y: fp32 tensor (channels-last unless nchw) or a split-padded buffer
+    y_is_split = False
     while idx < len(layers):
         m = layers[idx]
         if hasattr(m, "blk1"):                       # a residual block with no split-writing layer in front of it
@@ -229,10 +240,11 @@ def _split_chain_forward(self, xin: Tensor, with_final: bool = True) -> Optional
             idx += 1
             continue
         L = lower_conv2d_block(m)
-        j = idx + 1
-        while j < len(layers) and fus[j]:
-            j += 1
-        if nchw:
+        j = run_end(idx + 1)
+        if y_is_split:                               # the stride-2 layer between two runs
+            N, Hin, Win = y.shape[0], y.shape[1] - 4, y.shape[2] - 4
+            can = True
+        elif nchw:
             N, Hin, Win = (y.shape[0], y.shape[1], y.shape[2]) if y.dtype == torch.uint8 else (y.shape[0], y.shape[2], y.shape[3])
             can = (L.k, L.stride, L.cin, L.cout) == (5, 2, 3, 16) and N < 65536
         else:
@@ -241,15 +253,22 @@ def _split_chain_forward(self, xin: Tensor, with_final: bool = True) -> Optional
         if j > idx + 1 and can:
             Ho, Wo = _calc((Hin, Win), L.k, L.stride, L.k // 2)
             cur, other = _split2d_pair(self, N, Ho, Wo, y.device)
-            cur = L.run(y, in_nchw=nchw, out_split=cur)
+            if y_is_split:
+                cur = H.conv2d_s2_split(y, L.rs_weights(), L.shift, cur, L.neg_slope)
+            else:
+                cur = L.run(y, in_nchw=nchw, out_split=cur)
+            # the run's last block hands on split activations when a stride-2 16 -> 16 layer with another run behind it follows
+            nxt_split = j < len(layers) and not hasattr(layers[j], "blk1") and _s2_split_ok(lower_conv2d_block(layers[j])) \
+                and run_end(j + 1) > j + 1
             for t in range(idx + 1, j):
                 L1, L2 = lower_conv2d_block(layers[t].blk1), lower_conv2d_block(layers[t].blk2)
                 last = t == j - 1
                 out = H.resblock2d_split(cur, L1.rs_weights(), L1.shift, L2.rs_weights(), L2.shift, L1.neg_slope,
-                                         out_split=None if last else other)
+                                         out_split=None if (last and not nxt_split) else other)
                 cur, other = out, cur
-            y, idx = cur, j
+            y, idx, y_is_split = cur, j, nxt_split
         else:
+            assert not y_is_split
             y = L.run(y, in_nchw=nchw)
             idx += 1
         nchw = False

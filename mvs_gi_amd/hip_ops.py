@@ -828,6 +828,20 @@ def resblock2d_split(x_split, wp1, shift1, wp2, shift2, neg_slope=0.01, out_spli
     return y
 
 
+def conv2d_s2_split(x_split, w_packed, shift, out_split, neg_slope=0.01) -> torch.Tensor:
+    """16 -> 16 channel 3x3 stride-2 layer on 2-D split-padded activations (weights from pack_resblock2d_split_weights)."""
+    lib = _lib.load()
+    N, Hp, Wp, _ = x_split.shape
+    Hh, W = Hp - 4, Wp - 4
+    _check_split2d(x_split, N, Hh, W, x_split.device)
+    _check_split2d(out_split, N, (Hh - 1) // 2 + 1, (W - 1) // 2 + 1, x_split.device)
+    if shift.numel() != 16:
+        raise AssertionError("conv2d_s2_split is the 16-channel layer")
+    _lib.check(lib.mvsgi_conv2d_s2_split(x_split.data_ptr(), w_packed.data_ptr(), shift.data_ptr(), out_split.data_ptr(), N, Hh, W,
+                                         float(neg_slope), _stream_ptr(x_split)), "mvsgi_conv2d_s2_split")
+    return out_split
+
+
 def resblock2d(x_nhwc, wp1, scale1, shift1, wp2, scale2, shift2, neg_slope=0.01) -> torch.Tensor:
     """Fused 16 -> 16 residual block (two 3x3 convs + BN + LeakyReLU + skip): x [N, H, W, 16] -> y, same shape."""
     lib = _lib.load()

@@ -1041,6 +1041,30 @@ def test_conv2d_out_split2d_matches_fp32_output():
         H.set_conv_mode(old_mode)
 
 
+@pytest.mark.parametrize("shape", [(1, 2, 2), (2, 16, 32), (3, 17, 33), (1, 9, 100), (5, 64, 256), (2, 35, 47), (4, 256, 1024)])
+def test_conv2d_s2_split_vs_reference_conv(shape):
+    """The extractor's stride-2 layer on 2-D split-padded activations (LDS-DMA staging, even / odd column de-interleave) against
+    conv2d(stride 2, padding 1) + scale / shift + LeakyReLU in float64 on the same (16-bit-split) input: even and odd sizes,
+    ragged bricks, several bricks per workgroup; the output's zero border untouched."""
+    N, Hh, W = shape
+    rng = np.random.default_rng(sum(shape) + 17)
+    x = _g(rng.standard_normal((N, Hh, W, 16), dtype=np.float32))
+    wt = (rng.standard_normal((16, 16, 3, 3)) / 12).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, 16).astype(np.float32), (rng.standard_normal(16) * 0.2).astype(np.float32)
+    xs = H.f32_to_split2d(x)
+    ho, wo = (Hh - 1) // 2 + 1, (W - 1) // 2 + 1
+    ys = H.conv2d_s2_split(xs, H.pack_resblock2d_split_weights(_g(wt), _g(sc)), _g(sh), H.split2d_buffer(N, ho, wo, x.device), 0.01)
+    y = H.split2d_to_f32(ys).cpu().numpy()
+    xq = H.split2d_to_f32(xs).cpu().double().permute(0, 3, 1, 2)
+    ref = F.conv2d(xq, torch.from_numpy(wt).double(), padding=1, stride=2) * torch.from_numpy(sc).double().view(1, -1, 1, 1) \
+        + torch.from_numpy(sh).double().view(1, -1, 1, 1)
+    ref = torch.where(ref > 0, ref, ref * 0.01).permute(0, 2, 3, 1).numpy()
+    assert _rel(y, ref) <= 1e-4
+    border = ys.clone()
+    border[:, 2:-2, 2:-2] = 0
+    assert int(border.count_nonzero()) == 0
+
+
 def test_resblock2d_split_at_bench_size_matches_round2_block():
     """K5 at the end-to-end bench's size (192 images of 256 x 1024: 3.3 GB tensors, byte offsets beyond 2^31, 127 680 bricks on a
     persistent grid) against the round-2 fused block on fp32 activations, both output formats."""
