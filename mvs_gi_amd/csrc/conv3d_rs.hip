@@ -26,6 +26,12 @@
 //   x = hi + lo, hi = bf16(x) (RNE), lo = bf16(x - hi): 16-17 significant bits, the same 4 B per element as fp32;
 //   the border voxels are zero and never written (the convolution's padding).
 #include "common.hpp"
+#ifndef MVSGI_RS_NT3
+#define MVSGI_RS_NT3 0       // cache policy of the polyphase layer's output stores (2 = nt: measured slower, 1742 -> 1772 us)
+#endif
+#ifndef MVSGI_RS16_NT
+#define MVSGI_RS16_NT 2      // post_vol's output stores: nt (276 -> 272 us, and the stride-2 kernel behind it 491 -> 484)
+#endif
 
 #include <cstring>
 #ifdef MVSGI_RS_STAMPS
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 #if MVSGI_RS_ABL & 8      // no output stores (the value is kept alive)
 #define RS_F_STORE(V, D, O) { u32x4 v_ = V; asm volatile("" ::"v"(v_)); }
 #else
-#define RS_F_STORE(V, D, O) __builtin_amdgcn_raw_buffer_store_b128(V, D, O, 0, 0);
+#define RS_F_STORE(V, D, O) __builtin_amdgcn_raw_buffer_store_b128(V, D, O, 0, (MODE == 3 ? MVSGI_RS_NT3 : 0));
 #endif
 #if MVSGI_RS_ABL & 16     // no residual requests
 #define RS_F_RES(R, D, O)
@@ -714,7 +720,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
 // front of asm MFMAs whose hazards it cannot pad
 #define RS_MF0(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG));
 #define RS_PIN_V(V) asm volatile("" : "+v"(V));
-#define RS_F_STORE16(V, D, O) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, V), D, O, 0, 0);
+#define RS_F_STORE16(V, D, O) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, V), D, O, 0, MVSGI_RS16_NT);
 #define RS16_F_SPL(...) if constexpr (OSPLIT) { __VA_ARGS__ }
 #define RS16_F_F32(...) if constexpr (!OSPLIT) { __VA_ARGS__ }
 

@@ -11,6 +11,9 @@
 // norm_costs (training only; inference discards it, spherical_sweep_stereo.py:266).  The 4 source pixels of neighbouring lanes coincide or
 // are adjacent, so every candidate plane is read once from HBM and served from L1/L2 after.
 #include "common.hpp"
+#ifndef MVSGI_SA_NT
+#define MVSGI_SA_NT 1      // norm_costs leaves with nt stores (435 MB per 64 frames nothing on the path reads back): 164 -> 157 us
+#endif
 
 #include <cstdlib>
 
@@ -242,7 +245,11 @@ __global__ __launch_bounds__(DMAX == 32 ? 512 : 640) void softargmin_rows_kernel
             for (int d = 0; d < DMAX; ++d) {
                 if (d < D) {
                     if (vec) {
+#if MVSGI_SA_NT
+                        __builtin_nontemporal_store(f32x4{v[d][0] * rs[0], v[d][1] * rs[1], v[d][2] * rs[2], v[d][3] * rs[3]}, reinterpret_cast<f32x4*>(np + d * OHW));
+#else
                         *reinterpret_cast<f32x4*>(np + d * OHW) = f32x4{v[d][0] * rs[0], v[d][1] * rs[1], v[d][2] * rs[2], v[d][3] * rs[3]};
+#endif
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
