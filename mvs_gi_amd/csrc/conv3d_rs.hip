@@ -26,6 +26,9 @@
 //   x = hi + lo, hi = bf16(x) (RNE), lo = bf16(x - hi): 16-17 significant bits, the same 4 B per element as fp32;
 //   the border voxels are zero and never written (the convolution's padding).
 #include "common.hpp"
+#ifndef MVSGI_RS_NT0
+#define MVSGI_RS_NT0 0       // cache policy of the 32 -> 32 layers' output stores (2 = nt: measured slower, the next layer reads them)
+#endif
 #ifndef MVSGI_RS_NT3
 #define MVSGI_RS_NT3 0       // cache policy of the polyphase layer's output stores (2 = nt: measured slower, 1742 -> 1772 us)
 #endif
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 #if MVSGI_RS_ABL & 8      // no output stores (the value is kept alive)
 #define RS_F_STORE(V, D, O) { u32x4 v_ = V; asm volatile("" ::"v"(v_)); }
 #else
-#define RS_F_STORE(V, D, O) __builtin_amdgcn_raw_buffer_store_b128(V, D, O, 0, (MODE == 3 ? MVSGI_RS_NT3 : 0));
+#define RS_F_STORE(V, D, O) __builtin_amdgcn_raw_buffer_store_b128(V, D, O, 0, (MODE == 3 ? MVSGI_RS_NT3 : MVSGI_RS_NT0));
 #endif
 #if MVSGI_RS_ABL & 16     // no residual requests
 #define RS_F_RES(R, D, O)

@@ -21,6 +21,10 @@
 
 #include <cstdlib>
 
+#ifndef MVSGI_S2RS_ST_AUX
+#define MVSGI_S2RS_ST_AUX 0     // cache policy bits of the output stores (2 = nt: measured neutral to slower)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -60,7 +64,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t s2_desc(const unsigned char* b
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base) + off, 0, rec, 0x00020000);
 }
 __device__ __forceinline__ void s2_store16(const u32x4 v, const __amdgpu_buffer_rsrc_t dsc, const unsigned voff, const int soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, dsc, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, dsc, voff, soff, MVSGI_S2RS_ST_AUX);
 }
 __device__ __forceinline__ u32x4 s2_pack_split(const f32x4 v) {
     // hi | lo of four channels; lanes kg and kg ^ 1 trade halves: kg even ends up with hi / lo of channels 8 (kg >> 1) .. + 7

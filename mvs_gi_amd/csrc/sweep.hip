@@ -420,6 +420,9 @@ __device__ __forceinline__ Bilin quad_bcast(const Bilin& m) {
 // walks `dchunk` candidates, fetching the NEXT candidate's grid point and validity byte before the
 // 12 texel gathers of the current one, so a voxel costs one exposed memory round trip instead of
 // three.  Logical block order (b, ho, d-chunk, w-tile), XCD-contiguous (see sweep_xcd_remap).
+#ifndef MVSGI_SWEEP_NT
+#define MVSGI_SWEEP_NT 0      // nt stores of the split-padded volume: measured neutral (post_vol reads it straight back)
+#endif
 #ifndef MVSGI_SWEEP_WAVES
 #define MVSGI_SWEEP_WAVES 5      // waves per SIMD the register allocation aims at (experiment knob; 92 registers -> 5)
 #endif
@@ -606,7 +609,14 @@ __global__ __launch_bounds__(256, MVSGI_SWEEP_WAVES) void sweep_std_nhwc_v_kerne
 #else
                 if (live) {
 #endif
+#if MVSGI_SWEEP_NT
+                    {
+                        typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(nt_u32x4{piece.x, piece.y, piece.z, piece.w}, reinterpret_cast<nt_u32x4*>(os));
+                    }
+#else
                     *reinterpret_cast<uint4*>(os) = piece;
+#endif
                 }
             } else if (live) *reinterpret_cast<f32x4_t*>(reinterpret_cast<char*>(o) + cb) = r;
         }
