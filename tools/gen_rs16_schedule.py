@@ -162,12 +162,12 @@ def build(with_pairs, split=False):
         if not with_pairs:
             lo = max(lo, 30)
         S.place(lo, 4, f"fin[{op}] = acc[{op}]; RS_PIN_V(fin[{op}])", end=hi + 1, cap=5.0)
-    # The next brick's LDS-DMA goes FIRST: one piece every 10th slot from slot 6 (the image it lands in was released at the
+    # The next brick's LDS-DMA goes FIRST: one piece every 12th slot from slot 6 (the image it lands in was released at the
     # barrier), the epilogue fills the slots around it; nothing orders the two (the phase ends with vmcnt(0)).  The kernel has
     # ONE window in flight per CU and a phase is about as long as a loaded HBM round trip, so every slot the requests go out
     # earlier is time the phase's end does not wait: split-padded output 312 us with the DMA behind the epilogue (slot 113 on),
-    # 288 from slot 38, 265 from slot 6.
-    dma_start, dma_step = int(os.environ.get("RS16_DMA_START", "6")), int(os.environ.get("RS16_DMA_STEP", "10"))
+    # 288 from slot 38, 269 from slot 6 every 10th slot, 264 every 12th.
+    dma_start, dma_step = int(os.environ.get("RS16_DMA_START", "6")), int(os.environ.get("RS16_DMA_STEP", "12"))
     early = os.environ.get("RS16_DMA_EARLY_F32", "1") == "1"
     if with_pairs and (split or early):
         for m in range(14):
