@@ -183,11 +183,9 @@ def build(with_pairs: bool):
         # from the phase's first block on: the image the pieces land in was released at the barrier (its last fragments were
         # read in the previous phase); one block earlier than before = 3 % less time in the fp32-output variant, 0.5 % overall
         b0 = int(os.environ.get("RS_DMA_FIRST_PAIR", "0"))
-        for b in range(b0, b0 + 8):
-            for pos in (10, 22):
-                if m < 15:
-                    S.place(b * 24 + pos, 2.0, f"RS_F_DMA(RS_DMA({m}))")
-                    m += 1
+        step = int(os.environ.get("RS_DMA_STEP", "12"))
+        for m in range(15):
+            S.place(b0 * 24 + 10 + step * m, 2.0, f"RS_F_DMA(RS_DMA({m}))")
     # G. epilogue of the brick two phases back: in program order, wherever a slot has room, from pair 1 on
     s = 2 * 24
     last = s
