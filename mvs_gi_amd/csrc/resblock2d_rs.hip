@@ -69,6 +69,9 @@ __device__ __forceinline__ float lrelu(const float v, const float slope) {
 #ifndef MVSGI_RB_ST_AUX
 #define MVSGI_RB_ST_AUX 2     // cache policy bits of the output stores: nt (never re-read by this launch; 9.37 -> 9.22 ms per 32 frames)
 #endif
+#ifndef MVSGI_RB_EPI_OVERLAP
+#define MVSGI_RB_EPI_OVERLAP 1
+#endif
 #ifndef MVSGI_RB_DMA_SPREAD
 #define MVSGI_RB_DMA_SPREAD 2     // 0: all 10 pieces behind the barrier; 1: two per step over conv2's first five steps; 2: one per step
 #endif
@@ -333,25 +336,36 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
         // ---- phase A: conv1 on the 16 x 32 region, result -> image B (zero outside the image: conv2's padding) ----
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] = b1;
-        STAMP()
-        RB_CONV(rbp, w1h, w1l, 4, RB_NOHOOK)
-        STAMP()
+        // the epilogue of a tile whose accumulation is complete (group 0: tiles 0 .. 3, after step 4) is written INTO the steps of
+        // group 1 (MVSGI_RB_EPI_OVERLAP): its ~25 vector instructions then sit between that step's MFMAs instead of behind the
+        // whole convolution
         bf16x8 xres[7];                            // skip connection: window pixel (r + 2, c + 2) as an MFMA operand
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            f32x4 v = acc[k];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], a.neg_slope);
-            u32x2 hi, lo;
-            split4(v, hi, lo);
-            if (edge) {
-                const int gh = oh0 - 1 + r0 + 2 * k, gw = ow0 - 1 + 16 * hf + col;
-                if (!(gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)) hi = lo = u32x2{0u, 0u};
-            }
-            *reinterpret_cast<u32x2*>(lds + wrb + k * TSTEP) = hi;
-            *reinterpret_cast<u32x2*>(lds + wrb + k * TSTEP + REGION) = lo;
-            if (k < 7) xres[k] = *reinterpret_cast<const bf16x8*>(lds + rres + k * TSTEP);
+#define RB_EPI_A(K)                                                                                              \
+        {                                                                                                        \
+            f32x4 v = acc[K];                                                                                    \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], a.neg_slope);                       \
+            u32x2 hi, lo;                                                                                        \
+            split4(v, hi, lo);                                                                                   \
+            if (edge) {                                                                                          \
+                const int gh = oh0 - 1 + r0 + 2 * (K), gw = ow0 - 1 + 16 * hf + col;                             \
+                if (!(gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)) hi = lo = u32x2{0u, 0u};                      \
+            }                                                                                                    \
+            *reinterpret_cast<u32x2*>(lds + wrb + (K) * TSTEP) = hi;                                             \
+            *reinterpret_cast<u32x2*>(lds + wrb + (K) * TSTEP + REGION) = lo;                                    \
+            if ((K) < 7) xres[(K) < 7 ? (K) : 0] = *reinterpret_cast<const bf16x8*>(lds + rres + (K) * TSTEP);   \
         }
+#if MVSGI_RB_EPI_OVERLAP
+#define RB_HOOK_A(ST) if ((ST) >= 5 && (ST) < 9) RB_EPI_A((ST) - 5)
+#else
+#define RB_HOOK_A(ST)
+#endif
+        STAMP()
+        RB_CONV(rbp, w1h, w1l, 4, RB_HOOK_A)
+        STAMP()
+#pragma unroll
+        for (int k = MVSGI_RB_EPI_OVERLAP ? 4 : 0; k < 8; ++k) RB_EPI_A(k)
+#undef RB_HOOK_A
+#undef RB_EPI_A
         STAMP()
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // conv1 result complete; every wave is done with the window
         // the window of brick u + 1 lands under conv2.  Its 10 pieces per wave go out one per step of conv2 (MVSGI_RB_DMA_SPREAD):
@@ -359,6 +373,33 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
         // sits ~2000 cycles in that segment (tools/rb_stamps.py): 8.95 ms per 32 frames in a burst, 8.70 two per step, 8.66 one
         const bool more = u + 1 < nmine;
         const auto dsc_n = RB_DESC(nn, noh, now);
+        // output descriptor: base = the brick's first output pixel; lanes of columns >= 30 (or beyond the image) are masked
+        // (an out-of-range voffset is no substitute: the scalar row offset is added before the range check and wraps),
+        // rows beyond the image are skipped (wave-uniform)
+        const long long ooff_ = OUTF32 ? (((long long)n_ * a.H + oh0) * a.W + ow0) * 64
+                                       : (((long long)n_ * Hp + oh0 + PAD) * Wp + ow0 + PAD) * 64;
+        const long long oleft_ = out_bytes - ooff_;
+        const auto dsc_o = __builtin_amdgcn_make_buffer_rsrc(a.y + ooff_, 0, oleft_ > 0x7fffff00ll ? 0x7fffff00 : (int)oleft_, 0x00020000);
+        const bool okc = 16 * hf + col < TOW && ow0 + 16 * hf + col < a.W;
+#define RB_EPI_B(K)                                                                                              \
+        {                                                                                                        \
+            f32x4 v = acc[K];                                                                                    \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], a.neg_slope);                       \
+            u32x4 o;                                                                                             \
+            if constexpr (OUTF32) {                                                                              \
+                o = __builtin_bit_cast(u32x4, v);                                                                \
+            } else {                                                                                             \
+                u32x2 hi, lo;                                                                                    \
+                split4(v, hi, lo);                                                                               \
+                const u32x2 sa = __builtin_amdgcn_permlane16_swap(hi[0], lo[0], false, false);                   \
+                const u32x2 sb = __builtin_amdgcn_permlane16_swap(hi[1], lo[1], false, false);                   \
+                o = u32x4{sa[0], sb[0], sa[1], sb[1]};                                                           \
+            }                                                                                                    \
+            /* masked lanes / rows get an offset beyond num_records (no scalar offset here: it would be added before the   */ \
+            /* range check and wrap): no exec-mask region, so the store can sit between the MFMAs                          */ \
+            const unsigned so_ = (okc && oh0 + r0 + 2 * (K) < a.H) ? vst + (unsigned)(2 * (K) * orow) : 0xffffff00u;      \
+            __builtin_amdgcn_raw_buffer_store_b128(o, dsc_o, so_, 0, MVSGI_RB_ST_AUX);                           \
+        }
 #if !MVSGI_RB_DMA_SPREAD
         if (more) { _Pragma("unroll") for (int m = 0; m < DPW; ++m) RB_PIECE(dsc_n, m) }
 #define RB_DMAHOOK(ST)
@@ -377,41 +418,22 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
                 __builtin_amdgcn_sched_barrier(0);                                                               \
             }
 #endif
+#if MVSGI_RB_EPI_OVERLAP
+#define RB_HOOK_B(ST) RB_DMAHOOK(ST) if ((ST) >= 5 && (ST) < 9) RB_EPI_B((ST) - 5)
+#else
+#define RB_HOOK_B(ST) RB_DMAHOOK(ST)
+#endif
         // ---- phase B: conv2 on the 14 x 30 brick: 7 tiles per wave (columns 30, 31 of the right half are not stored) ----
 #pragma unroll
         for (int k = 0; k < 7; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ident, xres[k], b2, 0, 0, 0);
         STAMP()
-        RB_CONV(rbq, w2h, w2l, 3, RB_DMAHOOK)
-#undef RB_DMAHOOK
+        RB_CONV(rbq, w2h, w2l, 3, RB_HOOK_B)
         STAMP()
-        {
-            // output descriptor: base = the brick's first output pixel; lanes of columns >= 30 (or beyond the image) are masked
-            // (an out-of-range voffset is no substitute: the scalar row offset is added before the range check and wraps),
-            // rows beyond the image are skipped (wave-uniform)
-            const long long off_ = OUTF32 ? (((long long)n_ * a.H + oh0) * a.W + ow0) * 64
-                                          : (((long long)n_ * Hp + oh0 + PAD) * Wp + ow0 + PAD) * 64;
-            const long long left_ = out_bytes - off_;
-            const int rec_ = left_ > 0x7fffff00ll ? 0x7fffff00 : (int)left_;
-            const auto dsc_ = __builtin_amdgcn_make_buffer_rsrc(a.y + off_, 0, rec_, 0x00020000);
-            const bool okc = 16 * hf + col < TOW && ow0 + 16 * hf + col < a.W;
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                f32x4 v = acc[k];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], a.neg_slope);
-                u32x4 o;
-                if constexpr (OUTF32) {
-                    o = __builtin_bit_cast(u32x4, v);
-                } else {
-                    u32x2 hi, lo;
-                    split4(v, hi, lo);
-                    const u32x2 sa = __builtin_amdgcn_permlane16_swap(hi[0], lo[0], false, false);
-                    const u32x2 sb = __builtin_amdgcn_permlane16_swap(hi[1], lo[1], false, false);
-                    o = u32x4{sa[0], sb[0], sa[1], sb[1]};
-                }
-                if (okc && oh0 + r0 + 2 * k < a.H) __builtin_amdgcn_raw_buffer_store_b128(o, dsc_, vst, 2 * k * orow, MVSGI_RB_ST_AUX);
-            }
-        }
+        for (int k = MVSGI_RB_EPI_OVERLAP ? 4 : 0; k < 7; ++k) RB_EPI_B(k)
+#undef RB_HOOK_B
+#undef RB_DMAHOOK
+#undef RB_EPI_B
         n_ = nn; oh0 = noh; ow0 = now;
     }
 #undef RB_DECODE
