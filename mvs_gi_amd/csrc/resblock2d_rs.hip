@@ -214,18 +214,26 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
     //      k = 0 .. 6 in conv2 (the 14 stored rows: no tile is computed for rows 14, 15), every offset between them an immediate.
     //      lane (col, kg) reads chunk kg & 1 of the pixel under tap 2 p + (kg >> 1) ----
     const int hf = wave & 1, r0 = wave >> 1;
-    int rbp[5], rbq[5];           // window / conv1-result image (the latter's base does not fit the 16-bit immediates)
+    // The conv1-result image swaps the two 16-byte chunks of every second group of four pixels (chunk c of pixel v sits at
+    // c ^ ((v >> 2) & 1)): the epilogue's 8-byte writes (16 lanes x 32-byte pitch) are then 2-way instead of 4-way bank
+    // conflicts, the fragment reads stay conflict-free.  A wave's tiles are 68 pixels apart, so the swap alternates with the
+    // tile index: one address set for even tiles, one for odd.
+    int rbp[5], rbq[5], rbqo[5];  // window / conv1-result image (even, odd tiles; its base does not fit the 16-bit immediates)
 #pragma unroll
     for (int p = 0; p < 5; ++p) {
         const int tA = 2 * p, tB = 2 * p + 1 < 9 ? 2 * p + 1 : 2 * p;
         const int t = (kg >> 1) ? tB : tA;
-        rbp[p] = ((r0 + t / 3) * IW + 16 * hf + col + t % 3) * 32 + (kg & 1) * 16;
-        rbq[p] = rbp[p] + IMGA;
+        const int v = (r0 + t / 3) * IW + 16 * hf + col + t % 3;
+        rbp[p] = v * 32 + (kg & 1) * 16;
+        rbq[p] = IMGA + v * 32 + (((kg & 1) ^ ((v >> 2) & 1)) << 4);
+        rbqo[p] = rbq[p] ^ 16;
     }
     // skip connection: window pixel (r + 2, c + 2), 16-byte chunk kg & 1 of the HI (kg < 2) or LO region
     const int rres = ((r0 + 2) * IW + 16 * hf + col + 2) * 32 + (kg & 1) * 16 + (kg >> 1) * REGION;
     // conv1 result -> image B: region pixel (r, c), this lane's channels 4 kg .. 4 kg + 3 (8 bytes of hi, 8 of lo)
-    const int wrb = IMGA + (r0 * IW + 16 * hf + col) * 32 + kg * 8;
+    const int wv0 = r0 * IW + 16 * hf + col;
+    const int wrb = IMGA + wv0 * 32 + ((((kg >> 1) ^ ((wv0 >> 2) & 1)) << 4) | ((kg & 1) << 3));
+    const int wrbo = wrb ^ 16;
     constexpr int TSTEP = 2 * IW * 32;          // bytes between a wave's consecutive tiles (two rows)
     // ---- DMA plan: piece q = wave + 4 m fills LDS bytes [q * 1024, +1024) of the window: 32 pixels x 2 chunks of one region ----
     unsigned voff[DPW];
@@ -279,24 +287,24 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
         _Pragma("unroll") for (int m = 0; m < DPW; ++m) RB_PIECE(dsc_, m)                                        \
     }
 // fragments of tiles 4 G .. 4 G + NT - 1 under tap pair P
-#define RB_READ(RB, G, NT, P, BUFI)                                                                              \
+#define RB_READ(RB, RBO, G, NT, P, BUFI)                                                                         \
     {                                                                                                            \
         _Pragma("unroll") for (int i = 0; i < (NT); ++i) {                                                       \
-            xh[BUFI][i] = *reinterpret_cast<const bf16x8*>(lds + RB[P] + (4 * (G) + i) * TSTEP);                 \
-            xl[BUFI][i] = *reinterpret_cast<const bf16x8*>(lds + RB[P] + (4 * (G) + i) * TSTEP + REGION);        \
+            xh[BUFI][i] = *reinterpret_cast<const bf16x8*>(lds + ((i & 1) ? RBO[P] : RB[P]) + (4 * (G) + i) * TSTEP);          \
+            xl[BUFI][i] = *reinterpret_cast<const bf16x8*>(lds + ((i & 1) ? RBO[P] : RB[P]) + (4 * (G) + i) * TSTEP + REGION); \
         }                                                                                                        \
     }
 // one convolution = 10 steps (2 groups of tiles x 5 tap pairs) of up to 4 tiles x 3 products, fragments requested one step
 // ahead; NT1 = tiles of the second group (4: conv1's 8 tiles, 3: conv2's 7)
 #define RB_NOHOOK(ST)
-#define RB_CONV(RB, WH, WL, NT1, HOOK)                                                                           \
+#define RB_CONV(RB, RBO, WH, WL, NT1, HOOK)                                                                           \
     {                                                                                                            \
         bf16x8 xh[2][4], xl[2][4];                                                                               \
-        RB_READ(RB, 0, 4, 0, 0)                                                                                  \
+        RB_READ(RB, RBO, 0, 4, 0, 0)                                                                               \
         _Pragma("unroll") for (int st = 0; st < 10; ++st) {                                                      \
             const int g = st / 5, p = st % 5, nt = g ? (NT1) : 4;                                                \
             HOOK(st)                                                                                             \
-            if (st + 1 < 10) RB_READ(RB, (st + 1) / 5, ((st + 1) / 5 ? (NT1) : 4), (st + 1) % 5, (st + 1) & 1)   \
+            if (st + 1 < 10) RB_READ(RB, RBO, (st + 1) / 5, ((st + 1) / 5 ? (NT1) : 4), (st + 1) % 5, (st + 1) & 1)   \
             _Pragma("unroll") for (int i = 0; i < nt; ++i)                                                       \
                 acc[4 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WL[p], xh[st & 1][i], acc[4 * g + i], 0, 0, 0); \
             _Pragma("unroll") for (int i = 0; i < nt; ++i)                                                       \
@@ -350,8 +358,8 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
                 const int gh = oh0 - 1 + r0 + 2 * (K), gw = ow0 - 1 + 16 * hf + col;                             \
                 if (!(gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)) hi = lo = u32x2{0u, 0u};                      \
             }                                                                                                    \
-            *reinterpret_cast<u32x2*>(lds + wrb + (K) * TSTEP) = hi;                                             \
-            *reinterpret_cast<u32x2*>(lds + wrb + (K) * TSTEP + REGION) = lo;                                    \
+            *reinterpret_cast<u32x2*>(lds + (((K) & 1) ? wrbo : wrb) + (K) * TSTEP) = hi;                        \
+            *reinterpret_cast<u32x2*>(lds + (((K) & 1) ? wrbo : wrb) + (K) * TSTEP + REGION) = lo;               \
             if ((K) < 7) xres[(K) < 7 ? (K) : 0] = *reinterpret_cast<const bf16x8*>(lds + rres + (K) * TSTEP);   \
         }
 #if MVSGI_RB_EPI_OVERLAP
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
 #define RB_HOOK_A(ST)
 #endif
         STAMP()
-        RB_CONV(rbp, w1h, w1l, 4, RB_HOOK_A)
+        RB_CONV(rbp, rbp, w1h, w1l, 4, RB_HOOK_A)
         STAMP()
 #pragma unroll
         for (int k = MVSGI_RB_EPI_OVERLAP ? 4 : 0; k < 8; ++k) RB_EPI_A(k)
@@ -427,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void resblock2d_rs_kernel(RbArgs a) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ident, xres[k], b2, 0, 0, 0);
         STAMP()
-        RB_CONV(rbq, w2h, w2l, 3, RB_HOOK_B)
+        RB_CONV(rbq, rbqo, w2h, w2l, 3, RB_HOOK_B)
         STAMP()
 #pragma unroll
         for (int k = MVSGI_RB_EPI_OVERLAP ? 4 : 0; k < 7; ++k) RB_EPI_B(k)
