@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0}   # MI355X_MICROARCH.md: dense fp32-MFMA / bf16-MFMA peaks
 DTYPE = {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA operands, f32 accumulate/activations)"}
 PEAK_HBM_GBS = 8000.0
-EXTRA_CONFIGS = (("G16VV", 32), ("E8", 32), ("4cam-32", 32))      # (tag, frames per step: +4..8 % over 8 on MI355X)
+EXTRA_CONFIGS = (("G16VV", 32), ("E8", 64), ("4cam-32", 32))      # (tag, frames per step at which the configuration runs best on MI355X)
 LIB = os.path.join(ROOT, "mvs_gi_amd", "libmvsgi_hip.so")
 
 
@@ -60,7 +60,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl=RCCL)")
+    ap.add_argument("--settle-seconds", type=float, default=1.5,
+                    help="after the W warm-up steps the same step keeps running untimed until this much wall time has passed since "
+                         "the first step: the board reaches its power-capped clock (~1 s on MI355X) before the K timed steps, so "
+                         "`value` is the rate the chip sustains (extras.sustained checks it over 3 s)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-dump-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-dump", default=None, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -70,6 +75,17 @@ def parse_args(argv=None):
 # ------------------------------------------------------------------------------------------
 def dist_env():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def gather_device_ordinals(local_rank: int, world: int, dev=None):
+    """Every rank's device ordinal, in rank order (the line shows which GPUs the job really ran on)."""
+    import torch
+    import torch.distributed as dist
+    on_cpu = dev is None or dist.get_backend() == "gloo"
+    mine = torch.tensor([local_rank], dtype=torch.int64, device="cpu" if on_cpu else dev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    return [int(t.item()) for t in allr]
 
 
 def frame_shard(total_frames: int, world: int, rank: int):
@@ -136,6 +152,10 @@ class ConvProbe:
         self.hbm_records = []      # (kernel name, algorithmic bytes, start event, end event): the HBM-bound launches
         self.hbm_orig = {}
         self.enabled = False
+        self.by_shape = False      # tools/layer_table.py: one row per (kernel, layer shape) instead of one per kernel
+
+    def _tag(self, name, cin, cout, d, h, w, stride=1):
+        return f"{name} @ {cin}->{cout} [{d},{h},{w}] s{stride}" if self.by_shape else name
 
     def _wrap_hbm(self, fname, describe):
         """Event pair around H.<fname>; describe(args, kwargs, result) -> (kernel name, algorithmic bytes)."""
@@ -168,7 +188,7 @@ class ConvProbe:
             y = self.orig(x, w_oidhw, w_packed, scale, shift, res, stride, neg_slope, impl, out)
             e.record()
             vox = y.numel() // Cout
-            self.records.append((H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, impl), 2.0 * 27 * Cin * Cout * vox, s, e,
+            self.records.append((self._tag(H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, impl), Cin, Cout, D, Hh, W, stride), 2.0 * 27 * Cin * Cout * vox, s, e,
                                  4.0 * (x.numel() + y.numel() * (2 if res is not None else 1))))
             return y
 
@@ -182,7 +202,7 @@ class ConvProbe:
             y = self.orig_up2(x, w_packed_b3, scale, shift, res, neg_slope, out, w_layout)
             e.record()
             vox = y.numel() // Cout
-            self.records.append((H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, w_layout), 2.0 * 27 * Cin * Cout * vox, s, e,
+            self.records.append((self._tag(H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, w_layout), Cin, Cout, 2 * Dl, 2 * Hl, 2 * Wl), 2.0 * 27 * Cin * Cout * vox, s, e,
                                  4.0 * (x.numel() + y.numel() * (2 if res is not None else 1))))
             return y
 
@@ -207,7 +227,7 @@ class ConvProbe:
             s.record()
             y = self.orig_os(x, w_packed_b3, scale, shift, out, res, stride, neg_slope)
             e.record()
-            self.records.append((H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3) + " [split-padded out]",
+            self.records.append((self._tag(H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3) + " [split-padded out]", Cin, Cout, D, Hh, W, stride),
                                  2.0 * 27 * Cin * Cout * out.B * out.D * out.H * out.W, s, e,
                                  4.0 * (x.numel() + out.B * out.D * out.H * out.W * Cout * (2 if res is not None else 1))))
             return y
@@ -261,7 +281,7 @@ class ConvProbe:
             y = orig_up2s(x, w_packed_b3, scale, shift, out, res, neg_slope, w_layout)
             e.record()
             vox = out.B * out.D * out.H * out.W
-            self.records.append((H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, w_layout) + " [split-padded out]",
+            self.records.append((self._tag(H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, w_layout) + " [split-padded out]", Cin, Cout, 2 * Dl, 2 * Hl, 2 * Wl),
                                  2.0 * 27 * Cin * Cout * vox, s, e, 4.0 * (x.numel() + vox * Cout * (2 if res is not None else 1))))
             return y
         orig_polys, orig_heads = H.conv3d_up2_poly_split, H.conv3d_head_split
@@ -451,6 +471,30 @@ def cpu_baseline_subprocess(args, dump_path):
                 "sample": f"CPU baseline did not finish: {type(e).__name__}"}
 
 
+def oracle_dump_subprocess(args, dump_path):
+    """One oracle forward of the seed-0 frame in a child process (before this process touches the GPU): the parity reference of
+    a multi-rank line, which carries no CPU baseline."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-dump-only", "--config", args.config, "--cpu-dump", dump_path]
+    try:
+        subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    except Exception:
+        pass
+
+
+def oracle_dump(cfg, dump_path):
+    import numpy as np
+    import torch
+    from mvs_gi_amd import synth
+    from oracle import mvsgi_oracle as O
+    torch.set_num_threads(effective_cores())
+    inp = O.to_torch(synth.make_inputs(cfg, seed=0, batch=1))
+    w = O.to_torch(synth.make_weights(cfg, seed=0))
+    ref = O.hot_path(inp["feats"], inp["grids"], inp["grid_masks"], inp["masks"], w, cfg.builder,
+                     cfg.dist_cands, cfg.bf, cfg.interp_scale_factor, cfg.pre_interp)
+    np.save(dump_path, ref.numpy())
+
+
 def cpu_baseline(cfg, seconds: float, dump_path=None):
     """The oracle (CPU restatement of the reference's PyTorch path) on this host's cores:
     B=1 frames of the same workload until ~`seconds` have elapsed (at least 3 frames), then the three
@@ -562,7 +606,7 @@ def make_feats(B, shape, rng, dev, torch, np, nchw=False):
     return torch.from_numpy(rng.standard_normal((B, N, Hi, Wi, C), dtype=np.float32)).to(dev).permute(0, 1, 4, 2, 3)
 
 
-def measure_path(cfg, B, mode, steps, warmup, dev, H, HotPath, synth, torch, np, rng, graph=False):
+def measure_path(cfg, B, mode, steps, warmup, dev, H, HotPath, synth, torch, np, rng, graph=False, kernels=False):
     """frames/s, ms/step and per-conv-kernel attribution of one configuration at one batch size (single process,
     outside the headline's timed region)."""
     from mvs_gi_amd.configs import path_gflop
@@ -583,18 +627,24 @@ def measure_path(cfg, B, mode, steps, warmup, dev, H, HotPath, synth, torch, np,
         probe.enabled = True
         el = timed_steps(step, sync, steps, 0, 1, False, dev)
         probe.enabled = False
-        agg = probe.summary()
+        agg, hbm_agg = probe.summary(), probe.hbm_summary()
     dname, (dn, dflops, dms, _) = max(agg.items(), key=lambda kv: kv[1][2])
     ach = dflops / (dms * 1e-3) / 1e12
     res = {"frames_per_step": B, "frames_per_s": round(B * steps / el, 2), "ms_per_step": round(el / steps * 1e3, 4),
            "path_tflops": round(B * steps / el * path_gflop(cfg) / 1e3, 2),
            "dominant_kernel": dname, "dominant_avg_us": round(dms / dn * 1e3, 2),
            "dominant_tflops": round(ach, 2), "frac": round(ach / PEAK_TFLOPS[mode], 4)}
+    if kernels:
+        res["kernels"] = kernels_block(agg, hbm_agg)
     if graph:
-        hp.capture(feats)
-        gel = timed_steps(lambda: hp.replay(), sync, steps, warmup, 1, False, dev)
-        res["graph_replay_frames_per_s"] = round(B * steps / gel, 2)
-        res["graph_replay_ms_per_step"] = round(gel / steps * 1e3, 4)
+        try:
+            hp.capture(feats)
+            gel = timed_steps(lambda: hp.replay(), sync, steps, warmup, 1, False, dev)
+            res["graph_replay_frames_per_s"] = round(B * steps / gel, 2)
+            res["graph_replay_ms_per_step"] = round(gel / steps * 1e3, 4)
+        except Exception as e:
+            res["graph_replay_error"] = f"{type(e).__name__}: {e}"
+            torch.cuda.synchronize(dev)
     del hp, feats
     torch.cuda.empty_cache()
     return res
@@ -607,6 +657,10 @@ def main(argv=None):
         from mvs_gi_amd.configs import CONFIGS as _C
         print(json.dumps(cpu_baseline(_C[args.config], args.cpu_seconds, args.cpu_dump)), flush=True)
         return
+    if args.cpu_dump_only:
+        from mvs_gi_amd.configs import CONFIGS as _C
+        oracle_dump(_C[args.config], args.cpu_dump)
+        return
     if world != args.gpus:
         if "WORLD_SIZE" not in os.environ and args.gpus > 1:
             raise SystemExit(self_launch(args, sys.argv[1:] if argv is None else argv))
@@ -615,6 +669,10 @@ def main(argv=None):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ref_dump = os.path.join(tempfile.mkdtemp(prefix="mvsgi_bench_"), "oracle_inv_dist.npy")
         cpu_res = cpu_baseline_subprocess(args, ref_dump)      # before any GPU initialisation
+    elif rank == 0 and world > 1:
+        # a multi-rank line carries no CPU baseline, but it does carry an error figure: one oracle frame, before any GPU call
+        ref_dump = os.path.join(tempfile.mkdtemp(prefix="mvsgi_bench_"), "oracle_inv_dist.npy")
+        oracle_dump_subprocess(args, ref_dump)
     ensure_library(local_rank)
     import numpy as np
     import torch
@@ -638,13 +696,7 @@ def main(argv=None):
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
         backend_ready = True
-    devices = [local_rank]
-    if backend_ready:       # every rank's device ordinal, in rank order (the line shows which GPUs the job really ran on)
-        on_cpu = dist.get_backend() == "gloo"
-        mine = torch.tensor([local_rank], dtype=torch.int64, device="cpu" if on_cpu else dev)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        devices = [int(t.item()) for t in allr]
+    devices = gather_device_ordinals(local_rank, world, dev) if backend_ready else [local_rank]
 
     cfg = CONFIGS[args.config]
     B = args.batch
@@ -664,6 +716,7 @@ def main(argv=None):
         torch.cuda.synchronize(dev)
 
     per_rank = []
+    t_first = time.perf_counter()
     for _ in range(args.warmup):
         step()
     sync()
@@ -686,6 +739,15 @@ def main(argv=None):
         sync()
     else:
         timed_step = step
+    # settle: the same step, untimed, until the board sits at its power-capped clock (it ramps for ~1 s from idle; a 0.25 s timed
+    # region right behind a short warm-up would catch the chip still above the clock it sustains)
+    settle_steps = 0
+    while time.perf_counter() - t_first < args.settle_seconds:
+        timed_step()
+        settle_steps += 1
+        if settle_steps % 8 == 0:
+            sync()
+    sync()
     # the timed region: K steps, nothing but the path's own launches in it
     el = timed_steps(timed_step, sync, args.steps, 0, world, backend_ready, dev, per_rank)
     # per-kernel attribution: the same K steps once more with a HIP event pair around every conv launch (on the launch
@@ -716,6 +778,8 @@ def main(argv=None):
         "config": {"workload": f"{cfg.tag}: {cfg.num_cams} cams, D={cfg.num_cands}, builder={cfg.builder}, "
                                f"regulator=({cfg.reg_in_chs},{cfg.reg_f_int_chs}), feats {cfg.feat_hw}, cv {cfg.cv_hw}",
                    "frames_per_gpu_per_step": B, "parallelism": f"frame-sharded x{world} (no collective)",
+                   "settle": f"{settle_steps} untimed steps behind the {args.warmup} warm-up steps ({args.settle_seconds} s since the first step): "
+                             "the timed region starts at the power-capped clock (extras.sustained)",
                    "submission": ("one hipGraph replay per step (captured in warm-up; extras.eager_launches: per-launch submission)" if use_graph
                                   else (graph_note or "per-launch submission from Python / ctypes")),
                    "feats_layout": "channels-last storage, as the HIP feature extractor emits (extras.feats_nchw: contiguous NCHW)",
@@ -759,7 +823,14 @@ def main(argv=None):
             if tag == cfg.tag:
                 continue
             try:
-                cfgs[tag] = measure_path(CONFIGS[tag], b, args.mode, args.extra_steps, 3, dev, H, HotPath, synth, torch, np, rng)
+                m = measure_path(CONFIGS[tag], b, args.mode, args.extra_steps, 3, dev, H, HotPath, synth, torch, np, rng,
+                                 graph=use_graph, kernels=True)
+                if "graph_replay_frames_per_s" in m:      # as the headline: the step is one hipGraph replay (per-launch beside it)
+                    m["eager_frames_per_s"], m["eager_ms_per_step"] = m["frames_per_s"], m["ms_per_step"]
+                    m["frames_per_s"], m["ms_per_step"] = m.pop("graph_replay_frames_per_s"), m.pop("graph_replay_ms_per_step")
+                    m["path_tflops"] = round(m["frames_per_s"] * path_gflop(CONFIGS[tag]) / 1e3, 2)
+                    m["submission"] = "one hipGraph replay per step"
+                cfgs[tag] = m
             except Exception as e:       # never lose the headline to an extra
                 cfgs[tag] = {"error": f"{type(e).__name__}: {e}"}
         res["configs"] = cfgs
@@ -825,6 +896,109 @@ def run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, 
             el = timed_steps(lambda: hp.replay(), sync, K, W, 1, False, dev)
         return {"frames_per_s": round(B * K / el, 2), "ms_per_step": round(el / K * 1e3, 4)}
     guarded("eager_launches" if use_graph else "graph_replay", graph)
+
+    def sustained():
+        # the headline's submission (the captured graph, or per-launch with --eager) for >= 3 s and >= 250 steps; the rate over
+        # the LAST second, with the board's power and shader clock (hwmon) sampled by a thread of this process during the loop
+        import glob
+        import threading
+        if use_graph and getattr(hp, "_graph", None) is None:
+            hp.capture(feats)
+        fn = hp.replay if use_graph else (lambda: hp(feats))
+        samples, stop = [], threading.Event()
+
+        def read_num(path, scale):
+            try:
+                return int(open(path).read().split()[0]) / scale
+            except Exception:
+                return None
+
+        def sampler():
+            # a box exposes every card of the host under /sys: the card this process drives is the one drawing the most power
+            dirs = glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/")
+            while not stop.is_set():
+                best = (None, None)
+                for d in dirs:
+                    w = read_num(d + "power1_average", 1e6)
+                    if w is None:
+                        w = read_num(d + "power1_input", 1e6)
+                    if w is not None and (best[0] is None or w > best[0]):
+                        best = (w, read_num(d + "freq1_input", 1e6))
+                samples.append((time.perf_counter(), best[0], best[1]))
+                stop.wait(0.1)
+        th = threading.Thread(target=sampler, daemon=True)
+        sync()
+        th.start()
+        marks, n, t0 = [], 0, time.perf_counter()
+        while True:
+            for _ in range(5):
+                fn()
+            sync()
+            n += 5
+            marks.append((time.perf_counter() - t0, n))
+            if marks[-1][0] >= 3.0 and n >= 250:
+                break
+        stop.set()
+        th.join()
+        t_end, n_end = marks[-1]
+        t_a, n_a = min(marks, key=lambda m: abs(m[0] - (t_end - 1.0)))
+        last = B * (n_end - n_a) / (t_end - t_a)
+        first = B * marks[0][1] / marks[0][0]
+        pw = [(t - t0, w, f) for t, w, f in samples if w is not None or f is not None]
+        tail = [x for x in pw if x[0] >= t_end - 1.0]
+        avg = lambda xs: round(sum(xs) / len(xs), 1) if xs else None      # noqa: E731
+        return {"frames_per_s_last_second": round(last, 2), "frames_per_s_whole_run": round(B * n_end / t_end, 2),
+                "frames_per_s_first_5_steps": round(first, 2), "seconds": round(t_end, 2), "steps": n_end,
+                "vs_headline": round(last / headline_fps, 4),
+                "power_W_last_second": avg([w for _, w, _ in tail if w is not None]),
+                "sclk_MHz_last_second": avg([f for _, _, f in tail if f is not None]),
+                "power_W_first_300ms": avg([w for t, w, _ in pw if t <= 0.3 and w is not None]),
+                "samples": len(pw), "how": "same submission as the headline, sync every 5 steps; hwmon power1_average / freq1_input "
+                                           "read every 100 ms by a thread of this process (None: not exposed on this box)"}
+    guarded("sustained", sustained)
+
+    def random_grids():
+        # SURVEY section 8(d)'s second input variant: sampling grids U[-1.1, 1.1] (worst-case gather locality, 9 % of the taps
+        # outside the image), Bernoulli grid masks / masks, at full size
+        r_inp = synth.make_inputs(cfg, seed=0, batch=1, grid_kind="random")
+        hp2 = HotPath(cfg, weights, r_inp, device=dev)
+        for _ in range(W):
+            hp2(feats)
+        sub = "per-launch submission"
+        fn = lambda: hp2(feats)      # noqa: E731
+        if use_graph:
+            try:
+                hp2.capture(feats)
+                fn, sub = hp2.replay, "one hipGraph replay per step"
+            except Exception:
+                torch.cuda.synchronize(dev)
+        el = timed_steps(fn, sync, K, W, 1, False, dev)
+        with ConvProbe(H) as probe:
+            probe.enabled = True
+            hp2(feats)
+            sync()
+            probe.enabled = False
+            hb = probe.hbm_summary()
+        sw = {k: {"us": round(v[2] / v[0] * 1e3, 1), "GBps": round(v[1] / (v[2] * 1e-3) / 1e9, 1)} for k, v in hb.items() if "sweep" in k}
+        del hp2
+        return {"frames_per_s": round(B * K / el, 2), "ms_per_step": round(el / K * 1e3, 4), "submission": sub, "sweep_launches": sw,
+                "note": "grids U[-1.1, 1.1] (no locality between neighbouring voxels), Bernoulli(0.9) grid masks, Bernoulli(0.95) masks"}
+    guarded("random_grids", random_grids)
+
+    def strict_interface():
+        # the reference's interface taken literally, all at once: contiguous NCHW feats (the reference extractor's layout), the
+        # rig's grid_masks / masks re-sampled inside every step (no constants lowered ahead of time), norm_costs stored
+        f2 = make_feats(B, (1, cfg.num_cams, cfg.feat_chs, *cfg.feat_hw), rng, dev, torch, np, nchw=True)
+        hp.cv_builder.cache_rig_constants = False
+        hp.dist_regressor.return_norm_costs = True
+        try:
+            el = timed_steps(lambda: hp(f2), sync, K, W, 1, False, dev)
+        finally:
+            hp.cv_builder.cache_rig_constants = True
+        return {"frames_per_s": round(B * K / el, 2), "ms_per_step": round(el / K * 1e3, 4), "vs_headline": round(B * K / el / headline_fps, 4),
+                "submission": "per-launch submission",
+                "note": "NCHW feats + rig cache off + norm_costs stored, together (each alone: extras.feats_nchw, extras.rig_cache_off)"}
+    guarded("strict_interface", strict_interface)
 
     def b1():
         r = measure_path(cfg, 1, args.mode, 200, 20, dev, H, HotPath, synth, torch, np, rng, graph=True)

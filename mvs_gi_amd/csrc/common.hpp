@@ -4,6 +4,8 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <string>
 
 #include "../../include/mvsgi.h"
@@ -36,6 +38,14 @@ inline int check_launch(const char* what) {
 inline hipStream_t as_stream(mvsgi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
+
+// Experiment knobs (A/B switches whose measurement is recorded in DESIGN.md / DESIGN_HISTORY.md) exist only in diagnostic
+// builds (-DMVSGI_EXPERIMENTAL, __graft_entry__.build_variant): the product library reads no environment variable.
+#ifdef MVSGI_EXPERIMENTAL
+inline const char* exp_env(const char* name) { return getenv(name); }
+#else
+inline const char* exp_env(const char*) { return nullptr; }
+#endif
 
 // Per-(kernel, device) launch set-up of the persistent kernels: the dynamic-LDS limit is a per-device function
 // attribute and the persistent grid is sized from THAT device's CU count and residency (a process may drive several

@@ -299,7 +299,7 @@ enum Variant {
     V_DIRECT1, V_DIRECT4, V_HEAD,
     V_S1_N16_B256, V_S1_N32_B256, V_S1_N32_B64, V_S1_N64_B128, V_S1_N64_B64, V_S2_N32_B64, V_S2_N64_B64,
     // split-bf16 kernel: 16-wide bricks (conflict-free LDS reads); N = couts per workgroup
-    B3_N16, B3_N32, B3_N48, B3_N64, B3_N64_H5, B3_N96, B3_N32_S, B3_N64_S, B3_N16_T, B3_N32_T, B3_S2_N32, B3_S2_N64,
+    B3_N16, B3_N32, B3_N48, B3_N64, B3_N64_H5, B3_N96, B3_N96_H5, B3_N128_P, B3_N128_PH5, B3_N192_PH5, B3_N32_S, B3_N64_S, B3_N16_T, B3_N32_T, B3_S2_N32, B3_S2_N64,
     // split-bf16 kernel with the trilinear x2 upsample fused into its producers (even bricks only)
     B3U_N16, B3U_N32, B3U_N32_M, B3U_N48, B3U_N64, B3U_N96,
     // Cout == 16 plane schedule (weights from mvsgi_conv3d_pack_weights_bf16x3_c16), plain and fused-upsample
@@ -308,7 +308,7 @@ enum Variant {
     B3V_N32, B3V_N64, B3VU_N32, B3VU_N64,
     V_COUNT
 };
-const char* const kVariantNames[V_COUNT] = {
+const char* const kVariantNames[] = {
     "conv3d_direct_kernel<1>", "conv3d_direct_kernel<4>", "conv3d_head_kernel",
     "conv3d_mfma_kernel<1, 4, 4, 1, 4, 8, 8, 1>", "conv3d_mfma_kernel<2, 4, 4, 1, 4, 8, 8, 1>",
     "conv3d_mfma_kernel<2, 1, 4, 1, 2, 4, 8, 1>", "conv3d_mfma_kernel<2, 4, 2, 2, 2, 8, 8, 1>",
@@ -317,7 +317,10 @@ const char* const kVariantNames[V_COUNT] = {
     "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false>",
     "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, false, false, false>",
     "conv3d_bf16x3_kernel<2, 5, 2, 2, 2, 5, 16, 1, 3, false, false, false>",
-    "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false>",
+    "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<3, 5, 2, 2, 2, 5, 16, 1, 3, false, false, false>",
+    "conv3d_bf16x3_kernel<2, 4, 1, 4, 1, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 5, 1, 4, 1, 5, 16, 1, 3, false, false, false>",
+    "conv3d_bf16x3_kernel<3, 5, 1, 4, 1, 5, 16, 1, 3, false, false, false>",
+    "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false>",
     "conv3d_bf16x3_kernel<2, 2, 2, 2, 1, 4, 16, 1, 3, false, false, false>",
     "conv3d_bf16x3_kernel<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false>",
     "conv3d_bf16x3_kernel<2, 1, 4, 1, 2, 4, 8, 2, 3, false, false, false>",
@@ -329,6 +332,7 @@ const char* const kVariantNames[V_COUNT] = {
     "conv3d_bf16x3_kernel<1, 2, 4, 1, 4, 4, 16, 1, 3, false, false, true>", "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 16, 1, 3, false, false, true>",
     "conv3d_bf16x3_kernel<1, 2, 4, 1, 4, 4, 16, 1, 3, true, false, true>", "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 16, 1, 3, true, false, true>",
 };
+static_assert(sizeof(kVariantNames) / sizeof(kVariantNames[0]) == V_COUNT, "one name per variant");
 
 // 32x32x16 schedule: Cout % 32 == 0, stride 1, and enough bricks to fill the chip with its two brick shapes
 bool v32_applies(const ConvArgs& a) {
@@ -407,17 +411,35 @@ int select_variant(const ConvArgs& a, int impl) {
         if (CT == 1) return B3_N16;
         if (CT == 2) return big >= 384 ? B3_N32 : B3_N32_S;
         if (CT == 3) return B3_N48;
+        const bool h5ok = a.Ho % 5 == 0 && a.Ho % 4 != 0;
+#ifdef MVSGI_EXPERIMENTAL
+        if (const char* f = mvsgi::exp_env("MVSGI_B3_FORCE")) {       // force a variant by its enum name suffix (tools/ only)
+            static const struct { const char* n; int v; } tab[] = {{"N64", B3_N64}, {"N64_H5", B3_N64_H5}, {"N96", B3_N96}, {"N96_H5", B3_N96_H5},
+                {"N128_P", B3_N128_P}, {"N128_PH5", B3_N128_PH5}, {"N192_PH5", B3_N192_PH5}, {"N64_S", B3_N64_S}};
+            for (const auto& t : tab) if (!strcmp(f, t.n)) return t.v;
+        }
+#endif
+        // one-plane volumes (the coarsest level of an 8-candidate regulator): bricks one plane thick -- a 2-plane brick would do
+        // half of its MFMAs on padding.  All four consumer waves share the brick's voxel tiles and split the couts.
+        if (a.Do == 1 && CT >= 8 && CT % 4 == 0) {
+            const long long rows5 = (long long)a.B * (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16);
+            if (h5ok && CT % 12 == 0 && rows5 * (CT / 12) >= 384) return B3_N192_PH5;
+            if (h5ok && CT % 8 == 0) return B3_N128_PH5;
+            if (CT % 8 == 0 && (long long)a.B * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16) * (CT / 8) >= 384) return B3_N128_P;
+        }
+        if (CT % 6 == 0 && h5ok && !mvsgi::exp_env("MVSGI_NO_H5") &&
+            (long long)a.B * mvsgi::cdiv(a.Do, 2) * (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16) * (CT / 6) >= 384) return B3_N96_H5;
         if (CT % 6 == 0 && mid * (CT / 6) >= 384) return B3_N96;
         // planes whose height is a multiple of 5 but not of 4 (the 10 x 40 planes of UNet level 2): 2 x 5 x 16 bricks cover them
         // exactly where 2 x 4 x 16 ones pad 10 rows to 12 (17 % of the MFMAs) and stage 7 % more halo per voxel
-        static const bool h5 = !getenv("MVSGI_NO_H5");
-        if (h5 && a.Ho % 5 == 0 && a.Ho % 4 != 0 && (long long)a.B * mvsgi::cdiv(a.Do, 2) * (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16) * mvsgi::cdiv(CT, 4) >= 384)
+        static const bool h5 = !mvsgi::exp_env("MVSGI_NO_H5");
+        if (h5 && h5ok && (long long)a.B * mvsgi::cdiv(a.Do, 2) * (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16) * mvsgi::cdiv(CT, 4) >= 384)
             return B3_N64_H5;
         if (mid * mvsgi::cdiv(CT, 4) >= 384) return B3_N64;
         // a frame or two (latency path): 64-voxel bricks, and as few couts per workgroup as it takes to put a few hundred
         // workgroups on the chip -- each then walks Cin / 16 slices of 42 (16 couts) or 84 (32 couts) MFMAs per wave
         const long long tiny = (long long)a.B * a.Do * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
-        static const int force = getenv("MVSGI_B3_SMALL") ? atoi(getenv("MVSGI_B3_SMALL")) : 0;      // experiments: 16 / 32 / 64
+        static const int force = mvsgi::exp_env("MVSGI_B3_SMALL") ? atoi(mvsgi::exp_env("MVSGI_B3_SMALL")) : 0;      // experiments: 16 / 32 / 64
         if (force == 16) return B3_N16_T;
         if (force == 32) return B3_N32_T;
         if (force == 64) return B3_N64_S;
@@ -450,6 +472,10 @@ int launch_variant(int v, const ConvArgs& a, hipStream_t st) {
         case B3_N64: return launch_bf16x3<2, 4, 2, 2, 2, 4, 16, 1>(a, st);
         case B3_N64_H5: return launch_bf16x3<2, 5, 2, 2, 2, 5, 16, 1>(a, st);
         case B3_N96: return launch_bf16x3<3, 4, 2, 2, 2, 4, 16, 1>(a, st);
+        case B3_N96_H5: return launch_bf16x3<3, 5, 2, 2, 2, 5, 16, 1>(a, st);
+        case B3_N128_P: return launch_bf16x3<2, 4, 1, 4, 1, 4, 16, 1>(a, st);
+        case B3_N128_PH5: return launch_bf16x3<2, 5, 1, 4, 1, 5, 16, 1>(a, st);
+        case B3_N192_PH5: return launch_bf16x3<3, 5, 1, 4, 1, 5, 16, 1>(a, st);
         case B3_N32_S: return launch_bf16x3<2, 1, 4, 1, 1, 4, 16, 1>(a, st);
         case B3_N64_S: return launch_bf16x3<2, 2, 2, 2, 1, 4, 16, 1>(a, st);
         case B3_N16_T: return launch_bf16x3<1, 1, 4, 1, 1, 4, 16, 1>(a, st);

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
 #define MVSGI_WBX 5      // five buffers (four slots ahead) for the 2 x 4-tile variants: 214 + 16 registers; measured against 4 and 6
 #endif
                        (KD == 3 && !PLANE && !V32 && NW == 2 && MW == 4) ? MVSGI_WBX :
-                       NW <= 2 ? 4 : 2;
+                       NW <= 2 ? 4 : 2;      // NW = 3: three buffers (8 spilled registers) measured 2 % slower
     constexpr int LA = WB - 1;
     constexpr int NSLOT = ((kPairs + WB - 1) / WB) * WB;
     static_assert(NSLOT % WB == 0 && NSLOT >= kPairs, "pipeline geometry");

@@ -331,11 +331,12 @@ extern "C" int mvsgi_conv3d_s2rs(const void* x_split, const void* w_packed, cons
     a.Do = (D - 1) / 2 + 1; a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
     MVSGI_REQUIRE((long long)(a.Do + 2) * (a.Ho + 2) * (a.Wo + 2) * 128 < 0x7fffff00ll, "mvsgi_conv3d_s2rs: output frame too large for 32-bit offsets");
     a.neg_slope = neg_slope;
-    const char* th_e = getenv("MVSGI_S2RS_TH");          // brick height: 4 output rows (one workgroup per CU) or 2 (two)
-    const int th_env = th_e ? atoi(th_e) : 0;
     hipStream_t st = mvsgi::as_stream(stream);
-    const char* nb_e = getenv("MVSGI_S2RS_NBUF");        // windows per workgroup: 1 (two workgroups per CU) or 2 (TH = 4: one)
-    const int nbuf = nb_e ? atoi(nb_e) : 2;
-    if (th_env == 2) return s2_launch<2, 2>(a, st);
-    return nbuf == 1 ? s2_launch<4, 1>(a, st) : s2_launch<4, 2>(a, st);
+#ifdef MVSGI_EXPERIMENTAL      // measured equal or slower (DESIGN_HISTORY.md): 2-row bricks with two workgroups per CU, single-window workgroups
+    const char* th_e = mvsgi::exp_env("MVSGI_S2RS_TH");          // brick height: 4 output rows (one workgroup per CU) or 2 (two)
+    const char* nb_e = mvsgi::exp_env("MVSGI_S2RS_NBUF");        // windows per workgroup: 1 (two workgroups per CU) or 2 (TH = 4: one)
+    if (th_e && atoi(th_e) == 2) return s2_launch<2, 2>(a, st);
+    if (nb_e && atoi(nb_e) == 1) return s2_launch<4, 1>(a, st);
+#endif
+    return s2_launch<4, 2>(a, st);
 }

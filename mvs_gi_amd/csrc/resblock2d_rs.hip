@@ -745,7 +745,7 @@ extern "C" int mvsgi_resblock2d_split(const void* x_split, const void* w_packed1
     const long long nb = (long long)N * a.tiles_h * a.tiles_w;
     MVSGI_REQUIRE(nb < (1ll << 31), "mvsgi_resblock2d_split: too many bricks");
     a.total_units = (int)nb;
-    static const int patch_env = [] { const char* e = getenv("MVSGI_RB_PATCH"); return e ? atoi(e) : 0; }();   // experiments
+    static const int patch_env = [] { const char* e = mvsgi::exp_env("MVSGI_RB_PATCH"); return e ? atoi(e) : 0; }();   // experiments
     a.patch = patch_env > 0 ? patch_env : 8;
     hipStream_t st = mvsgi::as_stream(stream);
     return y_is_split ? rb_launch<false>(a, st, "mvsgi_resblock2d_split") : rb_launch<true>(a, st, "mvsgi_resblock2d_split(fp32 out)");

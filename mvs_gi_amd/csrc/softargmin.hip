@@ -315,7 +315,7 @@ extern "C" int mvsgi_softargmin_div_f32(const float* costs, const float* inv_idx
     MVSGI_REQUIRE(post_div != 0.0f, "mvsgi_softargmin_div_f32: post_div must be non-zero");
     MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_softargmin_f32: non-positive dimension");
     MVSGI_REQUIRE(scale == 1 || scale == 2, "mvsgi_softargmin_f32: scale %d not in {1, 2}", scale);
-    if (scale == 2 && !getenv("MVSGI_SOFTARGMIN_PIXEL")) {
+    if (scale == 2 && !mvsgi::exp_env("MVSGI_SOFTARGMIN_PIXEL")) {
         // row-pair kernel: column tiles of xt low-resolution columns (a multiple of 4), 2 * (xt / 2) threads, LDS 2 * D * (xt + 4) floats
         int xt = (int)(mvsgi::cdiv(W, 4) * 4);
         const int xt_max = (D > 16 && D <= 32) ? 512 : 640;      // = the kernels' launch bounds
@@ -334,7 +334,7 @@ extern "C" int mvsgi_softargmin_div_f32(const float* costs, const float* inv_idx
                 MVSGI_REQUIRE(e == hipSuccess, "mvsgi_softargmin_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
                 attr_set[ki][dev] = true;
             }
-            static const int contiguous = getenv("MVSGI_SOFTARGMIN_RR") ? 0 : 1;
+            static const int contiguous = mvsgi::exp_env("MVSGI_SOFTARGMIN_RR") ? 0 : 1;
             hipLaunchKernelGGL(kern, dim3((unsigned)units), dim3(threads), lds, mvsgi::as_stream(stream), costs, inv_idx, inv_dist,
                                norm_costs, B, D, H, W, xt, (int)xtiles, (int)units, post_div, contiguous);
             return mvsgi::check_launch("mvsgi_softargmin_f32(rows)");

@@ -809,7 +809,7 @@ int sweep_std_nhwc_valid_impl(const float* feats, const float* grids, const unsi
     // (never one chunk: with two the rows of blocks resident on an XCD span half as many feature-map rows, which then stay
     // in its 4 MiB L2 -- FETCH_SIZE 3.7 -> 0.79 GiB per 64-frame launch, profiles/r02_pmc_sweep_l2.txt)
     long long nd = rows >= 8192 ? 2 : mvsgi::cdiv(8192, rows);
-    static const int nd_env = getenv("MVSGI_SWEEP_ND") ? atoi(getenv("MVSGI_SWEEP_ND")) : 0;      // experiments
+    static const int nd_env = mvsgi::exp_env("MVSGI_SWEEP_ND") ? atoi(mvsgi::exp_env("MVSGI_SWEEP_ND")) : 0;      // experiments
     if (nd_env > 0) nd = nd_env;
     if (nd > D) nd = D;
     const int dchunk = (int)mvsgi::cdiv(D, nd);

@@ -44,7 +44,7 @@ NORM3D_TYPE: Dict[str, Type[nn.Module]] = {"batch": nn.BatchNorm3d, "instance": 
 # lowering of one conv block to the arguments of mvsgi_conv3d_f32
 # ------------------------------------------------------------------------------------------
 # MVSGI_V32=1: 32x32x16-MFMA kernels for the Cout % 32 == 0 layers (measured on par with the 16x16x32 kernels, so off by default)
-_USE_V32 = os.environ.get("MVSGI_V32", "0") != "0"
+_USE_V32 = H.exp_env("MVSGI_V32", "0") != "0"
 
 
 class ConvLaunch:

@@ -105,12 +105,12 @@ def cat_sweep_ndhwc(feats, grids) -> Tensor:
     return H.sweep_cat(feats, grids)
 
 
-_USE_RS = os.environ.get("MVSGI_RS", "1") != "0"
+_USE_RS = H.exp_env("MVSGI_RS", "1") != "0"
 # frames per sweep -> post_vol chunk (0: the whole batch at once): a chunk's split-padded vol_raw is written by the sweep and read
 # straight back by post_vol, and the buffer is 16 frames instead of B.  4763 -> 4835 frames/s at B=64 (chunks of 4: 4845;
 # tools/ab_bench.py, one box, 3 rounds); the same chunking of out_costs.0 -> head measured slower (4769 -> 4667)
 _FRONT_CHUNK = int(os.environ.get("MVSGI_FRONT_CHUNK", "16"))
-_RS_MIN_UNITS = int(os.environ.get("MVSGI_RS_MIN_UNITS", "0"))      # measured faster down to one frame (B=1: 16.9 vs 24.2 us, 23.5 vs 32.2 us)
+_RS_MIN_UNITS = int(H.exp_env("MVSGI_RS_MIN_UNITS", "0"))      # measured faster down to one frame (B=1: 16.9 vs 24.2 us, 23.5 vs 32.2 us)
 
 
 def _std_front(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor, hand_over_split: bool):

@@ -36,8 +36,8 @@ class UNetDownBlk(nn.Module):
 
 # MVSGI_RS=0 keeps every layer on the streaming kernels.  MVSGI_RS_MIN_UNITS: minimum
 # 128-voxel bricks per launch (one workgroup per CU, each with a prologue and two drain phases: small launches lose)
-_USE_RS = os.environ.get("MVSGI_RS", "1") != "0"
-_RS_MIN_UNITS = int(os.environ.get("MVSGI_RS_MIN_UNITS", "0"))      # measured faster down to one frame (B=1: 16.9 vs 24.2 us, 23.5 vs 32.2 us)
+_USE_RS = H.exp_env("MVSGI_RS", "1") != "0"
+_RS_MIN_UNITS = int(H.exp_env("MVSGI_RS_MIN_UNITS", "0"))      # measured faster down to one frame (B=1: 16.9 vs 24.2 us, 23.5 vs 32.2 us)
 
 
 def _rs_chain(blk, x: Tensor):
@@ -94,7 +94,7 @@ def _down_block_rs(blk, x: Tensor, L0, chain, dims) -> Tensor:
 # MVSGI_S2RS=0: the builder -> regulator hand-over stays an fp32 tensor (the regulator's first layer on the streaming kernel).
 # MVSGI_S2RS_MIN_FRAMES: smallest batch for the split-padded hand-over
 _USE_S2RS = os.environ.get("MVSGI_S2RS", "1") != "0"
-_S2RS_MIN_FRAMES = int(os.environ.get("MVSGI_S2RS_MIN_FRAMES", "1"))
+_S2RS_MIN_FRAMES = int(H.exp_env("MVSGI_S2RS_MIN_FRAMES", "1"))
 
 
 class _Shape:
@@ -141,7 +141,7 @@ _HEAD_SPLIT = os.environ.get("MVSGI_HEAD_SPLIT", "1") != "0"      # 0: polyphase
 # (measured on MI355X, G16V, 400 bricks per frame and role, one hipGraph replay per step: 1 frame 0.506 vs 0.497 ms with / without,
 # 2 frames 0.779 vs 0.766, 4 frames 1.150 vs 1.167, 64 frames 12.57 vs 13.28 -- three launches and a prologue + two drain phases
 # per workgroup need ~4 frames to pay)
-_POLY_MIN_UNITS = int(os.environ.get("MVSGI_POLY_MIN_UNITS", "1600"))
+_POLY_MIN_UNITS = int(H.exp_env("MVSGI_POLY_MIN_UNITS", "1600"))
 
 
 def _poly_tail(self, x: Tensor, skip: Tensor):

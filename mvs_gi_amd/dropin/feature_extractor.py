@@ -21,8 +21,8 @@ from . import common_modules as cm
 from .common_modules import module_getstate, NoOp, NORM2D_TYPE, RELU_TYPE, _is_identity
 
 
-_SPLIT_CHAIN = os.environ.get("MVSGI_EXTRACTOR_SPLIT", "1") != "0"  # 0: the round-2 chain (fp32 activations between all layers)
-_STEM_MFMA = os.environ.get("MVSGI_STEM_MFMA", "1") != "0"      # 0: the LDS-tiled VALU stem for uint8 images too
+_SPLIT_CHAIN = H.exp_env("MVSGI_EXTRACTOR_SPLIT", "1") != "0"  # 0: the round-2 chain (fp32 activations between all layers)
+_STEM_MFMA = H.exp_env("MVSGI_STEM_MFMA", "1") != "0"      # 0: the LDS-tiled VALU stem for uint8 images too
 
 
 class Conv2dLaunch:
@@ -148,7 +148,7 @@ class BaseConvBlk2d(nn.Module):
         return h + 2 * self.out_pad, w + 2 * self.out_pad
 
 
-_FUSE_RESBLOCK = os.environ.get("MVSGI_FUSE_RESBLOCK", "1") != "0"
+_FUSE_RESBLOCK = H.exp_env("MVSGI_FUSE_RESBLOCK", "1") != "0"
 
 
 def res_block2d_nhwc(blk, x: Tensor) -> Tensor:

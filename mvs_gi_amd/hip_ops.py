@@ -23,6 +23,13 @@ if _CONV_MODE not in ("f32", "bf16x3"):
     raise ValueError(f"MVSGI_CONV_MODE={_CONV_MODE!r} not in ('f32', 'bf16x3')")
 
 
+def exp_env(name: str, default: str) -> str:
+    """Experiment switches -- A/B knobs whose measurement is recorded in DESIGN.md / DESIGN_HISTORY.md as neutral or slower -- are
+    read only when MVSGI_EXPERIMENTAL=1; the product configuration surface is MVSGI_CONV_MODE, MVSGI_RIG_CACHE, MVSGI_POLY,
+    MVSGI_S2RS, MVSGI_HEAD_SPLIT, MVSGI_FRONT_CHUNK (each covered by tests/test_gpu_parity.py::test_product_switches_off) and MVSGI_LIB."""
+    return os.environ.get(name, default) if os.environ.get("MVSGI_EXPERIMENTAL") == "1" else default
+
+
 def set_conv_mode(mode: str) -> None:
     global _CONV_MODE
     if mode not in ("f32", "bf16x3"):

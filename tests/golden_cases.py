@@ -30,9 +30,9 @@ FULL_CASES = {
     "full_G16V": dict(cfg=CONFIGS["G16V"], seed=0, batch=1, grid_kind="smooth", grid_mask_dtype="bool",
                       gains=(0.25, 1.0)),
     "full_G16VV": dict(cfg=CONFIGS["G16VV"], seed=0, batch=1, grid_kind="smooth", grid_mask_dtype="bool",
-                       gains=(1.0,)),
+                       gains=(1.0, 4.0)),
     "full_E8": dict(cfg=CONFIGS["E8"], seed=0, batch=1, grid_kind="smooth", grid_mask_dtype="bool",
-                    gains=(4.0,)),
+                    gains=(4.0, 1.0)),
     "full_4cam-32": dict(cfg=CONFIGS["4cam-32"], seed=0, batch=1, grid_kind="smooth", grid_mask_dtype="bool",
-                         gains=(0.05,)),
+                         gains=(0.05, 0.2)),
 }

@@ -52,3 +52,38 @@ def test_timed_steps_max_over_ranks_gloo_world2(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     el = json.loads(line)["el"]
     assert 0.19 <= el <= 1.0, el     # 5 steps x 40 ms of the slow rank, not 5 x 20 ms
+
+
+def test_control_plane_world8_gloo(tmp_path):
+    """The N = 8 line's control plane, eight ranks over gloo on the CPU (a GPU box admits six processes on its card, so the
+    eight-rank case cannot be rehearsed there): rendezvous, every rank's device ordinal gathered in rank order, the barrier
+    + max-over-ranks timing with every rank's own time, the thread clamp of self_launch."""
+    code = textwrap.dedent("""
+        import os, sys, time, json
+        sys.path.insert(0, %r)
+        import torch, torch.distributed as dist
+        import bench
+        rank, local, world = bench.dist_env()
+        assert world == 8
+        torch.set_num_threads(max(1, bench.effective_cores() // world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        devs = bench.gather_device_ordinals(local, world)
+        assert devs == list(range(8)), devs
+        per = []
+        el = bench.timed_steps(lambda: time.sleep(0.01 if rank != 5 else 0.03), lambda: None, steps=4, warmup=1, world=world,
+                               backend_ready=True, per_rank=per)
+        assert len(per) == 8 and max(per) == per[5] and el >= per[5]
+        if rank == 0:
+            print(json.dumps({"el": el, "per": per, "threads": torch.get_num_threads()}))
+        dist.destroy_process_group()
+    """ % ROOT)
+    script = tmp_path / "w8.py"
+    script.write_text(code)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", "29613", str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    import json
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert 0.11 <= d["el"] <= 2.0 and d["threads"] >= 1

@@ -170,7 +170,16 @@ CONV_SHAPES = [
     (1, 64, 32, 5, 7, 9, 1, False, 1.0),        # identity activation
     (32, 128, 128, 2, 10, 40, 1, True, 0.01),   # UNet level 2 at 32 frames: the 2 x 5 x 16 brick variant (H a multiple of 5, not of 4)
     (32, 64, 64, 3, 15, 21, 1, True, 0.01),     # the same variant, ragged in D and W
+    (32, 32, 96, 4, 10, 40, 1, True, 0.01),     # 96-cout units on 2 x 5 x 16 bricks (the fint96 regulators' level 2 at D = 16)
+    (24, 32, 128, 1, 10, 40, 1, True, 0.01),    # one-plane volume (E8's level 2): 1 x 5 x 16 bricks, 128-cout units
+    (64, 16, 192, 1, 10, 40, 1, False, 0.01),   # ... 192-cout units
+    (96, 16, 128, 1, 7, 21, 1, True, 0.0),      # one-plane volume, H not a multiple of 5: 1 x 4 x 16 bricks, ragged
 ]
+EXPECTED_VARIANT = {        # (B, Cin, Cout, D, H, W) -> brick / unit shape the dispatcher must pick
+    (32, 128, 128, 2, 10, 40): "<2, 5, 2, 2, 2, 5, 16", (32, 64, 64, 3, 15, 21): "<2, 5, 2, 2, 2, 5, 16",
+    (32, 32, 96, 4, 10, 40): "<3, 5, 2, 2, 2, 5, 16", (24, 32, 128, 1, 10, 40): "<2, 5, 1, 4, 1, 5, 16",
+    (64, 16, 192, 1, 10, 40): "<3, 5, 1, 4, 1, 5, 16", (96, 16, 128, 1, 7, 21): "<2, 4, 1, 4, 1, 4, 16",
+}
 
 
 def _conv_case(rng, B, Cin, Cout, D, Hh, W, stride, res, slope, bias=False):
@@ -219,8 +228,8 @@ def test_conv3d_bf16x3_vs_oracle(shape):
     wg = _g(w)
     wp = H.pack_conv_weights_bf16x3(wg)
     assert "bf16x3" in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3)
-    if B == 32:
-        assert "<2, 5, 2, 2, 2, 5, 16" in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3)
+    if shape[:6] in {(k[0], k[1], k[2], k[3], k[4], k[5]) for k in EXPECTED_VARIANT}:
+        assert EXPECTED_VARIANT[shape[:6]] in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3)
     y = H.conv3d(xg, wg, wp, _g(scale), _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3)
     err = _rel(_ncdhw(y), yref)
     assert err <= 1e-4, err
@@ -441,6 +450,46 @@ def test_small_cases_vs_reference_goldens(golden_dir, name, conv_mode):
             assert _rel(pr.cpu().numpy(), z["norm_costs"]) <= 1e-3 * tol
 
 
+@pytest.mark.parametrize("switch", ["MVSGI_POLY", "MVSGI_S2RS", "MVSGI_HEAD_SPLIT", "MVSGI_RIG_CACHE", "MVSGI_FRONT_CHUNK", "MVSGI_CONV_MODE"])
+def test_product_switches_off(golden_dir, switch):
+    """The product's configuration surface (hip_ops.exp_env lists it): the std_d16_rand golden (random grids, float grid masks,
+    two frames, a peaky gain) through the whole path with each switch turned away from its default -- every alternative path
+    stays within the north-star bar.  (The switches are read at import; the test sets what they set.)"""
+    from mvs_gi_amd.dropin import cost_volume_builder as cb, cost_volume_regulator as cr
+    case = SMALL_CASES["std_d16_rand"]
+    cfg = case["cfg"]
+    z = _load(golden_dir, "std_d16_rand")
+    inp = synth.make_inputs(cfg, seed=case["seed"], batch=case["batch"], grid_kind=case["grid_kind"], grid_mask_dtype=case["grid_mask_dtype"])
+    assert synth.digest(inp) == str(z["inputs_sha256"])
+    saved = (H.get_conv_mode(), cr._USE_POLY, cr._POLY_MIN_UNITS, cr._USE_S2RS, cr._HEAD_SPLIT, cb._FRONT_CHUNK)
+    try:
+        H.set_conv_mode("bf16x3")
+        cr._POLY_MIN_UNITS = 0                 # the polyphase tail runs at this size (its default threshold is four full-size frames)
+        rig_cache = True
+        if switch == "MVSGI_POLY":
+            cr._USE_POLY = False
+        elif switch == "MVSGI_S2RS":
+            cr._USE_S2RS = False
+        elif switch == "MVSGI_HEAD_SPLIT":
+            cr._HEAD_SPLIT = False
+        elif switch == "MVSGI_RIG_CACHE":
+            rig_cache = False
+        elif switch == "MVSGI_FRONT_CHUNK":
+            cb._FRONT_CHUNK = 1                # the sweep -> post_vol front end one frame at a time
+        else:
+            H.set_conv_mode("f32")
+        gain = 16.0
+        hp = HotPath(cfg, synth.make_weights(cfg, seed=case["seed"], gain=gain), inp, device=DEV)
+        hp.cv_builder.cache_rig_constants = rig_cache
+        inv, _ = hp(_g(inp["feats"]))
+        err = _rel(inv.cpu().numpy(), z[f"inv_dist_g{gain:g}"])
+        print(f"{switch} off: inv_dist max-rel {err:.3e}")
+        assert err <= 1e-3, (switch, err)
+    finally:
+        H.set_conv_mode(saved[0])
+        cr._USE_POLY, cr._POLY_MIN_UNITS, cr._USE_S2RS, cr._HEAD_SPLIT, cb._FRONT_CHUNK = saved[1:]
+
+
 _ORACLE_FULL = {}       # (case, gain) -> oracle inv_dist, shared by the two conv modes
 
 
@@ -573,7 +622,7 @@ def test_bench_two_ranks_frame_sharded_on_one_gpu():
     env = dict(os.environ, MVSGI_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29655", os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--backend", "gloo"],
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--backend", "gloo", "--settle-seconds", "0"],
                        capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -582,30 +631,33 @@ def test_bench_two_ranks_frame_sharded_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
     assert d["value"] > 0 and abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.02
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "mfma"
+    assert d["parity"]["max_rel"] <= 1e-3 and d["parity"]["frames"] == 1        # a multi-rank line carries an error figure too
 
 
 def test_bench_self_launches_its_ranks():
-    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how a driver that does not use torchrun would call
+    """`python bench.py --gpus 4` with no WORLD_SIZE in the environment (how a driver that does not use torchrun would call
     it) starts its own ranks as a child torch.distributed.run and relays rank 0's single line; the line says how many ranks
-    and which device ordinals really ran, and attributes the HBM-bound launches (sweep, soft-argmin) beside the convs."""
+    and which device ordinals really ran, and attributes the HBM-bound launches (sweep, soft-argmin) beside the convs.
+    Four ranks: a GPU box admits at most six processes on its card, this test process included (the eight-rank control plane runs over gloo on the CPU,
+    tests/test_bench_sharding.py::test_control_plane_world8_gloo)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["MVSGI_BENCH_SHARE_GPU"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--batch", "2", "--backend", "gloo"], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1",
+                        "--batch", "1", "--backend", "gloo", "--settle-seconds", "0"], capture_output=True, text=True, env=env, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line (rank 0)"
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["devices"] == [0, 0]
-    assert d["value"] > 0 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 4 and d["n_ranks_seen"] == 4 and d["devices"] == [0] * 4
+    assert d["value"] > 0 and d["scaling"] == "weak" and d["parity"]["max_rel"] <= 1e-3
     hbm = {k: v for k, v in d["kernels"].items() if v.get("bound") == "hbm"}
     assert any(k.startswith("sweep_std") for k in hbm) and any(k.startswith("softargmin") for k in hbm) and any(k.startswith("conv3d_head") for k in hbm)
     assert all(v["GBps"] > 0 for v in hbm.values())
-    assert d["roofline"]["attributed_time_frac_of_step"] > 0.7      # (two ranks share the card here: each rank's wall time holds the other's kernels)
+    assert d["roofline"]["attributed_time_frac_of_step"] > 0.2      # (four ranks share the card here: each rank's wall time holds the others' kernels)
 
 
 # ------------------------------------------------------------------------------ feature extractor (§8(f) rank 1)
@@ -1333,12 +1385,10 @@ def test_conv3d_rs16_split_output_is_the_split_of_the_fp32_output(shape):
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 2, 16), (2, 4, 8, 32), (1, 5, 7, 19), (3, 2, 9, 33), (2, 16, 20, 40), (4, 16, 80, 320)])
-@pytest.mark.parametrize("th", [4, 2])
-def test_conv3d_s2rs_vs_reference_conv(shape, th):
+def test_conv3d_s2rs_vs_reference_conv(shape, th=4):
     """The stride-2 16 -> 32 layer on split-padded activations (LDS-DMA staging, even / odd column de-interleave) against
     conv3d(stride 2, padding 1) + scale / shift + LeakyReLU in float64 on the same (16-bit-split) input: even and odd sizes,
-    ragged tiles, a launch with several bricks per workgroup (4 x 16 x 80 x 320: 3200 bricks); both brick heights; the output's
-    zero border untouched."""
+    ragged tiles, a launch with several bricks per workgroup (4 x 16 x 80 x 320: 3200 bricks); the output's zero border untouched."""
     B, d, h, w = shape
     rng = np.random.default_rng(sum(shape) + th)
     x = _g(rng.standard_normal((B, d, h, w, 16), dtype=np.float32))
@@ -1347,15 +1397,7 @@ def test_conv3d_s2rs_vs_reference_conv(shape, th):
     xs = H.act_to_split(x)
     do, ho, wo = (d - 1) // 2 + 1, (h - 1) // 2 + 1, (w - 1) // 2 + 1
     out = H.SplitAct(B, do, ho, wo, 32, x.device)
-    old = os.environ.get("MVSGI_S2RS_TH")
-    os.environ["MVSGI_S2RS_TH"] = str(th)              # read by the launcher on every call
-    try:
-        ys = H.conv3d_s2rs(xs, H.pack_conv_weights_s2rs(_g(wt), _g(sc)), _g(sh), out, neg_slope=0.01)
-    finally:
-        if old is None:
-            del os.environ["MVSGI_S2RS_TH"]
-        else:
-            os.environ["MVSGI_S2RS_TH"] = old
+    ys = H.conv3d_s2rs(xs, H.pack_conv_weights_s2rs(_g(wt), _g(sc)), _g(sh), out, neg_slope=0.01)
     y = H.act_from_split(ys).cpu().numpy()
     xq = H.act_from_split(xs).cpu().double().permute(0, 4, 1, 2, 3)
     ref = F.conv3d(xq, torch.from_numpy(wt).double(), padding=1, stride=2) * torch.from_numpy(sc).double().view(1, -1, 1, 1, 1) \
@@ -1510,7 +1552,7 @@ def test_hipgraph_survives_eager_calls_at_other_batch_sizes():
                                    (3, 16, 80, 320)])
 def test_softargmin_row_pair_kernel_equals_pixel_kernel_and_oracle(shape):
     """The x2 soft-argmin as one workgroup per low-resolution row pair (LDS-staged rows, four pixels per thread, 16-byte stores)
-    against the thread-per-pixel kernel (MVSGI_SOFTARGMIN_PIXEL=1) and the oracle: W % 4 != 0, odd W, two column tiles, H = 1,
+    against the thread-per-pixel kernel (run at scale 1 on the upsampled costs) and the oracle: W % 4 != 0, odd W, two column tiles, H = 1,
     D in registers (<= 16, <= 32) and the multi-pass form (D = 48), with and without norm_costs, with the / bf post-division."""
     B, D, Hh, W = shape
     rng = np.random.default_rng(sum(shape))
@@ -1519,13 +1561,11 @@ def test_softargmin_row_pair_kernel_equals_pixel_kernel_and_oracle(shape):
     c = _g(costs)
     inv, pr = H.softargmin(c, inv_idx, 2, True)
     inv_only, none = H.softargmin(c, inv_idx, 2, False, post_div=96.0)
-    os.environ["MVSGI_SOFTARGMIN_PIXEL"] = "1"
-    try:
-        inv_p, pr_p = H.softargmin(c, inv_idx, 2, True)
-    finally:
-        del os.environ["MVSGI_SOFTARGMIN_PIXEL"]
+    # the thread-per-pixel kernel serves scale 1: upsampling first and running it at scale 1 is the same arithmetic as its x2 path
+    up_dev = F.interpolate(c, scale_factor=2, mode="bilinear").contiguous()
+    inv_p, pr_p = H.softargmin(up_dev, inv_idx, 1, True)
     assert none is None and _rel(inv_only.cpu().numpy() * 96.0, inv.cpu().numpy()) <= 1e-6
-    assert _rel(inv.cpu().numpy(), inv_p.cpu().numpy()) <= 1e-6 and _rel(pr.cpu().numpy(), pr_p.cpu().numpy()) <= 1e-6
+    assert _rel(inv.cpu().numpy(), inv_p.cpu().numpy()) <= 1e-5 and _rel(pr.cpu().numpy(), pr_p.cpu().numpy()) <= 1e-5
     up = F.interpolate(torch.from_numpy(costs), scale_factor=2, mode="bilinear")
     ref_pr = F.softmax(up, 1)
     ref_inv = (ref_pr * inv_idx.cpu().view(1, -1, 1, 1)).sum(1, keepdim=True)
