@@ -46,7 +46,11 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="G16V")
-    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (64: +6 % over 32 on MI355X; 96 +1 % more)")
+    ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step, cut into --streams equal parts")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent parts of a step's batch, each on its own HIP stream inside the step's one hipGraph "
+                         "(StreamedHotPath: one part's kernel tails are filled by the other's launches; MI355X, G16V: 2 x 64 frames "
+                         "+1.8 % over 1 x 128 and +3.3 % over 1 x 64); 1 = the whole batch on one stream")
     ap.add_argument("--mode", default="bf16x3", choices=["bf16x3", "f32"],
                     help="conv arithmetic: split-bf16 MFMA (3 bf16 MFMAs per product, fp32 accumulate) or exact fp32 MFMA")
     ap.add_argument("--no-extras", action="store_true",
@@ -679,7 +683,7 @@ def main(argv=None):
     import torch.distributed as dist
     from mvs_gi_amd import hip_ops as H, synth
     from mvs_gi_amd.configs import CONFIGS, path_gflop
-    from mvs_gi_amd.pipeline import HotPath
+    from mvs_gi_amd.pipeline import HotPath, StreamedHotPath
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     if os.environ.get("MVSGI_BENCH_SHARE_GPU"):      # test hook: N ranks on one device (use --backend gloo)
@@ -704,13 +708,22 @@ def main(argv=None):
     peak = PEAK_TFLOPS[args.mode]
     inp = synth.make_inputs(cfg, seed=0, batch=1)
     weights = synth.make_weights(cfg, seed=0)
-    hp = HotPath(cfg, weights, inp, device=dev)
+    S = max(1, min(args.streams, B))
+    while B % S:                                 # a batch that does not split evenly runs in fewer parts
+        S -= 1
+    shp = StreamedHotPath(cfg, weights, inp, device=dev, n_streams=S)
+    hp = shp.parts[0]                            # one part: what the per-kernel attribution, the parity frame and the extras run on
     rng = np.random.default_rng(1000 + rank)     # every rank owns different frames
     feats = make_feats(B, inp["feats"].shape, rng, dev, torch, np)
     out = {}
 
     def step():
-        out["inv"], out["pr"] = hp(feats)
+        out["inv"], out["pr"] = shp(feats)[-1]
+
+    def step_serial():
+        # the same launches, part after part on ONE stream: per-kernel event pairs then time a kernel alone on the chip
+        for part, f in zip(shp.parts, feats.split(B // S, dim=0)):
+            out["inv"], out["pr"] = part(f)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -727,13 +740,13 @@ def main(argv=None):
     graph_note = None
     if use_graph:
         try:
-            hp.capture(feats)
+            shp.capture(feats)
         except Exception as e:      # never lose the run to the submission mode: per-launch submission measures the same kernels
             use_graph, graph_note = False, f"hipGraph capture failed ({type(e).__name__}: {e}); per-launch submission"
             torch.cuda.synchronize(dev)
     if use_graph:
         def timed_step():
-            out["inv"], out["pr"] = hp.replay()
+            out["inv"], out["pr"] = shp.replay()[-1]
         for _ in range(max(2, args.warmup // 2)):
             timed_step()
         sync()
@@ -754,7 +767,7 @@ def main(argv=None):
     # stream).  Kept out of the region above: ~70 event records per step cost ~3 % of it.
     with ConvProbe(H) as probe:
         probe.enabled = True
-        el_ev = timed_steps(step, sync, args.steps, 0, world, backend_ready, dev)
+        el_ev = timed_steps(step_serial, sync, args.steps, 0, world, backend_ready, dev)
         probe.enabled = False
         sync()
         agg = probe.summary()
@@ -778,6 +791,9 @@ def main(argv=None):
         "config": {"workload": f"{cfg.tag}: {cfg.num_cams} cams, D={cfg.num_cands}, builder={cfg.builder}, "
                                f"regulator=({cfg.reg_in_chs},{cfg.reg_f_int_chs}), feats {cfg.feat_hw}, cv {cfg.cv_hw}",
                    "frames_per_gpu_per_step": B, "parallelism": f"frame-sharded x{world} (no collective)",
+                   "streams": (f"{S} independent parts of {B // S} frames, each on its own HIP stream inside the step's graph (fork / join): one "
+                               "part's kernel tails are filled by the other's launches; extras.one_stream: the whole batch on one stream"
+                               if S > 1 else "one stream"),
                    "settle": f"{settle_steps} untimed steps behind the {args.warmup} warm-up steps ({args.settle_seconds} s since the first step): "
                              "the timed region starts at the power-capped clock (extras.sustained)",
                    "submission": ("one hipGraph replay per step (captured in warm-up; extras.eager_launches: per-launch submission)" if use_graph
@@ -799,8 +815,8 @@ def main(argv=None):
                      "avg_launch_us": round(dms / dn * 1e3, 2), "gflop_per_launch": round(dflops / dn / 1e9, 3),
                      "conv_time_frac_of_step": round(conv_ms / (el_ev * 1e3), 3),
                      "attributed_time_frac_of_step": round(attributed_ms / (el_ev * 1e3), 3),
-                     "how": "HIP events around every conv launch in a second pass of the same K steps "
-                            f"({round(el_ev / args.steps * 1e3, 4)} ms per step with the events in)"},
+                     "how": "HIP events around every conv launch in a second pass of the same K steps, the parts one after the other on "
+                            f"one stream ({round(el_ev / args.steps * 1e3, 4)} ms per step with the events in): a launch is {B // S} frames"},
         "kernels": kernels_block(agg, hbm_agg),
         "n_ranks_seen": dist.get_world_size() if backend_ready else 1,
         "devices": devices,
@@ -815,8 +831,8 @@ def main(argv=None):
                          "frames": 1, "mode": args.mode}
     # ---- extras: single GPU only, outside the timed region above
     if world == 1 and rank == 0 and not args.no_extras:
-        res["extras"] = run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, value)
-        del hp, feats
+        res["extras"] = run_extras(args, cfg, B // S, hp, feats[:B // S], weights, dev, H, synth, torch, np, rng, value, shp, feats)
+        del hp, shp, feats
         torch.cuda.empty_cache()
         cfgs = {}
         for tag, b in EXTRA_CONFIGS:
@@ -843,8 +859,10 @@ def main(argv=None):
         print(json.dumps(res), flush=True)
 
 
-def run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, headline_fps):
-    """Measurements beside the headline (same process, same device, after the timed region)."""
+def run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, headline_fps, shp, feats_all):
+    """Measurements beside the headline (same process, same device, after the timed region).  `hp`, `feats`, `B`: ONE part of the
+    headline's step (one stream); `shp`, `feats_all`: the headline's whole step."""
+    B_all = feats_all.shape[0]
     use_graph = not args.eager
     from mvs_gi_amd import dropin
     from mvs_gi_amd.pipeline import HotPath
@@ -889,22 +907,38 @@ def run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, 
     guarded("inverse_distance_only", inv_only)
 
     def graph():
-        if use_graph:      # the headline is the graph: report the per-launch submission beside it
-            el = timed_steps(lambda: hp(feats), sync, K, W, 1, False, dev)
+        if use_graph:      # the headline is the graph: report the per-launch submission of the same step beside it
+            el = timed_steps(lambda: shp(feats_all), sync, K, W, 1, False, dev)
         else:
-            hp.capture(feats)
-            el = timed_steps(lambda: hp.replay(), sync, K, W, 1, False, dev)
-        return {"frames_per_s": round(B * K / el, 2), "ms_per_step": round(el / K * 1e3, 4)}
+            shp.capture(feats_all)
+            el = timed_steps(lambda: shp.replay(), sync, K, W, 1, False, dev)
+        return {"frames_per_s": round(B_all * K / el, 2), "ms_per_step": round(el / K * 1e3, 4)}
     guarded("eager_launches" if use_graph else "graph_replay", graph)
+
+    def one_stream():
+        # the headline's batch, and one part of it (round 3's headline: 64 frames), each as ONE launch chain on one stream
+        r = {}
+        for name, f in (("whole_batch", feats_all), ("one_part", feats)):
+            n = f.shape[0]
+            if use_graph:
+                hp.capture(f)
+                el = timed_steps(lambda: hp.replay(), sync, K, W, 1, False, dev)
+            else:
+                el = timed_steps(lambda: hp(f), sync, K, W, 1, False, dev)
+            r[name] = {"frames_per_step": n, "frames_per_s": round(n * K / el, 2), "ms_per_step": round(el / K * 1e3, 4)}
+        r["note"] = "the same kernels without the second stream: what the fork / join inside the step's graph buys"
+        return r
+    if len(shp.parts) > 1:
+        guarded("one_stream", one_stream)
 
     def sustained():
         # the headline's submission (the captured graph, or per-launch with --eager) for >= 3 s and >= 250 steps; the rate over
         # the LAST second, with the board's power and shader clock (hwmon) sampled by a thread of this process during the loop
         import glob
         import threading
-        if use_graph and getattr(hp, "_graph", None) is None:
-            hp.capture(feats)
-        fn = hp.replay if use_graph else (lambda: hp(feats))
+        if use_graph and getattr(shp, "_graph", None) is None:
+            shp.capture(feats_all)
+        fn = shp.replay if use_graph else (lambda: shp(feats_all))
         samples, stop = [], threading.Event()
 
         def read_num(path, scale):
@@ -942,12 +976,12 @@ def run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, 
         th.join()
         t_end, n_end = marks[-1]
         t_a, n_a = min(marks, key=lambda m: abs(m[0] - (t_end - 1.0)))
-        last = B * (n_end - n_a) / (t_end - t_a)
-        first = B * marks[0][1] / marks[0][0]
+        last = B_all * (n_end - n_a) / (t_end - t_a)
+        first = B_all * marks[0][1] / marks[0][0]
         pw = [(t - t0, w, f) for t, w, f in samples if w is not None or f is not None]
         tail = [x for x in pw if x[0] >= t_end - 1.0]
         avg = lambda xs: round(sum(xs) / len(xs), 1) if xs else None      # noqa: E731
-        return {"frames_per_s_last_second": round(last, 2), "frames_per_s_whole_run": round(B * n_end / t_end, 2),
+        return {"frames_per_s_last_second": round(last, 2), "frames_per_s_whole_run": round(B_all * n_end / t_end, 2),
                 "frames_per_s_first_5_steps": round(first, 2), "seconds": round(t_end, 2), "steps": n_end,
                 "vs_headline": round(last / headline_fps, 4),
                 "power_W_last_second": avg([w for _, w, _ in tail if w is not None]),

@@ -144,6 +144,9 @@ class ConvLaunch:
 
     def run_up2_split(self, x_lowres_ndhwc: Tensor, res: Optional[Tensor], out) -> "H.SplitAct":
         """conv(trilinear_x2(x)) (+ res) written split-padded into `out` (the polyphase layer's input)."""
+        if self._c16():       # Cout == 16: the plane schedule (one cout tile)
+            return H.conv3d_up2_out_split(x_lowres_ndhwc, self._wp_c16(), self.scale, self.shift, out=out, res=res,
+                                          neg_slope=self.neg_slope, w_layout=H.CONV_BF16X3_C16)
         return H.conv3d_up2_out_split(x_lowres_ndhwc, self._wp_b3(), self.scale, self.shift, out=out, res=res, neg_slope=self.neg_slope)
 
     def can_fuse_up2(self) -> bool:

@@ -190,8 +190,30 @@ def regulator_forward_ndhwc(self, x: Tensor) -> Tensor:
             if y is not None:
                 return y
         x = cm.resize_conv_ndhwc(up, x, res=skips[i])
+    y = _split_head_tail(self, x)          # out_costs.0 writes the split-padded format the split-bf16 cost head reads
+    if y is not None:
+        return y
     x = cm.resize_conv_ndhwc(self.out_costs[0], x)
     return cm.lower_conv_block(self.out_costs[1]).run(x)
+
+
+def _split_head_tail(self, x: Tensor):
+    """out_costs of a regulator the polyphase tail does not serve (every shape but (16, 32)): the ResizeConv3d on the streaming
+    kernel (upsample in its producers) writes its result split-padded into a module-owned buffer, and the cost head
+    (csrc/conv3d_headsplit.hip) takes whole B operands from it -- 2 x 16 matrix-core cycles per 16 voxels and 16 taps instead of the
+    exact-fp32 head's 8 x 64 per 32 voxels, which is bound by the fp32 matrix rate.  Returns costs [B, D, H, W, 1] or None."""
+    oc = self.out_costs[0]
+    Lo, Lh = cm.lower_conv_block(oc.conv), cm.lower_conv_block(self.out_costs[1])
+    if not (_HEAD_SPLIT and Lh.head_split_ok() and Lo.can_fuse_up2() and oc.scale == 2 and oc.out_pad == 0 and Lh.cin == Lo.cout):
+        return None
+    B, Dl, Hl, Wl, _ = x.shape
+    if (2 * Dl + 2) * (2 * Hl + 2) * (2 * Wl + 2) * Lo.cout * 4 >= 2 ** 31:        # the split-padded frame must fit 32-bit offsets
+        return None
+    bufs = self.__dict__.setdefault("_mvsgi_poly_bufs", {})          # one split-padded buffer per shape, never replaced
+    key = (B, 2 * Dl, 2 * Hl, 2 * Wl, Lo.cout, "head-in", x.device)
+    if key not in bufs:
+        bufs[key] = H.SplitAct(B, 2 * Dl, 2 * Hl, 2 * Wl, Lo.cout, x.device)
+    return Lh.run_head_split(Lo.run_up2_split(x, None, bufs[key]))
 
 
 def regulator_forward(self, x: Tensor) -> Tensor:

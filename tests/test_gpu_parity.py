@@ -174,11 +174,15 @@ CONV_SHAPES = [
     (24, 32, 128, 1, 10, 40, 1, True, 0.01),    # one-plane volume (E8's level 2): 1 x 5 x 16 bricks, 128-cout units
     (64, 16, 192, 1, 10, 40, 1, False, 0.01),   # ... 192-cout units
     (96, 16, 128, 1, 7, 21, 1, True, 0.0),      # one-plane volume, H not a multiple of 5: 1 x 4 x 16 bricks, ragged
+    (64, 16, 96, 8, 16, 24, 2, False, 0.01),    # stride 2 in 96-cout units
+    (48, 32, 128, 7, 17, 23, 2, False, 0.01),   # stride 2 in 128-cout units, odd sizes
+    (64, 16, 192, 8, 16, 24, 2, False, 0.0),    # stride 2 in 192-cout units
 ]
 EXPECTED_VARIANT = {        # (B, Cin, Cout, D, H, W) -> brick / unit shape the dispatcher must pick
     (32, 128, 128, 2, 10, 40): "<2, 5, 2, 2, 2, 5, 16", (32, 64, 64, 3, 15, 21): "<2, 5, 2, 2, 2, 5, 16",
     (32, 32, 96, 4, 10, 40): "<3, 5, 2, 2, 2, 5, 16", (24, 32, 128, 1, 10, 40): "<2, 5, 1, 4, 1, 5, 16",
     (64, 16, 192, 1, 10, 40): "<3, 5, 1, 4, 1, 5, 16", (96, 16, 128, 1, 7, 21): "<2, 4, 1, 4, 1, 4, 16",
+    (64, 16, 96, 8, 16, 24): "<3, 2, 2, 2, 2, 4, 8, 2", (48, 32, 128, 7, 17, 23): "<2, 4, 1, 4, 2, 4, 8, 2", (64, 16, 192, 8, 16, 24): "<3, 4, 1, 4, 2, 4, 8, 2",
 }
 
 
@@ -610,6 +614,41 @@ def test_hipgraph_replay_equals_eager():
     g1b = hp.replay(f1)[0].clone()
     assert torch.equal(e1, g1) and torch.equal(e2, g2) and torch.equal(g1, g1b)
     assert not torch.equal(g1, g2)
+
+
+@pytest.mark.parametrize("conv_mode", ["bf16x3"])
+def test_streamed_hot_path_equals_one_stream(conv_mode):
+    """StreamedHotPath (the batch in two parts on two HIP streams, fork / join; one hipGraph) returns, part by part, exactly what
+    one HotPath returns for the whole batch -- eagerly and as a graph replay, also for new contents of the static input -- at a
+    size where the register-stationary kernels and the split-padded hand-over run (module-owned buffers per replica)."""
+    from mvs_gi_amd.configs import CONFIGS, DIST_8L
+    from mvs_gi_amd.pipeline import StreamedHotPath
+    old = H.get_conv_mode()
+    H.set_conv_mode(conv_mode)
+    try:
+        cfg = CONFIGS["G16V"].scaled(feat_hw=(32, 128), mask_hw=(64, 256), cv_hw=(16, 64), dist_cands=DIST_8L)
+        inp = synth.make_inputs(cfg, seed=7, batch=1)
+        w = synth.make_weights(cfg, seed=7)
+        hp = HotPath(cfg, w, inp, device=DEV)
+        shp = StreamedHotPath(cfg, w, inp, device=DEV, n_streams=2)
+        rng = np.random.default_rng(3)
+        f1 = _g(rng.standard_normal((6, *inp["feats"].shape[1:]), dtype=np.float32))
+        f2 = _g(rng.standard_normal((6, *inp["feats"].shape[1:]), dtype=np.float32))
+        ref1, ref2 = [t.clone() for t in hp(f1)], [t.clone() for t in hp(f2)]
+        for attempt in range(3):                               # repeated: a race between the parts' buffers would show as a flaky mismatch
+            parts = shp(f1)
+            torch.cuda.synchronize()
+            assert len(parts) == 2
+            assert torch.equal(torch.cat([p[0] for p in parts]), ref1[0]) and torch.equal(torch.cat([p[1] for p in parts]), ref1[1])
+        shp.capture(f1)
+        for f, ref in ((f1, ref1), (f2, ref2), (f1, ref1)):
+            parts = shp.replay(f)
+            torch.cuda.synchronize()
+            assert torch.equal(torch.cat([p[0] for p in parts]), ref[0])
+        with pytest.raises(ValueError):
+            shp(f1[:5])                                        # five frames do not split into two equal parts
+    finally:
+        H.set_conv_mode(old)
 
 
 def test_bench_two_ranks_frame_sharded_on_one_gpu():
