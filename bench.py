@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0}   # MI355X_MICROARCH.md: dense fp32-MFMA / bf16-MFMA peaks
 DTYPE = {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA operands, f32 accumulate/activations)"}
 PEAK_HBM_GBS = 8000.0
-EXTRA_CONFIGS = (("G16VV", 32), ("E8", 64), ("4cam-32", 32))      # (tag, frames per step at which the configuration runs best on MI355X)
+EXTRA_CONFIGS = (("G16VV", 32), ("E8", 64), ("4cam-32", 16))      # (tag, frames per part (= per stream) at which the configuration runs best on MI355X: tools/config_batch_probe.py)
 LIB = os.path.join(ROOT, "mvs_gi_amd", "libmvsgi_hip.so")
 
 
@@ -610,14 +610,18 @@ def make_feats(B, shape, rng, dev, torch, np, nchw=False):
     return torch.from_numpy(rng.standard_normal((B, N, Hi, Wi, C), dtype=np.float32)).to(dev).permute(0, 1, 4, 2, 3)
 
 
-def measure_path(cfg, B, mode, steps, warmup, dev, H, HotPath, synth, torch, np, rng, graph=False, kernels=False):
+def measure_path(cfg, B, mode, steps, warmup, dev, H, HotPath, synth, torch, np, rng, graph=False, kernels=False, streams=1):
     """frames/s, ms/step and per-conv-kernel attribution of one configuration at one batch size (single process,
-    outside the headline's timed region)."""
+    outside the headline's timed region).  frames_per_s / the kernel table: B frames as one launch chain on one stream;
+    graph_replay_*: as the headline submits a step -- `streams` parts of B frames each in one hipGraph."""
     from mvs_gi_amd.configs import path_gflop
+    from mvs_gi_amd.pipeline import StreamedHotPath
     H.set_conv_mode(mode)
     inp = synth.make_inputs(cfg, seed=0, batch=1)
-    hp = HotPath(cfg, synth.make_weights(cfg, seed=0), inp, device=dev)
-    feats = make_feats(B, inp["feats"].shape, rng, dev, torch, np)
+    shp = StreamedHotPath(cfg, synth.make_weights(cfg, seed=0), inp, device=dev, n_streams=max(1, streams))
+    hp = shp.parts[0]
+    feats_all = make_feats(B * len(shp.parts), inp["feats"].shape, rng, dev, torch, np)
+    feats = feats_all[:B]
 
     def step():
         hp(feats)
@@ -642,14 +646,15 @@ def measure_path(cfg, B, mode, steps, warmup, dev, H, HotPath, synth, torch, np,
         res["kernels"] = kernels_block(agg, hbm_agg)
     if graph:
         try:
-            hp.capture(feats)
-            gel = timed_steps(lambda: hp.replay(), sync, steps, warmup, 1, False, dev)
-            res["graph_replay_frames_per_s"] = round(B * steps / gel, 2)
+            shp.capture(feats_all)
+            gel = timed_steps(lambda: shp.replay(), sync, steps, warmup, 1, False, dev)
+            res["graph_replay_frames_per_s"] = round(feats_all.shape[0] * steps / gel, 2)
             res["graph_replay_ms_per_step"] = round(gel / steps * 1e3, 4)
+            res["graph_replay_frames_per_step"] = feats_all.shape[0]
         except Exception as e:
             res["graph_replay_error"] = f"{type(e).__name__}: {e}"
             torch.cuda.synchronize(dev)
-    del hp, feats
+    del hp, shp, feats, feats_all
     torch.cuda.empty_cache()
     return res
 
@@ -840,12 +845,13 @@ def main(argv=None):
                 continue
             try:
                 m = measure_path(CONFIGS[tag], b, args.mode, args.extra_steps, 3, dev, H, HotPath, synth, torch, np, rng,
-                                 graph=use_graph, kernels=True)
-                if "graph_replay_frames_per_s" in m:      # as the headline: the step is one hipGraph replay (per-launch beside it)
-                    m["eager_frames_per_s"], m["eager_ms_per_step"] = m["frames_per_s"], m["ms_per_step"]
+                                 graph=use_graph, kernels=True, streams=S)
+                if "graph_replay_frames_per_s" in m:      # as the headline: parts on their own streams, one hipGraph replay per step
+                    m["one_stream_eager_frames_per_s"], m["one_stream_eager_ms_per_step"] = m["frames_per_s"], m["ms_per_step"]
                     m["frames_per_s"], m["ms_per_step"] = m.pop("graph_replay_frames_per_s"), m.pop("graph_replay_ms_per_step")
+                    m["frames_per_step"] = m.pop("graph_replay_frames_per_step")
                     m["path_tflops"] = round(m["frames_per_s"] * path_gflop(CONFIGS[tag]) / 1e3, 2)
-                    m["submission"] = "one hipGraph replay per step"
+                    m["submission"] = f"{S} parts of {b} frames on their own streams, one hipGraph replay per step"
                 cfgs[tag] = m
             except Exception as e:       # never lose the headline to an extra
                 cfgs[tag] = {"error": f"{type(e).__name__}: {e}"}

@@ -209,8 +209,8 @@ def _split_head_tail(self, x: Tensor):
     B, Dl, Hl, Wl, _ = x.shape
     if (2 * Dl + 2) * (2 * Hl + 2) * (2 * Wl + 2) * Lo.cout * 4 >= 2 ** 31:        # the split-padded frame must fit 32-bit offsets
         return None
-    bufs = self.__dict__.setdefault("_mvsgi_poly_bufs", {})          # one split-padded buffer per shape, never replaced
-    key = (B, 2 * Dl, 2 * Hl, 2 * Wl, Lo.cout, "head-in", x.device)
+    bufs = self.__dict__.setdefault("_mvsgi_head_bufs", {})          # one split-padded buffer per shape, never replaced
+    key = (B, 2 * Dl, 2 * Hl, 2 * Wl, Lo.cout, x.device)
     if key not in bufs:
         bufs[key] = H.SplitAct(B, 2 * Dl, 2 * Hl, 2 * Wl, Lo.cout, x.device)
     return Lh.run_head_split(Lo.run_up2_split(x, None, bufs[key]))
