@@ -81,6 +81,19 @@ inline int persistent_geometry(K kern, int threads, size_t lds_bytes, int max_wg
     return 0;
 }
 
+// CU count of the current device (cached per device ordinal; 256 when it cannot be read: MI355X)
+inline int device_cus() {
+    static int cache[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+    if (!cache[dev]) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        cache[dev] = cus;
+    }
+    return cache[dev];
+}
+
 // csrc/conv3d_rs.hip: the 32 -> 32 register-stationary kernel as the body of the polyphase ResizeConv3d (csrc/conv3d_up2poly.hip)
 constexpr size_t kRs32PackedBytes = (size_t)2 * 2 * 14 * 2 * 64 * 16;      // one weight set in the kernel's lane order
 void rs32_pack_weights_host(const float* w_oidhw_32x32x27, void* packed);

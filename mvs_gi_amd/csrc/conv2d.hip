@@ -256,9 +256,9 @@ __global__ __launch_bounds__(256) void conv2d_stem_u8_mfma_kernel(StemArgs a) {
 enum Variant2d { D2_DIRECT, D2_N16, D2_N32, D2_N64, D2_S2_N32, D2_S2_N64, D2_F32_N16, D2_F32_N32, D2_F32_S2, D2_COUNT };
 const char* const kNames2d[D2_COUNT] = {
     "conv2d_direct_kernel<4>",
-    "conv3d_bf16x3_kernel<1, 4, 4, 1, 1, 16, 16, 1, 1, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 1, 16, 16, 1, 1, false, false, false>",
-    "conv3d_bf16x3_kernel<2, 4, 2, 2, 1, 8, 16, 1, 1, false, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 2, 1, false, false, false>",
-    "conv3d_bf16x3_kernel<2, 2, 2, 2, 1, 4, 16, 2, 1, false, false, false>",
+    "conv3d_bf16x3_kernel<1, 4, 4, 1, 1, 16, 16, 1, 1, false, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 1, 16, 16, 1, 1, false, false, false, false>",
+    "conv3d_bf16x3_kernel<2, 4, 2, 2, 1, 8, 16, 1, 1, false, false, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 2, 1, false, false, false, false>",
+    "conv3d_bf16x3_kernel<2, 2, 2, 2, 1, 4, 16, 2, 1, false, false, false, false>",
     "conv3d_mfma_kernel<1, 4, 4, 1, 1, 16, 16, 1, 1>", "conv3d_mfma_kernel<2, 4, 4, 1, 1, 16, 16, 1, 1>",
     "conv3d_mfma_kernel<2, 1, 4, 1, 1, 4, 16, 2, 1>",
 };

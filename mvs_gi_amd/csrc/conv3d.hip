@@ -299,7 +299,7 @@ enum Variant {
     V_DIRECT1, V_DIRECT4, V_HEAD,
     V_S1_N16_B256, V_S1_N32_B256, V_S1_N32_B64, V_S1_N64_B128, V_S1_N64_B64, V_S2_N32_B64, V_S2_N64_B64,
     // split-bf16 kernel: 16-wide bricks (conflict-free LDS reads); N = couts per workgroup
-    B3_N16, B3_N32, B3_N48, B3_N64, B3_N64_H5, B3_N96, B3_N96_H5, B3_N128_P, B3_N128_PH5, B3_N192_PH5, B3_N32_S, B3_N64_S, B3_N16_T, B3_N32_T, B3_S2_N32, B3_S2_N64, B3_S2_N96, B3_S2_N128, B3_S2_N192,
+    B3_N16, B3_N32, B3_N48, B3_N64, B3_N64_H5, B3_N96, B3_N96_H5, B3_N128_P, B3_N128_PH5, B3_N192_PH5, B3_N32_S, B3_N64_S, B3_N16_T, B3_N32_T, B3_N16_TW, B3_S2_N32, B3_S2_N64, B3_S2_N96, B3_S2_N128, B3_S2_N192,
     // split-bf16 kernel with the trilinear x2 upsample fused into its producers (even bricks only)
     B3U_N16, B3U_N32, B3U_N32_M, B3U_N48, B3U_N64, B3U_N96,
     // Cout == 16 plane schedule (weights from mvsgi_conv3d_pack_weights_bf16x3_c16), plain and fused-upsample
@@ -314,25 +314,26 @@ const char* const kVariantNames[] = {
     "conv3d_mfma_kernel<2, 1, 4, 1, 2, 4, 8, 1>", "conv3d_mfma_kernel<2, 4, 2, 2, 2, 8, 8, 1>",
     "conv3d_mfma_kernel<2, 2, 2, 2, 2, 4, 8, 1>", "conv3d_mfma_kernel<2, 1, 4, 1, 2, 4, 8, 2>",
     "conv3d_mfma_kernel<2, 2, 2, 2, 2, 4, 8, 2>",
-    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false>",
-    "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, false, false, false>",
-    "conv3d_bf16x3_kernel<2, 5, 2, 2, 2, 5, 16, 1, 3, false, false, false>",
-    "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<3, 5, 2, 2, 2, 5, 16, 1, 3, false, false, false>",
-    "conv3d_bf16x3_kernel<2, 4, 1, 4, 1, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 5, 1, 4, 1, 5, 16, 1, 3, false, false, false>",
-    "conv3d_bf16x3_kernel<3, 5, 1, 4, 1, 5, 16, 1, 3, false, false, false>",
-    "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false>",
-    "conv3d_bf16x3_kernel<2, 2, 2, 2, 1, 4, 16, 1, 3, false, false, false>",
-    "conv3d_bf16x3_kernel<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false>",
-    "conv3d_bf16x3_kernel<2, 1, 4, 1, 2, 4, 8, 2, 3, false, false, false>",
-    "conv3d_bf16x3_kernel<2, 2, 2, 2, 2, 4, 8, 2, 3, false, false, false>",
-    "conv3d_bf16x3_kernel<3, 2, 2, 2, 2, 4, 8, 2, 3, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 1, 4, 2, 4, 8, 2, 3, false, false, false>",
-    "conv3d_bf16x3_kernel<3, 4, 1, 4, 2, 4, 8, 2, 3, false, false, false>",
-    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, true, false, false>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1, 3, true, false, false>",
-    "conv3d_bf16x3_kernel<2, 2, 4, 1, 2, 4, 16, 1, 3, true, false, false>", "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1, 3, true, false, false>",
-    "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, true, false, false>", "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, true, false, false>",
-    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, false, true, false>", "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, true, true, false>",
-    "conv3d_bf16x3_kernel<1, 2, 4, 1, 4, 4, 16, 1, 3, false, false, true>", "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 16, 1, 3, false, false, true>",
-    "conv3d_bf16x3_kernel<1, 2, 4, 1, 4, 4, 16, 1, 3, true, false, true>", "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 16, 1, 3, true, false, true>",
+    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1, 3, false, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<2, 5, 2, 2, 2, 5, 16, 1, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, false, false, false, false>", "conv3d_bf16x3_kernel<3, 5, 2, 2, 2, 5, 16, 1, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<2, 4, 1, 4, 1, 4, 16, 1, 3, false, false, false, false>", "conv3d_bf16x3_kernel<2, 5, 1, 4, 1, 5, 16, 1, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<3, 5, 1, 4, 1, 5, 16, 1, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<2, 2, 2, 2, 1, 4, 16, 1, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>",
+    "conv3d_bf16x3_kernel<2, 1, 4, 1, 2, 4, 8, 2, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<2, 2, 2, 2, 2, 4, 8, 2, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<3, 2, 2, 2, 2, 4, 8, 2, 3, false, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 1, 4, 2, 4, 8, 2, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<3, 4, 1, 4, 2, 4, 8, 2, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, true, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1, 3, true, false, false, false>",
+    "conv3d_bf16x3_kernel<2, 2, 4, 1, 2, 4, 16, 1, 3, true, false, false, false>", "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1, 3, true, false, false, false>",
+    "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, true, false, false, false>", "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, true, false, false, false>",
+    "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, false, true, false, false>", "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, true, true, false, false>",
+    "conv3d_bf16x3_kernel<1, 2, 4, 1, 4, 4, 16, 1, 3, false, false, true, false>", "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 16, 1, 3, false, false, true, false>",
+    "conv3d_bf16x3_kernel<1, 2, 4, 1, 4, 4, 16, 1, 3, true, false, true, false>", "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 16, 1, 3, true, false, true, false>",
 };
 static_assert(sizeof(kVariantNames) / sizeof(kVariantNames[0]) == V_COUNT, "one name per variant");
 
@@ -433,7 +434,8 @@ int select_variant(const ConvArgs& a, int impl) {
 #ifdef MVSGI_EXPERIMENTAL
         if (const char* f = mvsgi::exp_env("MVSGI_B3_FORCE")) {       // force a variant by its enum name suffix (tools/ only)
             static const struct { const char* n; int v; } tab[] = {{"N64", B3_N64}, {"N64_H5", B3_N64_H5}, {"N96", B3_N96}, {"N96_H5", B3_N96_H5},
-                {"N128_P", B3_N128_P}, {"N128_PH5", B3_N128_PH5}, {"N192_PH5", B3_N192_PH5}, {"N64_S", B3_N64_S}};
+                {"N128_P", B3_N128_P}, {"N128_PH5", B3_N128_PH5}, {"N192_PH5", B3_N192_PH5}, {"N64_S", B3_N64_S},
+                {"N16_T", B3_N16_T}, {"N32_T", B3_N32_T}, {"N16_TW", B3_N16_TW}, {"N32_S", B3_N32_S}};
             for (const auto& t : tab) if (!strcmp(f, t.n)) return t.v;
         }
 #endif
@@ -454,15 +456,18 @@ int select_variant(const ConvArgs& a, int impl) {
         if (h5 && h5ok && (long long)a.B * mvsgi::cdiv(a.Do, 2) * (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16) * mvsgi::cdiv(CT, 4) >= 384)
             return B3_N64_H5;
         if (mid * mvsgi::cdiv(CT, 4) >= 384) return B3_N64;
-        // a frame or two (latency path): 64-voxel bricks, and as few couts per workgroup as it takes to put a few hundred
-        // workgroups on the chip -- each then walks Cin / 16 slices of 42 (16 couts) or 84 (32 couts) MFMAs per wave
+        // a few frames (latency path): 64-voxel bricks.  A workgroup of this kernel fills a CU (8 waves x 256 registers), so a launch
+        // runs in rounds of one unit per CU and a round costs its unit's Cin / 16 slices end to end: the couts per unit are the
+        // FEWEST that still put every unit into the first round.  Measured per launch (MI355X, hipGraph replay, tools/wlds_probe.py),
+        // 16 / 32 / 64 couts per unit: 64 -> 64 [4,20,80] x 1 frame 14.8 / 12.2 / 12.4 us, x 2 frames 25.5 / 20.1 / 12.8;
+        // 128 -> 128 [2,10,40] x 1: 13.2 / 18.9 / 20.0, x 2: 23.1 / 18.8 / 19.9, x 4: 32.6 / 34.5 / 20.2 -- round 3's rule picked
+        // the variant with AT LEAST 256 units instead (x 4: 35.4 us).  The 16-cout units take their weight slice through LDS
+        // (conv3d_bf16x3.hpp, WLDS: the four consumer waves share it; 13.2 -> 12.7 us).
         const long long tiny = (long long)a.B * a.Do * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
-        static const int force = mvsgi::exp_env("MVSGI_B3_SMALL") ? atoi(mvsgi::exp_env("MVSGI_B3_SMALL")) : 0;      // experiments: 16 / 32 / 64
-        if (force == 16) return B3_N16_T;
-        if (force == 32) return B3_N32_T;
-        if (force == 64) return B3_N64_S;
-        if (tiny * mvsgi::cdiv(CT, 4) >= 256) return B3_N64_S;
-        return tiny * mvsgi::cdiv(CT, 2) >= 256 ? B3_N32_T : B3_N16_T;
+        const long long cus = mvsgi::device_cus();
+        if (tiny * CT <= cus) return B3_N16_TW;
+        if (tiny * mvsgi::cdiv(CT, 2) <= cus) return B3_N32_T;
+        return B3_N64_S;
     }
     if (a.stride == 1) {
         if (CT == 1) return V_S1_N16_B256;
@@ -496,8 +501,13 @@ int launch_variant(int v, const ConvArgs& a, hipStream_t st) {
         case B3_N192_PH5: return launch_bf16x3<3, 5, 1, 4, 1, 5, 16, 1>(a, st);
         case B3_N32_S: return launch_bf16x3<2, 1, 4, 1, 1, 4, 16, 1>(a, st);
         case B3_N64_S: return launch_bf16x3<2, 2, 2, 2, 1, 4, 16, 1>(a, st);
+#ifdef MVSGI_EXPERIMENTAL      // the dispatcher's 16-cout units are B3_N16_TW; this one is the A/B reference of tools/wlds_probe.py
         case B3_N16_T: return launch_bf16x3<1, 1, 4, 1, 1, 4, 16, 1>(a, st);
+#else
+        case B3_N16_T: return launch_bf16x3<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>(a, st);
+#endif
         case B3_N32_T: return launch_bf16x3<2, 1, 4, 1, 1, 4, 16, 1>(a, st);
+        case B3_N16_TW: return launch_bf16x3<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>(a, st);
         case B3_S2_N32: return launch_bf16x3<2, 1, 4, 1, 2, 4, 8, 2>(a, st);
         case B3_S2_N64: return launch_bf16x3<2, 2, 2, 2, 2, 4, 8, 2>(a, st);
         case B3_S2_N96: return launch_bf16x3<3, 2, 2, 2, 2, 4, 8, 2>(a, st);

@@ -198,9 +198,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // pitch is padded to a multiple of 256 B, which makes the 16-lane ds_read_b128 groups conflict-free for every
 // tap (rows differ by 0 mod 256 B, so the two half-rows of a group tile the 16 bank units exactly).
 // Weights: pack_weights_bf16x3_v32_kernel.
+//
+// WLDS = true is the schedule for the small launches (a frame or four) where the four consumer waves of a workgroup share
+// their cout tiles (WN == 1) and multiply ONE voxel tile each: every wave would fetch the same 2 KiB of weight fragments per
+// 48-cycle slot, 170 B / clk / CU through a vector-memory path that returns 64 (measured: ~200 cycles per slot).  The producers
+// stage the unit's weight slice (NW x 28 KiB, contiguous in the packed layout) into LDS beside the activation image, once per
+// workgroup, under the same per-unit barrier; the consumers read weight fragments like activation fragments (XB-deep, restarted
+// per unit): 16 ds_read_b128 per slot and CU instead of 8 KiB of vector-memory returns.
 template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false, bool PLANE = false,
-          bool V32 = false>
+          bool V32 = false, bool WLDS = false>
 __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {      // 2 waves per SIMD: 256 registers
+    static_assert(!WLDS || (WN == 1 && KD == 3 && !UPS && !PLANE && !V32 && S == 1 && MW * NW <= 2), "LDS-staged weights: shared cout tiles, one or two tiles per wave");
     static_assert(!V32 || (S == 1 && KD == 3 && TW == 16 && TH % 2 == 0 && !PLANE), "32x32x16 schedule: stride 1, 16-wide even bricks");
     static_assert(!PLANE || (NW == 1 && WN == 1 && WM == 4 && TH == 4 && MW == TD && TW == 16 && S == 1 && KD == 3),
                   "plane schedule: Cout == 16, 4 h-rows x TD planes x 16 w per brick");
@@ -221,7 +229,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
     // that every register-buffer index is a compile-time constant.
     // One or two tiles per wave (the one-frame variants): a slot is 3-6 MFMAs, far less than an L2 round trip, so the
     // fragments of (nearly) a whole slice are kept in flight -- 16 / 8 buffers instead of 4.
-    constexpr int WB = (KD == 3 && !PLANE && !V32 && MW * NW == 1) ? 16 : (KD == 3 && !PLANE && !V32 && MW * NW == 2) ? 8 :
+    constexpr int WB = WLDS ? (MW * NW == 1 ? 8 : 4) :         // = XB: weight and activation fragments of a slot travel together
+                       (KD == 3 && !PLANE && !V32 && MW * NW == 1) ? 16 : (KD == 3 && !PLANE && !V32 && MW * NW == 2) ? 8 :
 #ifndef MVSGI_WBX
 #define MVSGI_WBX 5      // five buffers (four slots ahead) for the 2 x 4-tile variants: 214 + 16 registers; measured against 4 and 6
 #endif
@@ -231,6 +240,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
     constexpr int NSLOT = ((kPairs + WB - 1) / WB) * WB;
     static_assert(NSLOT % WB == 0 && NSLOT >= kPairs, "pipeline geometry");
     constexpr bool RPRE = MW * NW <= 8;            // residual tiles requested during the last slot (register budget)
+    constexpr int WBYTES = WLDS ? NW * kPairs * 2048 : 0;      // the unit's weight slice in LDS, behind its activation image
+    constexpr int BUFW = BUF + WBYTES;             // one buffer of the double-buffered LDS (image + weights)
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -466,6 +477,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
         // offset plus three range checks per item -- the per-brick plan used to redo all of it and was most of the ~40 vector
         // instructions a producer spent per 16 staged bytes in the single-slice layers (Cin = 16: down.0.first).
         int ibase[NIT];          // byte offset of the item relative to the brick's origin voxel
+        // WLDS: this wave's share of the unit's weight slice -- pieces of 1 KiB (one per wave instruction), wave pw takes pieces
+        // pw, pw + 4, ...; requested two units ahead and written one unit ahead, like the activation items
+        constexpr int WPIECES = WBYTES / 1024, WNIT = WLDS ? WPIECES / 4 : 1;
+        static_assert(WPIECES % 4 == 0, "weight pieces are dealt to four producer waves");
+        f32x4 wpreA[WNIT], wpreB[WNIT];
+        (void)wpreA; (void)wpreB;
+        const char* wsrc = reinterpret_cast<const char*>(a.wp) + (wave - 4) * 1024 + lane * 16;
+        int pct0 = 0;            // first cout tile of the unit the plan stands at
         __amdgpu_buffer_rsrc_t xdesc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0, 0x00020000);
         unsigned cpk[NIT];       // id | ih << 8 | iw << 16
 #pragma unroll
@@ -482,7 +501,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
         {                                                                                               \
             int cb_, b_, od_, oh_, ow_;                                                                 \
             MVSGI_DECODE(UNIT, cb_, b_, od_, oh_, ow_)                                                  \
-            (void)cb_;                                                                                  \
+            pct0 = cb_ * NW < CT - NW ? cb_ * NW : CT - NW;                                             \
             const int id0_ = od_ * SD - KD / 2, ih0_ = oh_ * S - 1, iw0_ = ow_ * S - 1;                 \
             const int bbase_ = ((id0_ * a.Hin + ih0_) * a.Win + iw0_) * a.Cin * 4;                      \
             _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                        \
@@ -508,9 +527,20 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
             if (++cc2 == nchunks) { cc2 = 0; ++k2; }                                                    \
             if (k2 >= nmine) { k2 = nmine - 1; cc2 = nchunks - 1; }   /* past the end: re-request the last unit */ \
         }
-#define MVSGI_ISSUE(PRE, OK)                                                                            \
+#define MVSGI_WISSUE(WPRE)      /* the weight slice of unit (k2, cc2): [cc][cout tile][pair][hi | lo][64 lanes][16 B], NW tiles in a row */ \
+        if constexpr (WLDS) {                                                                           \
+            const char* ws_ = wsrc + ((long long)cc2 * CT + pct0) * (kPairs * 2048);                     \
+            _Pragma("unroll") for (int it = 0; it < WNIT; ++it) WPRE[it] = *reinterpret_cast<const f32x4*>(ws_ + it * 4096); \
+        }
+#define MVSGI_WPUT(WPRE, DST)                                                                           \
+        if constexpr (WLDS) {                                                                           \
+            _Pragma("unroll") for (int it = 0; it < WNIT; ++it)                                         \
+                *reinterpret_cast<f32x4*>((DST) + BUF + (wave - 4) * 1024 + lane * 16 + it * 4096) = WPRE[it]; \
+        }
+#define MVSGI_ISSUE(PRE, OK, WPRE)                                                                      \
         {                                                                                               \
             MVSGI_ISSUE_BEGIN()                                                                         \
+            MVSGI_WISSUE(WPRE)                                                                          \
             _Pragma("unroll") for (int it = 0; it < NIT; ++it) { MVSGI_ISSUE1(PRE, it) }                \
             MVSGI_ISSUE_END(OK)                                                                         \
         }
@@ -536,9 +566,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
 // one producer step: request unit u+2 into NEW while unit u+1 (OLD, in flight since the last step) is split and
 // written, ITEM BY ITEM.  A burst of NIT x 4 waves x 1 KiB requests would sit in the CU's vector-memory queue in
 // front of the consumers' weight fragments (measured: the burst form of this pipeline was 7 % SLOWER end to end).
-#define MVSGI_STEP(NEW, OKNEW, OLD, OKOLD, DST, DOPUT)                                                  \
+#define MVSGI_STEP(NEW, OKNEW, OLD, OKOLD, DST, DOPUT, WNEW, WOLD)                                      \
         {                                                                                               \
             MVSGI_ISSUE_BEGIN()                                                                         \
+            MVSGI_WISSUE(WNEW)                                                                          \
+            if (DOPUT) { MVSGI_WPUT(WOLD, DST) }                                                        \
             _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                        \
                 MVSGI_ISSUE1(NEW, it)                                                                   \
                 if (DOPUT) MVSGI_PUT1(OLD, OKOLD, DST, it)                                              \
@@ -548,29 +580,32 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
         }
         STAMP()
         MVSGI_PLAN((int)blockIdx.x)
-        MVSGI_ISSUE(preA, okA)                             // unit 0
+        MVSGI_ISSUE(preA, okA, wpreA)                      // unit 0
         MVSGI_PUT(preA, okA, ldsb)
+        MVSGI_WPUT(wpreA, ldsb)
         // Every request below is UNCONDITIONAL (past the last unit it re-reads that unit): a request under
         // `if (u + 2 < U)` makes the register set a phi of old and new values, the compiler materialises the
         // phi as copies of the freshly loaded registers, and a copy is a use -- s_waitcnt right behind the loads.
-        MVSGI_ISSUE(preA, okA)                             // unit 1 in flight
+        MVSGI_ISSUE(preA, okA, wpreA)                      // unit 1 in flight
         STAMP()
         __syncthreads();                                   // image 0 holds unit 0
         STAMP()
         for (int u = 0; u < U; u += 2) {
             // set A holds unit u+1 (in flight); request u+2 into B, then finish u+1
-            MVSGI_STEP(preB, okB, preA, okA, ldsb + ((u + 1) & 1) * BUF, u + 1 < U && !(MVSGI_ABL & 8))
+            MVSGI_STEP(preB, okB, preA, okA, ldsb + ((u + 1) & 1) * BUFW, u + 1 < U && !(MVSGI_ABL & 8), wpreB, wpreA)
             STAMP()
             __syncthreads();                               // unit u multiplied, image of unit u+1 complete
             STAMP()
             if (u + 1 < U) {
-                MVSGI_STEP(preA, okA, preB, okB, ldsb + ((u + 2) & 1) * BUF, u + 2 < U && !(MVSGI_ABL & 8))
+                MVSGI_STEP(preA, okA, preB, okB, ldsb + ((u + 2) & 1) * BUFW, u + 2 < U && !(MVSGI_ABL & 8), wpreA, wpreB)
                 STAMP()
                 __syncthreads();
                 STAMP()
             }
         }
 #undef MVSGI_ISSUE
+#undef MVSGI_WISSUE
+#undef MVSGI_WPUT
 #undef MVSGI_PUT
 #undef MVSGI_ISSUE_BEGIN
 #undef MVSGI_ISSUE1
@@ -804,6 +839,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                 xh[BUFI][i] = *reinterpret_cast<const bf16x8*>(img + base[i] + off_);                 \
                 xl[BUFI][i] = *reinterpret_cast<const bf16x8*>(img + base[i] + off_ + 32);            \
             }                                                                                         \
+            if constexpr (WLDS) {   /* the slot's weight fragments from the unit's LDS slice (lane-contiguous: conflict-free) */ \
+                _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                      \
+                    wh[BUFI][j] = *reinterpret_cast<const bf16x8*>(img + BUF + (j * kPairs + p_) * 2048 + (int)lane16);          \
+                    wl[BUFI][j] = *reinterpret_cast<const bf16x8*>(img + BUF + (j * kPairs + p_) * 2048 + 1024 + (int)lane16);   \
+                }                                                                                     \
+            }                                                                                         \
         }
 // term-major order: the three products of one accumulator are MW*NW MFMAs apart, never
 // back to back (a dependent v_mfma_f32_16x16x32_bf16 issued right behind its producer waits
@@ -866,7 +907,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
             unsigned l16 = lane16;
             MVSGI_PL_LOADW(0, 0, 0)
             MVSGI_PL_LOADW(1, 0, 1)
-        } else {
+        } else if constexpr (!WLDS) {
             unsigned l16 = lane16;
 #pragma unroll
             for (int s0 = 0; s0 < LA; ++s0) { MVSGI_LOADW(s0, 0, s0, ctc) }
@@ -876,7 +917,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
         STAMP()
         int k = 0, cc = 0;
         for (int u = 0; u < U; ++u) {
-            const unsigned char* img = ldsb + (u & 1) * BUF;
+            const unsigned char* img = ldsb + (u & 1) * BUFW;
             const bool last = cc + 1 == nchunks;
             const bool more = u + 1 < U;
             const int ncc = last ? 0 : cc + 1;
@@ -962,7 +1003,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                 asm volatile("" : "+v"(l16));      // keep `lane*16 + const` from being hoisted 28x out of the loop
                 const int xcur = XB >= 2 ? (s_ % XB) : 0, xnxt = XB >= 2 ? ((s_ + XLA) % XB) : 0;
                 // weight fragments LA slots ahead (this slice, or the first slots of the next unit)
-                if (!(MVSGI_ABL & 1)) {
+                if (!(MVSGI_ABL & 1) && !WLDS) {
                     if (s_ + LA < NSLOT) {
                         if (s_ + LA < kPairs) { MVSGI_LOADW((s_ + LA) % WB, cc, s_ + LA, ctc) }
                     } else {
@@ -1073,13 +1114,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
 }
 
 template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false, bool PLANE = false,
-          bool V32 = false>
+          bool V32 = false, bool WLDS = false>
 int launch_bf16x3(ConvArgs a, hipStream_t st) {
     constexpr int ITD = (TD - 1) * (KD == 1 ? 1 : S) + KD, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
     constexpr int ROWP = V32 ? ((ITW * kVSB + 255) / 256) * 256 : ITW * kVSB;
-    constexpr size_t lds_bytes = (size_t)2 * ITD * ITH * ROWP;             // double-buffered image
+    constexpr size_t lds_bytes = (size_t)2 * (ITD * ITH * ROWP + (WLDS ? NW * pairs_of(KD) * 2048 : 0));   // double-buffered image (+ weight slice)
     static_assert(lds_bytes <= 160 * 1024, "LDS images too large");
-    auto kern = conv3d_bf16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32>;
+    auto kern = conv3d_bf16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32, WLDS>;
     static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
     if (mvsgi::persistent_geometry(kern, 512, lds_bytes, 2, geo_cache, "conv3d(bf16x3)", geo)) return 1;

@@ -179,6 +179,8 @@ CONV_SHAPES = [
     (64, 16, 192, 8, 16, 24, 2, False, 0.0),    # stride 2 in 192-cout units
 ]
 EXPECTED_VARIANT = {        # (B, Cin, Cout, D, H, W) -> brick / unit shape the dispatcher must pick
+    (1, 128, 128, 2, 5, 9): "<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>",      # one frame: 16-cout units, weights through LDS
+    (2, 64, 64, 4, 8, 16): "<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>",
     (32, 128, 128, 2, 10, 40): "<2, 5, 2, 2, 2, 5, 16", (32, 64, 64, 3, 15, 21): "<2, 5, 2, 2, 2, 5, 16",
     (32, 32, 96, 4, 10, 40): "<3, 5, 2, 2, 2, 5, 16", (24, 32, 128, 1, 10, 40): "<2, 5, 1, 4, 1, 5, 16",
     (64, 16, 192, 1, 10, 40): "<3, 5, 1, 4, 1, 5, 16", (96, 16, 128, 1, 7, 21): "<2, 4, 1, 4, 1, 4, 16",
@@ -238,7 +240,7 @@ def test_conv3d_bf16x3_vs_oracle(shape):
     err = _rel(_ncdhw(y), yref)
     assert err <= 1e-4, err
     if Cout == 16 and stride == 1:       # the plane-schedule kernel of the Cout == 16 layers
-        assert "true, false>" in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3_C16)
+        assert "true, false, false>" in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3_C16)
         yp = H.conv3d(xg, wg, H.pack_conv_weights_bf16x3_c16(wg), _g(scale), _g(shift), res=rg, stride=stride,
                       neg_slope=slope, impl=H.CONV_BF16X3_C16)
         assert _rel(_ncdhw(yp), yref) <= 1e-4
@@ -279,11 +281,11 @@ def test_conv3d_v32_schedule_vs_oracle(shape):
     assert H.conv3d_v32_applies(B, Cin, *xin.shape[2:], Cout, 1)
     wv = H.pack_conv_weights_bf16x3_v32(wg)
     if up2:
-        assert "true, false, true>" in H.conv3d_up2_variant(B, Cin, D, Hh, W, Cout, H.CONV_BF16X3_V32)
+        assert "true, false, true, false>" in H.conv3d_up2_variant(B, Cin, D, Hh, W, Cout, H.CONV_BF16X3_V32)
         got = H.conv3d_up2(xg, wv, _g(scale), _g(shift), res=rg, neg_slope=slope, w_layout=H.CONV_BF16X3_V32)
         old = H.conv3d_up2(xg, H.pack_conv_weights_bf16x3(wg), _g(scale), _g(shift), res=rg, neg_slope=slope)
     else:
-        assert "false, false, true>" in H.conv3d_variant(B, Cin, D, Hh, W, Cout, 1, H.CONV_BF16X3_V32)
+        assert "false, false, true, false>" in H.conv3d_variant(B, Cin, D, Hh, W, Cout, 1, H.CONV_BF16X3_V32)
         got = H.conv3d(xg, wg, wv, _g(scale), _g(shift), res=rg, neg_slope=slope, impl=H.CONV_BF16X3_V32)
         old = H.conv3d(xg, wg, H.pack_conv_weights_bf16x3(wg), _g(scale), _g(shift), res=rg, neg_slope=slope,
                        impl=H.CONV_BF16X3)
@@ -325,7 +327,7 @@ def test_conv3d_fused_upsample_vs_interpolate_then_conv(shape):
     assert "true" in H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout)
     assert _rel(_ncdhw(got), yref) <= 1e-4
     if Cout == 16:
-        assert "true, true, false>" in H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, H.CONV_BF16X3_C16)
+        assert "true, true, false, false>" in H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, H.CONV_BF16X3_C16)
         gp = H.conv3d_up2(xg, H.pack_conv_weights_bf16x3_c16(_g(w)), _g(scale), _g(shift), res=rg, neg_slope=0.01,
                           w_layout=H.CONV_BF16X3_C16)
         assert _rel(_ncdhw(gp), yref) <= 1e-4
