@@ -423,6 +423,9 @@ __device__ __forceinline__ Bilin quad_bcast(const Bilin& m) {
 #ifndef MVSGI_SWEEP_NT
 #define MVSGI_SWEEP_NT 0      // nt stores of the split-padded volume: measured neutral (post_vol reads it straight back)
 #endif
+#ifndef MVSGI_SWEEP_SKIP_CAM
+#define MVSGI_SWEEP_SKIP_CAM 1
+#endif
 #ifndef MVSGI_SWEEP_WAVES
 #define MVSGI_SWEEP_WAVES 5      // waves per SIMD the register allocation aims at (experiment knob; 92 registers -> 5)
 #endif
@@ -525,6 +528,15 @@ __global__ __launch_bounds__(256, MVSGI_SWEEP_WAVES) void sweep_std_nhwc_v_kerne
 #endif
 #pragma unroll
             for (int cam = 0; cam < NCAM; ++cam) {
+#if MVSGI_SWEEP_SKIP_CAM
+                // a camera no voxel of this wave needs (validity is spatially coherent: whole waves fall outside a camera's image
+                // or mask) is not gathered at all: the kernel is bound by the texture addresser's instruction rate
+                // (profiles/r04_pmc_sweep_texture_path.txt), and a range-checked-away gather still costs its instruction
+                if (__builtin_amdgcn_ballot_w64(val[cam] & ok) == 0) {
+                    tx[cam][0] = tx[cam][1] = tx[cam][2] = tx[cam][3] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    continue;
+                }
+#endif
                 tx[cam][0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(img[cam], ft[cam].o00 + cb, 0, 0));
                 tx[cam][1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(img[cam], ft[cam].o01 + cb, 0, 0));
                 tx[cam][2] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(img[cam], ft[cam].o10 + cb, 0, 0));
