@@ -299,7 +299,7 @@ enum Variant {
     V_DIRECT1, V_DIRECT4, V_HEAD,
     V_S1_N16_B256, V_S1_N32_B256, V_S1_N32_B64, V_S1_N64_B128, V_S1_N64_B64, V_S2_N32_B64, V_S2_N64_B64,
     // split-bf16 kernel: 16-wide bricks (conflict-free LDS reads); N = couts per workgroup
-    B3_N16, B3_N32, B3_N48, B3_N64, B3_N64_H5, B3_N96, B3_N96_H5, B3_N128_P, B3_N128_PH5, B3_N192_PH5, B3_N32_S, B3_N64_S, B3_N16_T, B3_N32_T, B3_N16_TW, B3_S2_N32, B3_S2_N64, B3_S2_N96, B3_S2_N128, B3_S2_N192,
+    B3_N16, B3_N32, B3_N48, B3_N64, B3_N64_H5, B3_N96, B3_N96_H5, B3_N128_P, B3_N128_PH5, B3_N192_PH5, B3_N32_S, B3_N64_S, B3_N16_T, B3_N32_T, B3_N16_TW, B3_S2_N32, B3_S2_N32B, B3_S2_N64, B3_S2_N96, B3_S2_N128, B3_S2_N192,
     // split-bf16 kernel with the trilinear x2 upsample fused into its producers (even bricks only)
     B3U_N16, B3U_N32, B3U_N32_M, B3U_N48, B3U_N64, B3U_N96,
     // Cout == 16 plane schedule (weights from mvsgi_conv3d_pack_weights_bf16x3_c16), plain and fused-upsample
@@ -325,6 +325,7 @@ const char* const kVariantNames[] = {
     "conv3d_bf16x3_kernel<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, false>",
     "conv3d_bf16x3_kernel<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>",
     "conv3d_bf16x3_kernel<2, 1, 4, 1, 2, 4, 8, 2, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 8, 2, 3, false, false, false, false>",
     "conv3d_bf16x3_kernel<2, 2, 2, 2, 2, 4, 8, 2, 3, false, false, false, false>",
     "conv3d_bf16x3_kernel<3, 2, 2, 2, 2, 4, 8, 2, 3, false, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 1, 4, 2, 4, 8, 2, 3, false, false, false, false>",
     "conv3d_bf16x3_kernel<3, 4, 1, 4, 2, 4, 8, 2, 3, false, false, false, false>",
@@ -410,7 +411,7 @@ int select_variant(const ConvArgs& a, int impl) {
         if (a.stride == 2) {
 #ifdef MVSGI_EXPERIMENTAL
             if (const char* f = mvsgi::exp_env("MVSGI_B3_FORCE")) {
-                static const struct { const char* n; int v; } tab[] = {{"S2_N32", B3_S2_N32}, {"S2_N64", B3_S2_N64}, {"S2_N96", B3_S2_N96},
+                static const struct { const char* n; int v; } tab[] = {{"S2_N32", B3_S2_N32}, {"S2_N32B", B3_S2_N32B}, {"S2_N64", B3_S2_N64}, {"S2_N96", B3_S2_N96},
                     {"S2_N128", B3_S2_N128}, {"S2_N192", B3_S2_N192}};
                 for (const auto& t : tab) if (!strcmp(f, t.n)) return t.v;
             }
@@ -422,7 +423,9 @@ int select_variant(const ConvArgs& a, int impl) {
             if (CT % 12 == 0 && s2bricks * (CT / 12) >= 512) return B3_S2_N192;
             if (CT % 8 == 0 && s2bricks * (CT / 8) >= 512) return B3_S2_N128;
             if (CT % 6 == 0 && s2bricks * (CT / 6) >= 512) return B3_S2_N96;
-            return CT <= 3 ? B3_S2_N32 : B3_S2_N64;
+            // 32 couts per unit: waves as (voxel half, cout tile) -- 2 weight + 4 activation fragment reads per slot and wave instead of
+            // 4 + 2 with all four waves on both cout tiles (4cam-32's first layer, 64 -> 32: 1362 -> 1221 us per 16 frames)
+            return CT <= 3 ? B3_S2_N32B : B3_S2_N64;
         }
         // workgroups a 256-voxel (N <= 48) / 128-voxel (N >= 64) brick decomposition would give
         const long long big = (long long)a.B * mvsgi::cdiv(a.Do, 4) * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
@@ -509,6 +512,7 @@ int launch_variant(int v, const ConvArgs& a, hipStream_t st) {
         case B3_N32_T: return launch_bf16x3<2, 1, 4, 1, 1, 4, 16, 1>(a, st);
         case B3_N16_TW: return launch_bf16x3<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>(a, st);
         case B3_S2_N32: return launch_bf16x3<2, 1, 4, 1, 2, 4, 8, 2>(a, st);
+        case B3_S2_N32B: return launch_bf16x3<1, 2, 2, 2, 2, 4, 8, 2>(a, st);
         case B3_S2_N64: return launch_bf16x3<2, 2, 2, 2, 2, 4, 8, 2>(a, st);
         case B3_S2_N96: return launch_bf16x3<3, 2, 2, 2, 2, 4, 8, 2>(a, st);
         case B3_S2_N128: return launch_bf16x3<2, 4, 1, 4, 2, 4, 8, 2>(a, st);

@@ -179,6 +179,7 @@ CONV_SHAPES = [
     (64, 16, 192, 8, 16, 24, 2, False, 0.0),    # stride 2 in 192-cout units
 ]
 EXPECTED_VARIANT = {        # (B, Cin, Cout, D, H, W) -> brick / unit shape the dispatcher must pick
+    (1, 16, 32, 8, 16, 16): "<1, 2, 2, 2, 2, 4, 8, 2", (1, 16, 32, 7, 9, 13): "<1, 2, 2, 2, 2, 4, 8, 2",       # stride 2, 32 couts
     (1, 128, 128, 2, 5, 9): "<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>",      # one frame: 16-cout units, weights through LDS
     (2, 64, 64, 4, 8, 16): "<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>",
     (32, 128, 128, 2, 10, 40): "<2, 5, 2, 2, 2, 5, 16", (32, 64, 64, 3, 15, 21): "<2, 5, 2, 2, 2, 5, 16",
