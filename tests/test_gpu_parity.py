@@ -654,6 +654,35 @@ def test_streamed_hot_path_equals_one_stream(conv_mode):
         H.set_conv_mode(old)
 
 
+def test_cold_compile_and_load_on_this_box(tmp_path):
+    """The library normally travels with the tree (its source hash matches, so build() re-uses it); this compiles two of its
+    translation units from scratch with this box's hipcc, links them and runs a kernel of the result on this GPU: the build
+    recipe of __graft_entry__ works where the tests run, not only where the library was made."""
+    import ctypes
+    import subprocess
+    import __graft_entry__ as g
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for src in ("api.cpp", "layout.hip"):
+        o = str(tmp_path / (src + ".o"))
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(g.CSRC, src), "-o", o],
+                       check=True, timeout=600)
+        objs.append(o)
+    so = str(tmp_path / "libcold.so")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", so] + objs, check=True, timeout=600)
+    lib = ctypes.CDLL(so)
+    lib.mvsgi_abi_version.restype = ctypes.c_int
+    assert lib.mvsgi_abi_version() == 1
+    x = torch.arange(2 * 3 * 5, dtype=torch.float32, device=DEV).reshape(2, 3, 5)          # [B, C, V]
+    y = torch.empty((2, 5, 3), dtype=torch.float32, device=DEV)
+    lib.mvsgi_ncv_to_nvc_f32.restype = ctypes.c_int
+    lib.mvsgi_ncv_to_nvc_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
+    assert lib.mvsgi_ncv_to_nvc_f32(x.data_ptr(), y.data_ptr(), 2, 3, 5, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, x.permute(0, 2, 1))
+    assert not g._needs_rebuild()          # and the travelling library is the one this tree's sources hash to
+
+
 def test_bench_two_ranks_frame_sharded_on_one_gpu():
     """bench.py's N>1 path end to end (rendezvous, per-rank frames, barrier, max-over-ranks, one JSON
     line from rank 0): two ranks share this box's single GPU, control plane over gloo."""
@@ -1387,6 +1416,19 @@ def test_full_size_batch8_register_stationary_path_vs_reference_golden(golden_di
         assert not np.array_equal(g64[5], g64[0])
         hp.capture(f64)
         assert torch.equal(hp.replay()[0], inv64)
+        # bench.py's step: the batch in two parts on two HIP streams inside one hipGraph (StreamedHotPath) -- each part the bits
+        # of the one-stream launch of the same frames
+        from mvs_gi_amd.pipeline import StreamedHotPath
+        shp = StreamedHotPath(cfg, synth.make_weights(cfg, seed=case["seed"], gain=gain), inp, device=DEV, n_streams=2)
+        f128 = torch.cat([f64, f64])
+        shp.capture(f128)
+        parts = shp.replay()
+        torch.cuda.synchronize()
+        assert len(parts) == 2 and torch.equal(parts[0][0], inv64) and torch.equal(parts[1][0], inv64)
+        err = _rel(parts[1][0][63:64].cpu().numpy(), ref)
+        parity_log.record("full_G16V(2x64 streamed)[127]", "bf16x3", gain, err, _l1(parts[1][0][63:64].cpu().numpy(), ref), "golden")
+        assert err <= 1e-3
+        del shp, parts, f128
     finally:
         H.set_conv_mode(old)
         torch.cuda.empty_cache()
