@@ -29,6 +29,9 @@ SMALL_CASES = {
 FULL_CASES = {
     "full_G16V": dict(cfg=CONFIGS["G16V"], seed=0, batch=1, grid_kind="smooth", grid_mask_dtype="bool",
                       gains=(0.25, 1.0)),
+    # worst-case gather locality at full size: sampling grids U[-1.1, 1.1], Bernoulli float grid masks / camera masks
+    "full_G16V_rand": dict(cfg=CONFIGS["G16V"], seed=1, batch=1, grid_kind="random", grid_mask_dtype="f32",
+                           gains=(1.0,)),
     "full_G16VV": dict(cfg=CONFIGS["G16VV"], seed=0, batch=1, grid_kind="smooth", grid_mask_dtype="bool",
                        gains=(1.0, 4.0)),
     "full_E8": dict(cfg=CONFIGS["E8"], seed=0, batch=1, grid_kind="smooth", grid_mask_dtype="bool",
