@@ -697,6 +697,29 @@ def test_cold_compile_and_load_on_this_box(tmp_path):
     assert not g._needs_rebuild()          # and the travelling library is the one this tree's sources hash to
 
 
+def test_bench_default_submission_line():
+    """`python bench.py` as the driver calls it at N = 1 (here with a small batch): the step is two parts on two HIP streams inside one
+    hipGraph behind a settle phase; one JSON line with metric / value / roofline (+ traffic from profiles/pmc_traffic.json) / every
+    launch attributed / parity against the oracle frame / cpu_baseline."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--batch", "8", "--steps", "3", "--warmup", "2", "--no-extras",
+                        "--settle-seconds", "0.2", "--cpu-seconds", "1"], capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["unit"] == "frames/s" and d["value"] > 0 and d["vs_baseline"] is None and d["higher_is_better"]
+    assert d["config"]["frames_per_gpu_per_step"] == 8 and d["config"]["streams"].startswith("2 independent parts of 4 frames")
+    assert "hipGraph" in d["config"]["submission"] and "settle" in d["config"]
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1 / 3 and d["roofline"]["peak"] == 2500.0
+    assert d["parity"]["max_rel"] <= 1e-3 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert any(k.startswith("sweep_std") for k in d["kernels"]) and any(k.startswith("softargmin") for k in d["kernels"])
+
+
 def test_bench_two_ranks_frame_sharded_on_one_gpu():
     """bench.py's N>1 path end to end (rendezvous, per-rank frames, barrier, max-over-ranks, one JSON
     line from rank 0): two ranks share this box's single GPU, control plane over gloo."""
