@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256, MVSGI_SWEEP_WAVES) void sweep_std_nhwc_v_kerne
 #if MVSGI_SWEEP_SKIP_CAM
                 // a camera no voxel of this wave needs (validity is spatially coherent: whole waves fall outside a camera's image
                 // or mask) is not gathered at all: the kernel is bound by the texture addresser's instruction rate
-                // (profiles/r04_pmc_sweep_texture_path.txt), and a range-checked-away gather still costs its instruction
+                // (profiles/r04_sweep_texture_path_counters.txt), and a range-checked-away gather still costs its instruction
                 if (__builtin_amdgcn_ballot_w64(val[cam] & ok) == 0) {
                     tx[cam][0] = tx[cam][1] = tx[cam][2] = tx[cam][3] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                     continue;
