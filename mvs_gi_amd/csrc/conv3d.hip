@@ -361,6 +361,12 @@ int select_variant_up2(const ConvArgs& a, int w_layout) {
     const int CT = a.Cout / 16;
     const long long big = (long long)a.B * mvsgi::cdiv(a.Do, 4) * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
     const long long mid = (long long)a.B * mvsgi::cdiv(a.Do, 2) * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
+#ifdef MVSGI_EXPERIMENTAL
+    if (const char* f = mvsgi::exp_env("MVSGI_B3U_FORCE")) {
+        static const struct { const char* n; int v; } tab[] = {{"N32", B3U_N32}, {"N32_M", B3U_N32_M}, {"N48", B3U_N48}, {"N64", B3U_N64}, {"N96", B3U_N96}};
+        for (const auto& t : tab) if (!strcmp(f, t.n)) return t.v;
+    }
+#endif
     if (CT == 1) return c16_layout ? B3PU_N16 : B3U_N16;
     if (CT == 2) return big >= 384 ? B3U_N32 : B3U_N32_M;
     if (CT == 3) return B3U_N48;
