@@ -33,8 +33,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0}   # MI355X_MICROARCH.md: dense fp32-MFMA / bf16-MFMA peaks
-DTYPE = {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA operands, f32 accumulate/activations)"}
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "f16x3": 2500.0}   # MI355X_MICROARCH.md: dense fp32-MFMA / bf16-MFMA (= fp16-MFMA) peaks
+DTYPE = {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA operands, f32 accumulate/activations)",
+         "f16x3": "f16x3 (split-fp16 MFMA operands: 11 + 11 significant bits, f32 accumulate/activations)"}
 PEAK_HBM_GBS = 8000.0
 EXTRA_CONFIGS = (("G16VV", 32), ("E8", 64), ("4cam-32", 16))      # (tag, frames per part (= per stream) at which the configuration runs best on MI355X: tools/config_batch_probe.py)
 LIB = os.path.join(ROOT, "mvs_gi_amd", "libmvsgi_hip.so")
@@ -51,8 +52,9 @@ def parse_args(argv=None):
                     help="independent parts of a step's batch, each on its own HIP stream inside the step's one hipGraph "
                          "(StreamedHotPath: one part's kernel tails are filled by the other's launches; MI355X, G16V: 2 x 64 frames "
                          "+1.8 % over 1 x 128 and +3.3 % over 1 x 64); 1 = the whole batch on one stream")
-    ap.add_argument("--mode", default="bf16x3", choices=["bf16x3", "f32"],
-                    help="conv arithmetic: split-bf16 MFMA (3 bf16 MFMAs per product, fp32 accumulate) or exact fp32 MFMA")
+    ap.add_argument("--mode", default="bf16x3", choices=["bf16x3", "f16x3", "f32"],
+                    help="conv arithmetic: split-bf16 MFMA (3 bf16 MFMAs per product, fp32 accumulate), the same in the fp16 split "
+                         "(11 + 11 bits per operand: ~10x closer to the reference, streaming kernels only) or exact fp32 MFMA")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extras / configs blocks (rig cache off, hipGraph, B=1 latency, images -> inverse "
                          "distance, host feed, other BASELINE configs); they never touch the headline's timed region")
@@ -71,6 +73,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-dump-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-dump", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-dump-configs", default="", help=argparse.SUPPRESS)      # tags whose oracle frame is dumped beside --cpu-dump
     return ap.parse_args(argv)
 
 
@@ -466,6 +469,8 @@ def cpu_baseline_subprocess(args, dump_path):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", args.config,
            "--cpu-seconds", str(args.cpu_seconds), "--cpu-dump", dump_path]
+    if not args.no_extras:      # one oracle frame of each other configuration: the parity reference of the configs{} entries
+        cmd += ["--cpu-dump-configs", ",".join(t for t, _ in EXTRA_CONFIGS if t != args.config)]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_seconds * 6 + 120)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -484,6 +489,10 @@ def oracle_dump_subprocess(args, dump_path):
         subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     except Exception:
         pass
+
+
+def config_dump_path(dump_path, tag):
+    return f"{dump_path}.{tag}.npy"
 
 
 def oracle_dump(cfg, dump_path):
@@ -610,7 +619,7 @@ def make_feats(B, shape, rng, dev, torch, np, nchw=False):
     return torch.from_numpy(rng.standard_normal((B, N, Hi, Wi, C), dtype=np.float32)).to(dev).permute(0, 1, 4, 2, 3)
 
 
-def measure_path(cfg, B, mode, steps, warmup, dev, H, HotPath, synth, torch, np, rng, graph=False, kernels=False, streams=1):
+def measure_path(cfg, B, mode, steps, warmup, dev, H, HotPath, synth, torch, np, rng, graph=False, kernels=False, streams=1, ref_dump=None):
     """frames/s, ms/step and per-conv-kernel attribution of one configuration at one batch size (single process,
     outside the headline's timed region).  frames_per_s / the kernel table: B frames as one launch chain on one stream;
     graph_replay_*: as the headline submits a step -- `streams` parts of B frames each in one hipGraph."""
@@ -654,6 +663,23 @@ def measure_path(cfg, B, mode, steps, warmup, dev, H, HotPath, synth, torch, np,
         except Exception as e:
             res["graph_replay_error"] = f"{type(e).__name__}: {e}"
             torch.cuda.synchronize(dev)
+    if ref_dump is not None and os.path.isfile(ref_dump):
+        # parity AT THE OPERATING POINT: the oracle's seed-0 frame in every slot of the step's batch (other units and brick shapes
+        # than at one frame), first and last frame against the oracle
+        try:
+            ref = np.load(ref_dump)
+            f0 = torch.from_numpy(inp["feats"]).to(dev).expand(feats_all.shape[0], -1, -1, -1, -1).contiguous()
+            outs = shp.replay(f0) if getattr(shp, "_graph", None) is not None else shp(f0)
+            torch.cuda.synchronize(dev)
+            first, last = outs[0][0][:1].cpu().numpy(), outs[-1][0][-1:].cpu().numpy()
+            res["parity"] = {"max_rel": float(max(np.abs(first - ref).max(), np.abs(last - ref).max()) / np.abs(ref).max()),
+                             "mean_l1_rel": float(np.abs(first - ref).mean() / np.abs(ref).mean()), "bar": 1e-3, "mode": mode,
+                             "frames_checked": [0, int(feats_all.shape[0]) - 1], "frames_per_step": int(feats_all.shape[0]),
+                             "ref": "oracle/mvsgi_oracle.py (pinned to the reference goldens); the same step as measured"}
+            del f0, outs
+        except Exception as e:
+            res["parity"] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.synchronize(dev)
     del hp, shp, feats, feats_all
     torch.cuda.empty_cache()
     return res
@@ -664,7 +690,13 @@ def main(argv=None):
     rank, local_rank, world = dist_env()
     if args.cpu_baseline_only:
         from mvs_gi_amd.configs import CONFIGS as _C
-        print(json.dumps(cpu_baseline(_C[args.config], args.cpu_seconds, args.cpu_dump)), flush=True)
+        res_cpu = cpu_baseline(_C[args.config], args.cpu_seconds, args.cpu_dump)
+        for tag in [t for t in args.cpu_dump_configs.split(",") if t]:
+            try:
+                oracle_dump(_C[tag], config_dump_path(args.cpu_dump, tag))
+            except Exception:      # a missing dump only drops that entry's parity field
+                pass
+        print(json.dumps(res_cpu), flush=True)
         return
     if args.cpu_dump_only:
         from mvs_gi_amd.configs import CONFIGS as _C
@@ -834,9 +866,24 @@ def main(argv=None):
                          "mean_l1_rel": float(np.abs(got - ref).mean() / np.abs(ref).mean()),
                          "bar": 1e-3, "ref": "oracle/mvsgi_oracle.py (CPU fp32 restatement pinned to the reference goldens)",
                          "frames": 1, "mode": args.mode}
+        try:      # ... and at the operating point: the oracle's frame in every slot of the timed step's batch, first and last frame
+            f0 = torch.from_numpy(inp["feats"]).to(dev).expand(B, -1, -1, -1, -1).contiguous()
+            outs = shp.replay(f0) if use_graph else shp(f0)
+            sync()
+            fl = [outs[0][0][:1].cpu().numpy(), outs[-1][0][-1:].cpu().numpy()]
+            res["parity"]["at_batch"] = {"frames_per_step": B, "frames_checked": [0, B - 1],
+                                         "max_rel": float(max(np.abs(x - ref).max() for x in fl) / np.abs(ref).max())}
+            del f0, outs
+        except Exception as e:
+            res["parity"]["at_batch"] = {"error": f"{type(e).__name__}: {e}"}
     # ---- extras: single GPU only, outside the timed region above
     if world == 1 and rank == 0 and not args.no_extras:
+        args.ref_dump = ref_dump
         res["extras"] = run_extras(args, cfg, B // S, hp, feats[:B // S], weights, dev, H, synth, torch, np, rng, value, shp, feats)
+        # round-to-round comparable figure beside `value` (rounds 1-3 ran one part on one stream): one part of the step, one stream
+        one = res["extras"].get("one_stream", {}).get("one_part") if isinstance(res["extras"].get("one_stream"), dict) else None
+        if one:
+            res["one_stream_one_part"] = {"frames_per_s": one["frames_per_s"], "frames_per_step": one["frames_per_step"]}
         del hp, shp, feats
         torch.cuda.empty_cache()
         cfgs = {}
@@ -845,13 +892,23 @@ def main(argv=None):
                 continue
             try:
                 m = measure_path(CONFIGS[tag], b, args.mode, args.extra_steps, 3, dev, H, HotPath, synth, torch, np, rng,
-                                 graph=use_graph, kernels=True, streams=S)
+                                 graph=use_graph, kernels=True, streams=S,
+                                 ref_dump=config_dump_path(ref_dump, tag) if ref_dump else None)
                 if "graph_replay_frames_per_s" in m:      # as the headline: parts on their own streams, one hipGraph replay per step
                     m["one_stream_eager_frames_per_s"], m["one_stream_eager_ms_per_step"] = m["frames_per_s"], m["ms_per_step"]
                     m["frames_per_s"], m["ms_per_step"] = m.pop("graph_replay_frames_per_s"), m.pop("graph_replay_ms_per_step")
                     m["frames_per_step"] = m.pop("graph_replay_frames_per_step")
                     m["path_tflops"] = round(m["frames_per_s"] * path_gflop(CONFIGS[tag]) / 1e3, 2)
                     m["submission"] = f"{S} parts of {b} frames on their own streams, one hipGraph replay per step"
+                if args.mode == "bf16x3":      # the fp16 split of the same step: the streaming kernels' other arithmetic (rate and error)
+                    try:
+                        m16 = measure_path(CONFIGS[tag], b, "f16x3", max(3, args.extra_steps // 2), 2, dev, H, HotPath, synth, torch, np, rng,
+                                           graph=use_graph, streams=S, ref_dump=config_dump_path(ref_dump, tag) if ref_dump else None)
+                        m["mode_f16x3"] = {"frames_per_s": m16.get("graph_replay_frames_per_s", m16["frames_per_s"]),
+                                           "parity": m16.get("parity"), "dominant_kernel": m16["dominant_kernel"],
+                                           "dominant_tflops": m16["dominant_tflops"]}
+                    finally:
+                        H.set_conv_mode(args.mode)
                 cfgs[tag] = m
             except Exception as e:       # never lose the headline to an extra
                 cfgs[tag] = {"error": f"{type(e).__name__}: {e}"}
@@ -953,9 +1010,21 @@ def run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, 
             except Exception:
                 return None
 
-        def sampler():
-            # a box exposes every card of the host under /sys: the card this process drives is the one drawing the most power
+        # the hwmon directory of the DRIVEN device, found through its PCI address; a box that hides that (or a torch without the
+        # properties) falls back to "the card drawing the most power" over every card of the host, and the line says which it was
+        dirs, card = [], None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            pci = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            dirs = glob.glob(f"/sys/bus/pci/devices/{pci}/hwmon/hwmon*/")
+            card = f"/sys/bus/pci/devices/{pci}" if dirs else None
+        except Exception:
+            pass
+        if not dirs:
             dirs = glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/")
+            card = "max power over /sys/class/drm/card*/ (PCI address of the device not resolvable)"
+
+        def sampler():
             while not stop.is_set():
                 best = (None, None)
                 for d in dirs:
@@ -993,7 +1062,7 @@ def run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, 
                 "power_W_last_second": avg([w for _, w, _ in tail if w is not None]),
                 "sclk_MHz_last_second": avg([f for _, _, f in tail if f is not None]),
                 "power_W_first_300ms": avg([w for t, w, _ in pw if t <= 0.3 and w is not None]),
-                "samples": len(pw), "how": "same submission as the headline, sync every 5 steps; hwmon power1_average / freq1_input "
+                "samples": len(pw), "hwmon": card, "how": "same submission as the headline, sync every 5 steps; hwmon power1_average / freq1_input "
                                            "read every 100 ms by a thread of this process (None: not exposed on this box)"}
     guarded("sustained", sustained)
 
@@ -1072,6 +1141,24 @@ def run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, 
         m["peak_tflops"] = PEAK_TFLOPS["f32"]
         return m
     guarded("mode_f32", mode_f32)
+
+    def mode_f16x3():
+        # the fp16 split of the same path (hi = fp16(x), lo = fp16(x - hi): 11 + 11 bits per operand at the bf16 split's matrix rate):
+        # the deployer's answer for a checkpoint whose softmax is sharper than the bf16 split holds (Precision modes).
+        # Streaming kernels only -- the register-stationary level-0 / polyphase kernels of this regulator are bf16-split.
+        if args.mode == "f16x3":
+            return {"note": "the headline is the fp16-split mode"}
+        try:
+            m = measure_path(cfg, B, "f16x3", max(3, K // 2), 2, dev, H, HotPath, synth, torch, np, rng, graph=use_graph,
+                             streams=len(shp.parts), ref_dump=getattr(args, "ref_dump", None))
+        finally:
+            H.set_conv_mode(args.mode)
+        if "graph_replay_frames_per_s" in m:
+            m["frames_per_s_one_part_eager"] = m["frames_per_s"]
+            m["frames_per_s"] = m["graph_replay_frames_per_s"]
+        m["vs_headline"] = round(m["frames_per_s"] / headline_fps, 4)
+        return m
+    guarded("mode_f16x3", mode_f16x3)
 
     # ---- images -> inverse distance (HIP feature extractor in front), HBM-resident and host-fed
     Hi, Wi = cfg.feat_hw

@@ -54,6 +54,14 @@ typedef void* mvsgi_stream_t;
                                    issue-port time per flop) where mvsgi_conv3d_v32_applies(); weights from
                                    mvsgi_conv3d_pack_weights_bf16x3_v32                                                  */
 
+#define MVSGI_CONV_F16 0x100   /* FLAG, OR-ed into MVSGI_CONV_BF16X3 / _C16 / _V32 (impl of mvsgi_conv3d_f32, w_layout of
+                                  mvsgi_conv3d_up2_f32, layout of mvsgi_conv3d_pack_weights_split): the same kernels and packed
+                                  layouts in the fp16 split ("f16x3") -- hi = fp16(x), lo = fp16(x - hi), v_mfma_*_f16: 11 + 11
+                                  significant bits per operand instead of 8 + 8 at the same matrix rate (~10x closer to the
+                                  fp32 reference); operands are clamped to fp16's range (+-65504), and callers pre-scale each
+                                  output channel's weights by a power of two (undone in `scale`) so that their lo parts are
+                                  normal fp16 numbers                                                                    */
+
 int         mvsgi_abi_version(void);
 const char* mvsgi_last_error(void);
 
@@ -127,6 +135,9 @@ int mvsgi_conv3d_pack_weights_f32(const float* w_oidhw, float* w_packed, int Cou
 size_t mvsgi_conv3d_packed_weight_bytes_bf16x3(int Cout, int Cin);
 int mvsgi_conv3d_pack_weights_bf16x3(const float* w_oidhw, void* w_packed, int Cout, int Cin,
                                      mvsgi_stream_t stream);
+/* weights for a split kernel in either split: layout = MVSGI_CONV_BF16X3 | _C16 | _V32, optionally | MVSGI_CONV_F16; w_packed sized by
+ * mvsgi_conv3d_packed_weight_bytes_bf16x3 / _c16 / _v32 (the two splits share the layouts) */
+int mvsgi_conv3d_pack_weights_split(const float* w_oidhw, void* w_packed, int Cout, int Cin, int layout, mvsgi_stream_t stream);
 int mvsgi_conv3d_f32(const float* x, const float* w_oidhw, const float* w_packed,
                      const float* scale, const float* shift, const float* res, float* y,
                      int B, int Cin, int Din, int Hin, int Win, int Cout,
@@ -346,6 +357,11 @@ int mvsgi_conv3d_up2_poly_split(const void* x_split, const void* plan_dev, const
 size_t mvsgi_conv3d_head_split_packed_weight_bytes(int Cin);
 int mvsgi_conv3d_head_split_pack_weights(const float* w_oidhw, void* w_packed, int Cin, mvsgi_stream_t stream);
 int mvsgi_conv3d_head_split(const void* x_split, const void* w_packed, float scale, float shift, float* y, int B, int Cin,
+                            int D, int H, int W, float neg_slope, mvsgi_stream_t stream);
+/* the head in the fp16 split: x_split written by a kernel of the fp16 split (mvsgi_conv3d_up2_f32_out_split with w_layout |
+ * MVSGI_CONV_F16); weights pre-scaled by a power of two by the caller, its inverse folded into `scale` */
+int mvsgi_conv3d_head_split_pack_weights_f16(const float* w_oidhw, void* w_packed, int Cin, mvsgi_stream_t stream);
+int mvsgi_conv3d_head_split_f16(const void* x_split, const void* w_packed, float scale, float shift, float* y, int B, int Cin,
                             int D, int H, int W, float neg_slope, mvsgi_stream_t stream);
 size_t mvsgi_conv3d_up2_poly_plan_bytes(int D, int H, int W);
 int mvsgi_conv3d_up2_poly_plan(const float* w_oidhw_host, void* plan_host, int D, int H, int W);

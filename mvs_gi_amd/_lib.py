@@ -37,6 +37,7 @@ SIGNATURES = {
     "mvsgi_conv3d_pack_weights_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "mvsgi_conv3d_packed_weight_bytes_bf16x3": (c_size_t, [c_int, c_int]),
     "mvsgi_conv3d_pack_weights_bf16x3": (c_int, [_P, _P, c_int, c_int, _P]),
+    "mvsgi_conv3d_pack_weights_split": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "mvsgi_conv3d_f32": (c_int, [_P] * 7 + [c_int] * 7 + [c_float, c_int, _P]),
     "mvsgi_conv3d_variant_f32": (c_char_p, [c_int] * 8),
     "mvsgi_conv3d_up2_f32": (c_int, [_P, _P, c_int] + [_P] * 4 + [c_int] * 6 + [c_float, _P]),
@@ -89,6 +90,8 @@ SIGNATURES = {
     "mvsgi_conv3d_head_split_packed_weight_bytes": (c_size_t, [c_int]),
     "mvsgi_conv3d_head_split_pack_weights": (c_int, [_P, _P, c_int, _P]),
     "mvsgi_conv3d_head_split": (c_int, [_P, _P, c_float, c_float, _P] + [c_int] * 5 + [c_float, _P]),
+    "mvsgi_conv3d_head_split_pack_weights_f16": (c_int, [_P, _P, c_int, _P]),
+    "mvsgi_conv3d_head_split_f16": (c_int, [_P, _P, c_float, c_float, _P] + [c_int] * 5 + [c_float, _P]),
     "mvsgi_conv3d_up2_poly_plan_bytes": (c_size_t, [c_int] * 3),
     "mvsgi_conv3d_up2_poly_plan": (c_int, [_P, _P] + [c_int] * 3),
     "mvsgi_conv3d_up2_poly_f32": (c_int, [_P] * 5 + [c_int] * 4 + [c_float, _P]),

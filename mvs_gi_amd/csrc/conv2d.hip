@@ -297,7 +297,7 @@ extern "C" int mvsgi_conv2d_pack_weights_bf16x3(const float* w_oihw, void* w_pac
                   "mvsgi_conv2d_pack_weights_bf16x3: Cout=%d Cin=%d must be positive multiples of 16", Cout, Cin);
     const long long total = (long long)(Cin / 16) * pairs_of(1) * (Cout / 16) * 64;
     hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0,
-                       mvsgi::as_stream(stream), w_oihw, reinterpret_cast<bf16x8*>(w_packed), Cout, Cin, 9);
+                       mvsgi::as_stream(stream), w_oihw, reinterpret_cast<bf16x8*>(w_packed), Cout, Cin, 9, false);
     return mvsgi::check_launch("mvsgi_conv2d_pack_weights_bf16x3");
 }
 

@@ -22,6 +22,7 @@
 //    cross-check of the MFMA path.
 #include "common.hpp"
 #include "conv_common.hpp"
+#include "conv3d_variants.hpp"
 #ifdef MVSGI_STAMPS
 #include <cstdio>
 #include <cstdlib>
@@ -295,19 +296,6 @@ int launch_direct(const ConvArgs& a, hipStream_t st) {
 // One table drives both the launch and the name reported to the bench/profiler, so the kernel
 // named in a roofline line is the kernel that ran.  Names are the demangled kernel names as
 // rocprofv3 prints them (substring match).
-enum Variant {
-    V_DIRECT1, V_DIRECT4, V_HEAD,
-    V_S1_N16_B256, V_S1_N32_B256, V_S1_N32_B64, V_S1_N64_B128, V_S1_N64_B64, V_S2_N32_B64, V_S2_N64_B64,
-    // split-bf16 kernel: 16-wide bricks (conflict-free LDS reads); N = couts per workgroup
-    B3_N16, B3_N32, B3_N48, B3_N64, B3_N64_H5, B3_N96, B3_N96_H5, B3_N128_P, B3_N128_PH5, B3_N192_PH5, B3_N32_S, B3_N64_S, B3_N16_T, B3_N32_T, B3_N16_TW, B3_S2_N32, B3_S2_N32B, B3_S2_N64, B3_S2_N96, B3_S2_N128, B3_S2_N192,
-    // split-bf16 kernel with the trilinear x2 upsample fused into its producers (even bricks only)
-    B3U_N16, B3U_N32, B3U_N32_M, B3U_N48, B3U_N64, B3U_N96,
-    // Cout == 16 plane schedule (weights from mvsgi_conv3d_pack_weights_bf16x3_c16), plain and fused-upsample
-    B3P_N16, B3PU_N16,
-    // 32x32x16 schedule (Cout % 32 == 0, stride 1; weights from mvsgi_conv3d_pack_weights_bf16x3_v32), plain / fused upsample
-    B3V_N32, B3V_N64, B3VU_N32, B3VU_N64,
-    V_COUNT
-};
 const char* const kVariantNames[] = {
     "conv3d_direct_kernel<1>", "conv3d_direct_kernel<4>", "conv3d_head_kernel",
     "conv3d_mfma_kernel<1, 4, 4, 1, 4, 8, 8, 1>", "conv3d_mfma_kernel<2, 4, 4, 1, 4, 8, 8, 1>",
@@ -322,7 +310,12 @@ const char* const kVariantNames[] = {
     "conv3d_bf16x3_kernel<3, 5, 1, 4, 1, 5, 16, 1, 3, false, false, false, false>",
     "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, false>",
     "conv3d_bf16x3_kernel<2, 2, 2, 2, 1, 4, 16, 1, 3, false, false, false, false>",
-    "conv3d_bf16x3_kernel<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, false>", "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, false>",
+#ifdef MVSGI_EXPERIMENTAL      // B3_N16_T: the non-WLDS A/B reference in experimental builds only (launch_variant); the name follows the launch
+    "conv3d_bf16x3_kernel<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, false>",
+#else
+    "conv3d_bf16x3_kernel<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>",
+#endif
+    "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, false>",
     "conv3d_bf16x3_kernel<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>",
     "conv3d_bf16x3_kernel<2, 1, 4, 1, 2, 4, 8, 2, 3, false, false, false, false>",
     "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 8, 2, 3, false, false, false, false>",
@@ -453,7 +446,9 @@ int select_variant(const ConvArgs& a, int impl) {
         if (a.Do == 1 && CT >= 8 && CT % 4 == 0) {
             const long long rows5 = (long long)a.B * (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16);
             if (h5ok && CT % 12 == 0 && rows5 * (CT / 12) >= 384) return B3_N192_PH5;
-            if (h5ok && CT % 8 == 0) return B3_N128_PH5;
+            // (a launch of a few frames has too few of these units to fill the chip -- 384 -> 384 at one frame: 18 workgroups walking
+            // 24 slices each -- and falls through to the small-launch rule below)
+            if (h5ok && CT % 8 == 0 && rows5 * (CT / 8) >= mvsgi::device_cus() / 2) return B3_N128_PH5;
             if (CT % 8 == 0 && (long long)a.B * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16) * (CT / 8) >= 384) return B3_N128_P;
         }
         if (CT % 6 == 0 && h5ok && !mvsgi::exp_env("MVSGI_NO_H5") &&
@@ -487,6 +482,7 @@ int select_variant(const ConvArgs& a, int impl) {
 }
 
 int launch_variant(int v, const ConvArgs& a, hipStream_t st) {
+    if (a.f16) return mvsgi::conv3d_launch_b3_f16(v, &a, st);      // the fp16 split: the same variants, instantiated in conv3d_f16.hip
     switch (v) {
         case V_DIRECT1:
         case V_DIRECT4: return launch_direct(a, st);
@@ -498,43 +494,14 @@ int launch_variant(int v, const ConvArgs& a, hipStream_t st) {
         case V_S1_N64_B64: return launch_mfma<2, 2, 2, 2, 2, 4, 8, 1>(a, st);
         case V_S2_N32_B64: return launch_mfma<2, 1, 4, 1, 2, 4, 8, 2>(a, st);
         case V_S2_N64_B64: return launch_mfma<2, 2, 2, 2, 2, 4, 8, 2>(a, st);
-        case B3_N16: return launch_bf16x3<1, 4, 4, 1, 4, 4, 16, 1>(a, st);
-        case B3_N32: return launch_bf16x3<2, 4, 4, 1, 4, 4, 16, 1>(a, st);
-        case B3_N48: return launch_bf16x3<3, 4, 4, 1, 4, 4, 16, 1>(a, st);
-        case B3_N64: return launch_bf16x3<2, 4, 2, 2, 2, 4, 16, 1>(a, st);
-        case B3_N64_H5: return launch_bf16x3<2, 5, 2, 2, 2, 5, 16, 1>(a, st);
-        case B3_N96: return launch_bf16x3<3, 4, 2, 2, 2, 4, 16, 1>(a, st);
-        case B3_N96_H5: return launch_bf16x3<3, 5, 2, 2, 2, 5, 16, 1>(a, st);
-        case B3_N128_P: return launch_bf16x3<2, 4, 1, 4, 1, 4, 16, 1>(a, st);
-        case B3_N128_PH5: return launch_bf16x3<2, 5, 1, 4, 1, 5, 16, 1>(a, st);
-        case B3_N192_PH5: return launch_bf16x3<3, 5, 1, 4, 1, 5, 16, 1>(a, st);
-        case B3_N32_S: return launch_bf16x3<2, 1, 4, 1, 1, 4, 16, 1>(a, st);
-        case B3_N64_S: return launch_bf16x3<2, 2, 2, 2, 1, 4, 16, 1>(a, st);
+#define MVSGI_B3(V, ...) case V: return launch_bf16x3<__VA_ARGS__>(a, st);
+#include "conv3d_b3_variants.inc"
+#undef MVSGI_B3
 #ifdef MVSGI_EXPERIMENTAL      // the dispatcher's 16-cout units are B3_N16_TW; this one is the A/B reference of tools/wlds_probe.py
         case B3_N16_T: return launch_bf16x3<1, 1, 4, 1, 1, 4, 16, 1>(a, st);
 #else
         case B3_N16_T: return launch_bf16x3<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>(a, st);
 #endif
-        case B3_N32_T: return launch_bf16x3<2, 1, 4, 1, 1, 4, 16, 1>(a, st);
-        case B3_N16_TW: return launch_bf16x3<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>(a, st);
-        case B3_S2_N32: return launch_bf16x3<2, 1, 4, 1, 2, 4, 8, 2>(a, st);
-        case B3_S2_N32B: return launch_bf16x3<1, 2, 2, 2, 2, 4, 8, 2>(a, st);
-        case B3_S2_N64: return launch_bf16x3<2, 2, 2, 2, 2, 4, 8, 2>(a, st);
-        case B3_S2_N96: return launch_bf16x3<3, 2, 2, 2, 2, 4, 8, 2>(a, st);
-        case B3_S2_N128: return launch_bf16x3<2, 4, 1, 4, 2, 4, 8, 2>(a, st);
-        case B3_S2_N192: return launch_bf16x3<3, 4, 1, 4, 2, 4, 8, 2>(a, st);
-        case B3U_N16: return launch_bf16x3<1, 4, 4, 1, 4, 4, 16, 1, 3, true>(a, st);
-        case B3U_N32: return launch_bf16x3<2, 4, 4, 1, 4, 4, 16, 1, 3, true>(a, st);
-        case B3U_N32_M: return launch_bf16x3<2, 2, 4, 1, 2, 4, 16, 1, 3, true>(a, st);
-        case B3U_N48: return launch_bf16x3<3, 4, 4, 1, 4, 4, 16, 1, 3, true>(a, st);
-        case B3U_N64: return launch_bf16x3<2, 4, 2, 2, 2, 4, 16, 1, 3, true>(a, st);
-        case B3U_N96: return launch_bf16x3<3, 4, 2, 2, 2, 4, 16, 1, 3, true>(a, st);
-        case B3P_N16: return launch_bf16x3<1, 4, 4, 1, 4, 4, 16, 1, 3, false, true>(a, st);
-        case B3PU_N16: return launch_bf16x3<1, 4, 4, 1, 4, 4, 16, 1, 3, true, true>(a, st);
-        case B3V_N32: return launch_bf16x3<1, 2, 4, 1, 4, 4, 16, 1, 3, false, false, true>(a, st);
-        case B3V_N64: return launch_bf16x3<1, 2, 2, 2, 2, 4, 16, 1, 3, false, false, true>(a, st);
-        case B3VU_N32: return launch_bf16x3<1, 2, 4, 1, 4, 4, 16, 1, 3, true, false, true>(a, st);
-        case B3VU_N64: return launch_bf16x3<1, 2, 2, 2, 2, 4, 16, 1, 3, true, false, true>(a, st);
     }
     return mvsgi::fail("mvsgi_conv3d_f32: bad variant %d", v);
 }
@@ -565,6 +532,22 @@ int fill_args(ConvArgs& a, const float* x, const float* w_oidhw, const float* w_
     return 0;
 }
 
+// MVSGI_CONV_F16 OR-ed into a split-kernel selector (MVSGI_CONV_BF16X3 / _C16 / _V32): strips the flag and records it in the
+// launch arguments; any other selector with the flag is an error
+int split_flag(ConvArgs& a, int& impl, const char* who) {
+    a.f16 = (impl & MVSGI_CONV_F16) != 0;
+    impl &= ~MVSGI_CONV_F16;
+    MVSGI_REQUIRE(!a.f16 || impl == MVSGI_CONV_BF16X3 || impl == MVSGI_CONV_BF16X3_C16 || impl == MVSGI_CONV_BF16X3_V32,
+                  "%s: MVSGI_CONV_F16 goes with MVSGI_CONV_BF16X3 / _C16 / _V32 (got %d)", who, impl);
+    MVSGI_REQUIRE(!a.f16 || (a.Cin % 16 == 0 && a.Cout % 16 == 0), "%s: the fp16 split needs Cin, Cout multiples of 16 (got %d, %d)", who, a.Cin, a.Cout);
+    return 0;
+}
+
+const char* variant_name(int v, const ConvArgs& a) {
+    if (v == V_COUNT) return nullptr;
+    return a.f16 ? mvsgi::conv3d_b3_f16_name(v) : kVariantNames[v];
+}
+
 }  // namespace
 
 extern "C" size_t mvsgi_conv3d_packed_weight_floats(int Cout, int Cin) {
@@ -582,8 +565,38 @@ extern "C" int mvsgi_conv3d_pack_weights_bf16x3(const float* w_oidhw, void* w_pa
                   "mvsgi_conv3d_pack_weights_bf16x3: Cout=%d Cin=%d must be positive multiples of 16", Cout, Cin);
     const long long total = (long long)(Cin / 16) * pairs_of(3) * (Cout / 16) * 64;
     hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0,
-                       mvsgi::as_stream(stream), w_oidhw, reinterpret_cast<bf16x8*>(w_packed), Cout, Cin, 27);
+                       mvsgi::as_stream(stream), w_oidhw, reinterpret_cast<bf16x8*>(w_packed), Cout, Cin, 27, false);
     return mvsgi::check_launch("mvsgi_conv3d_pack_weights_bf16x3");
+}
+
+// weights of a split kernel in either split: layout = MVSGI_CONV_BF16X3 | _C16 | _V32, optionally | MVSGI_CONV_F16 (sizes as the bf16
+// packers': mvsgi_conv3d_packed_weight_bytes_bf16x3 / _c16 / _v32)
+extern "C" int mvsgi_conv3d_pack_weights_split(const float* w_oidhw, void* w_packed, int Cout, int Cin, int layout,
+                                               mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(w_oidhw && w_packed, "mvsgi_conv3d_pack_weights_split: null pointer");
+    const bool f16 = (layout & MVSGI_CONV_F16) != 0;
+    layout &= ~MVSGI_CONV_F16;
+    MVSGI_REQUIRE(Cout > 0 && Cin > 0 && Cout % 16 == 0 && Cin % 16 == 0,
+                  "mvsgi_conv3d_pack_weights_split: Cout=%d Cin=%d must be positive multiples of 16", Cout, Cin);
+    bf16x8* wp = reinterpret_cast<bf16x8*>(w_packed);
+    if (layout == MVSGI_CONV_BF16X3) {
+        const long long total = (long long)(Cin / 16) * pairs_of(3) * (Cout / 16) * 64;
+        hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0, mvsgi::as_stream(stream),
+                           w_oidhw, wp, Cout, Cin, 27, f16);
+    } else if (layout == MVSGI_CONV_BF16X3_C16) {
+        MVSGI_REQUIRE(Cout == 16, "mvsgi_conv3d_pack_weights_split: the plane layout is for Cout == 16 (got %d)", Cout);
+        const int total = (Cin / 16) * 5 * 3 * 64;
+        hipLaunchKernelGGL(pack_weights_bf16x3_c16_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0, mvsgi::as_stream(stream),
+                           w_oidhw, wp, Cin, f16);
+    } else if (layout == MVSGI_CONV_BF16X3_V32) {
+        MVSGI_REQUIRE(Cout % 32 == 0, "mvsgi_conv3d_pack_weights_split: the 32x32x16 layout needs Cout %% 32 == 0 (got %d)", Cout);
+        const long long total = (long long)(Cin / 16) * (Cout / 32) * 27 * 64;
+        hipLaunchKernelGGL(pack_weights_bf16x3_v32_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0, mvsgi::as_stream(stream),
+                           w_oidhw, wp, Cout, Cin, f16);
+    } else {
+        return mvsgi::fail("mvsgi_conv3d_pack_weights_split: layout %d is not a split-kernel layout", layout);
+    }
+    return mvsgi::check_launch("mvsgi_conv3d_pack_weights_split");
 }
 
 extern "C" size_t mvsgi_conv3d_packed_weight_bytes_bf16x3_v32(int Cout, int Cin) {
@@ -597,7 +610,7 @@ extern "C" int mvsgi_conv3d_pack_weights_bf16x3_v32(const float* w_oidhw, void* 
                   "mvsgi_conv3d_pack_weights_bf16x3_v32: Cout=%d must be a multiple of 32, Cin=%d of 16", Cout, Cin);
     const long long total = (long long)(Cin / 16) * (Cout / 32) * 27 * 64;
     hipLaunchKernelGGL(pack_weights_bf16x3_v32_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0,
-                       mvsgi::as_stream(stream), w_oidhw, reinterpret_cast<bf16x8*>(w_packed), Cout, Cin);
+                       mvsgi::as_stream(stream), w_oidhw, reinterpret_cast<bf16x8*>(w_packed), Cout, Cin, false);
     return mvsgi::check_launch("mvsgi_conv3d_pack_weights_bf16x3_v32");
 }
 
@@ -617,7 +630,7 @@ extern "C" int mvsgi_conv3d_pack_weights_bf16x3_c16(const float* w_oidhw, void* 
     MVSGI_REQUIRE(Cin > 0 && Cin % 16 == 0, "mvsgi_conv3d_pack_weights_bf16x3_c16: Cin=%d must be a positive multiple of 16", Cin);
     const int total = (Cin / 16) * 5 * 3 * 64;
     hipLaunchKernelGGL(pack_weights_bf16x3_c16_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0,
-                       mvsgi::as_stream(stream), w_oidhw, reinterpret_cast<bf16x8*>(w_packed), Cin);
+                       mvsgi::as_stream(stream), w_oidhw, reinterpret_cast<bf16x8*>(w_packed), Cin, false);
     return mvsgi::check_launch("mvsgi_conv3d_pack_weights_bf16x3_c16");
 }
 
@@ -645,6 +658,7 @@ extern "C" int mvsgi_conv3d_f32(const float* x, const float* w_oidhw, const floa
     ConvArgs a{};
     if (fill_args(a, x, w_oidhw, w_packed, scale, shift, res, y, B, Cin, Din, Hin, Win, Cout, stride, neg_slope))
         return 1;
+    if (split_flag(a, impl, "mvsgi_conv3d_f32")) return 1;
     const int v = select_variant(a, impl);
     if (v == V_COUNT) return 1;
     return launch_variant(v, a, mvsgi::as_stream(stream));
@@ -674,8 +688,9 @@ extern "C" const char* mvsgi_conv3d_variant_f32(int B, int Cin, int Din, int Hin
     if (fill_args(a, &dummy, &dummy, &dummy, &dummy, &dummy, nullptr, nullptr, B, Cin, Din, Hin, Win, Cout, stride,
                   1.f))
         return nullptr;
+    if (split_flag(a, impl, "mvsgi_conv3d_variant_f32")) return nullptr;
     const int v = select_variant(a, impl);
-    return v == V_COUNT ? nullptr : kVariantNames[v];
+    return variant_name(v, a);
 }
 
 // ResizeConv3d (common_modules.py:332-355) in one launch: trilinear x2 upsample (align_corners=False) of
@@ -684,6 +699,8 @@ extern "C" const char* mvsgi_conv3d_variant_f32(int B, int Cin, int Din, int Hin
 extern "C" int mvsgi_conv3d_up2_f32(const float* x, const void* w_packed, int w_layout, const float* scale,
                                     const float* shift, const float* res, float* y, int B, int Cin, int Dl, int Hl,
                                     int Wl, int Cout, float neg_slope, mvsgi_stream_t stream) {
+    const bool f16 = (w_layout & MVSGI_CONV_F16) != 0;
+    w_layout &= ~MVSGI_CONV_F16;
     MVSGI_REQUIRE(w_layout == MVSGI_CONV_BF16X3 || (w_layout == MVSGI_CONV_BF16X3_C16 && Cout == 16) ||
                       (w_layout == MVSGI_CONV_BF16X3_V32 && Cout % 32 == 0),
                   "mvsgi_conv3d_up2_f32: w_layout %d not valid for Cout %d", w_layout, Cout);
@@ -694,6 +711,7 @@ extern "C" int mvsgi_conv3d_up2_f32(const float* x, const void* w_packed, int w_
     if (fill_args(a, x, nullptr, static_cast<const float*>(w_packed), scale, shift, res, y, B, Cin, 2 * Dl, 2 * Hl,
                   2 * Wl, Cout, 1, neg_slope))
         return 1;
+    a.f16 = f16;
     const int v = select_variant_up2(a, w_layout);
     if (v == V_COUNT) return 1;
     return launch_variant(v, a, mvsgi::as_stream(stream));
@@ -703,6 +721,8 @@ extern "C" int mvsgi_conv3d_up2_f32(const float* x, const void* w_packed, int w_
 extern "C" int mvsgi_conv3d_up2_f32_out_split(const float* x, const void* w_packed, int w_layout, const float* scale, const float* shift,
                                               const float* res, void* y_split, int B, int Cin, int Dl, int Hl, int Wl, int Cout,
                                               float neg_slope, mvsgi_stream_t stream) {
+    const bool f16 = (w_layout & MVSGI_CONV_F16) != 0;      // the fp16 split: y_split then holds fp16 pairs (read by mvsgi_conv3d_head_split_f16)
+    w_layout &= ~MVSGI_CONV_F16;
     MVSGI_REQUIRE(w_layout == MVSGI_CONV_BF16X3 || (w_layout == MVSGI_CONV_BF16X3_C16 && Cout == 16),
                   "mvsgi_conv3d_up2_f32_out_split: w_layout %d not valid for Cout %d", w_layout, Cout);
     MVSGI_REQUIRE(x && y_split && scale && shift && w_packed, "mvsgi_conv3d_up2_f32_out_split: null pointer");
@@ -713,6 +733,7 @@ extern "C" int mvsgi_conv3d_up2_f32_out_split(const float* x, const void* w_pack
                   2 * Dl, 2 * Hl, 2 * Wl, Cout, 1, neg_slope))
         return 1;
     a.y_split = static_cast<unsigned char*>(y_split);
+    a.f16 = f16;
     const int v = select_variant_up2(a, w_layout);
     if (v == V_COUNT) return 1;
     return launch_variant(v, a, mvsgi::as_stream(stream));
@@ -724,6 +745,7 @@ extern "C" const char* mvsgi_conv3d_up2_variant_f32(int B, int Cin, int Dl, int 
     if (fill_args(a, &dummy, nullptr, &dummy, &dummy, &dummy, nullptr, nullptr, B, Cin, 2 * Dl, 2 * Hl, 2 * Wl, Cout, 1,
                   1.f))
         return nullptr;
-    const int v = select_variant_up2(a, w_layout);
-    return v == V_COUNT ? nullptr : kVariantNames[v];
+    a.f16 = (w_layout & MVSGI_CONV_F16) != 0;
+    const int v = select_variant_up2(a, w_layout & ~MVSGI_CONV_F16);
+    return variant_name(v, a);
 }

@@ -79,12 +79,64 @@ __device__ __forceinline__ f32x4 fma4(const f32x4 a, const f32x4 b, const f32x4 
     return __builtin_elementwise_fma(a, b, c);
 #endif
 }
+// ---- the second 16-bit split: fp16 ("f16x3") ----
+// hi = fp16(x), lo = fp16(x - hi): 11 + 11 significant bits per operand instead of bf16's 8 + 8, the same three products at the same
+// matrix rate (v_mfma_f32_16x16x32_f16), fp32 accumulation.  The split's error IS the arithmetic's error (tools/split_arith_emulation.py
+// reproduces the bf16x3 path's inverse-distance error on the CPU from the split alone): ~2^-21 per operand against 2^-17 -- inverse
+// distance 10x closer to the reference on a sharp softmax.  The price is fp16's range: an operand is CLAMPED to +-65504 (one
+// v_med3_f32; fp32's range in the bf16 split), and lo parts below 2^-14 are fp16 subnormals (honoured by the matrix cores of gfx950,
+// tools/ubench/mfma_f16_denorm.hip; absolute quantum 2^-24 -- why the host pre-scales the weights by a power of two per output
+// channel, undone in the epilogue's per-channel scale).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_f16x4(const f32x4 x, u32x2& hi, u32x2& lo) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const f32x2v v = {__builtin_amdgcn_fmed3f(x[2 * p], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(x[2 * p + 1], -65504.f, 65504.f)};
+        const f16x2v h = __builtin_convertvector(v, f16x2v);               // v_cvt_pk_f16_f32 (RNE)
+        hi[p] = __builtin_bit_cast(unsigned, h);
+        float r0 = v[0] - (float)h[0], r1 = v[1] - (float)h[1];            // exact in fp32
+        asm volatile("" : "+v"(r0));
+        asm volatile("" : "+v"(r1));
+        lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{r0, r1}, f16x2v));
+    }
+}
+template <bool F16>
+__device__ __forceinline__ void split_x4(const f32x4 x, u32x2& hi, u32x2& lo) {
+    if constexpr (F16) split_f16x4(x, hi, lo); else split_bf16x4(x, hi, lo);
+}
+// one matrix instruction of the split product: operands travel as 16-byte fragments whatever their element type
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(const bf16x8 a, const bf16x8 b, const f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+template <bool F16>
+__device__ __forceinline__ f32x16v mfma32(const bf16x8 a, const bf16x8 b, const f32x16v c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// host / pack kernels: one fp32 weight -> (hi, lo) of either split, as raw 16-bit patterns
+__device__ __forceinline__ void split_weight(float v, bool f16, unsigned short& hi, unsigned short& lo) {
+    if (f16) {
+        const _Float16 h = (_Float16)v;
+        hi = __builtin_bit_cast(unsigned short, h);
+        lo = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)h));
+    } else {
+        const __bf16 h = (__bf16)v;
+        hi = __builtin_bit_cast(unsigned short, h);
+        lo = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)h));
+    }
+}
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
 constexpr int pairs_of(int kd) { return (kd * 9 + 1) / 2; }      // KD = 3: 14 pairs of 27 taps; KD = 1 (2-D 3x3): 5 of 9
 
 // [Cout][Cin][taps] -> [Cin/16][Cout/16][pairs][hi|lo][64 lanes][8 bf16]   (taps = 27 or 9)
 //   lane = (kg << 4) | i holds W[cout = ct*16+i][cin = cc*16 + (kg>>1)*8 + j][tap = 2p + (kg&1)]
 __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout, int Cin,
-                                           int taps) {
+                                           int taps, bool f16 = false) {
     const int kPairs = (taps + 1) / 2;
     const int CT = Cout / 16;
     const long long total = (long long)(Cin / 16) * kPairs * CT * 64;
@@ -100,21 +152,22 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, bf16x8* 
     const int co = ct * 16 + (lane & 15);
     const int ci = cc * 16 + (kg >> 1) * 8;
     const int tap = 2 * p + (kg & 1);
-    bf16x8 hi, lo;
+    u16x8 hi, lo;
     for (int j = 0; j < 8; ++j) {
         const float v = tap < taps ? w[((long long)co * Cin + ci + j) * taps + tap] : 0.f;
-        const __bf16 h = (__bf16)v;
-        hi[j] = h;
-        lo[j] = (__bf16)(v - (float)h);
+        unsigned short h_, l_;
+        split_weight(v, f16, h_, l_);
+        hi[j] = h_;
+        lo[j] = l_;
     }
     const long long o = ((((long long)cc * CT + ct) * kPairs + p) * 2) * 64 + lane;
-    wp[o] = hi;
-    wp[o + 64] = lo;
+    wp[o] = __builtin_bit_cast(bf16x8, hi);
+    wp[o + 64] = __builtin_bit_cast(bf16x8, lo);
 }
 
 // Cout == 16 plane schedule: [16][Cin][27] -> [Cin/16][5 pairs][3 kd][hi|lo][64 lanes][8 bf16]
 //   lane = (kg << 4) | i holds W[cout = i][cin = cc*16 + (kg>>1)*8 + j][kd][in-plane tap 2p + (kg&1)]  (tap 9: zero)
-__global__ void pack_weights_bf16x3_c16_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cin) {
+__global__ void pack_weights_bf16x3_c16_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cin, bool f16 = false) {
     const int total = (Cin / 16) * 5 * 3 * 64;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
@@ -127,21 +180,22 @@ __global__ void pack_weights_bf16x3_c16_kernel(const float* __restrict__ w, bf16
     const int kg = lane >> 4, co = lane & 15;
     const int ci = cc * 16 + (kg >> 1) * 8;
     const int t2 = 2 * p + (kg & 1);
-    bf16x8 hi, lo;
+    u16x8 hi, lo;
     for (int j = 0; j < 8; ++j) {
         const float v = t2 < 9 ? w[((long long)co * Cin + ci + j) * 27 + kd * 9 + t2] : 0.f;
-        const __bf16 h = (__bf16)v;
-        hi[j] = h;
-        lo[j] = (__bf16)(v - (float)h);
+        unsigned short h_, l_;
+        split_weight(v, f16, h_, l_);
+        hi[j] = h_;
+        lo[j] = l_;
     }
     const long long o = ((long long)((cc * 5 + p) * 3 + kd) * 2) * 64 + lane;
-    wp[o] = hi;
-    wp[o + 64] = lo;
+    wp[o] = __builtin_bit_cast(bf16x8, hi);
+    wp[o + 64] = __builtin_bit_cast(bf16x8, lo);
 }
 
 // 32x32x16 schedule: [Cout][Cin][27] -> [Cin/16][Cout/32][27 taps][hi|lo][64 lanes][8 bf16]
 //   lane = (khalf << 5) | r holds W[cout = ct*32 + r][cin = cc*16 + khalf*8 + j][tap]
-__global__ void pack_weights_bf16x3_v32_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout, int Cin) {
+__global__ void pack_weights_bf16x3_v32_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout, int Cin, bool f16 = false) {
     const int CT = Cout / 32;
     const long long total = (long long)(Cin / 16) * CT * 27 * 64;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -154,16 +208,17 @@ __global__ void pack_weights_bf16x3_v32_kernel(const float* __restrict__ w, bf16
     const int cc = (int)(r / CT);
     const int co = ct * 32 + (lane & 31);
     const int ci = cc * 16 + (lane >> 5) * 8;
-    bf16x8 hi, lo;
+    u16x8 hi, lo;
     for (int j = 0; j < 8; ++j) {
         const float v = w[((long long)co * Cin + ci + j) * 27 + tap];
-        const __bf16 h = (__bf16)v;
-        hi[j] = h;
-        lo[j] = (__bf16)(v - (float)h);
+        unsigned short h_, l_;
+        split_weight(v, f16, h_, l_);
+        hi[j] = h_;
+        lo[j] = l_;
     }
     const long long o = ((((long long)cc * CT + ct) * 27 + tap) * 2) * 64 + lane;
-    wp[o] = hi;
-    wp[o + 64] = lo;
+    wp[o] = __builtin_bit_cast(bf16x8, hi);
+    wp[o + 64] = __builtin_bit_cast(bf16x8, lo);
 }
 
 // bijective XCD-aware remap of a flat block id (cdna_hip_programming.md T1): blocks b, b+8, ...
@@ -205,10 +260,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // stage the unit's weight slice (NW x 28 KiB, contiguous in the packed layout) into LDS beside the activation image, once per
 // workgroup, under the same per-unit barrier; the consumers read weight fragments like activation fragments (XB-deep, restarted
 // per unit): 16 ds_read_b128 per slot and CU instead of 8 KiB of vector-memory returns.
-template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false, bool PLANE = false,
-          bool V32 = false, bool WLDS = false>
-__global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {      // 2 waves per SIMD: 256 registers
-    static_assert(!WLDS || (WN == 1 && KD == 3 && !UPS && !PLANE && !V32 && S == 1 && MW * NW <= 2), "LDS-staged weights: shared cout tiles, one or two tiles per wave");
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD, bool UPS, bool PLANE, bool V32, bool WLDS, bool F16>
+__device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
+    // (NW == 1: the producers stage the tiles from pct0 = min(cb * NW, CT - NW) on, the consumers clamp tile by tile -- the two agree for one tile)
+    static_assert(!WLDS || (WN == 1 && KD == 3 && !UPS && !PLANE && !V32 && S == 1 && NW == 1 && MW <= 2), "LDS-staged weights: one shared cout tile, one or two voxel tiles per wave");
     static_assert(!V32 || (S == 1 && KD == 3 && TW == 16 && TH % 2 == 0 && !PLANE), "32x32x16 schedule: stride 1, 16-wide even bricks");
     static_assert(!PLANE || (NW == 1 && WN == 1 && WM == 4 && TH == 4 && MW == TD && TW == 16 && S == 1 && KD == 3),
                   "plane schedule: Cout == 16, 4 h-rows x TD planes x 16 w per brick");
@@ -381,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                         _Pragma("unroll") for (int kw = 0; kw < 2; ++kw) {                              \
                             const bool ok = ((IM[IT] >> kd) & (IM[IT] >> (2 + kh)) & (IM[IT] >> (4 + kw)) & 1u) != 0; \
                             u32x2 hi, lo;                                                               \
-                            split_bf16x4(xo[kh][kw], hi, lo);                                           \
+                            split_x4<F16>(xo[kh][kw], hi, lo);                                           \
                             if (!ok) hi = lo = u32x2{0u, 0u};                                           \
                             const int vo_ = ((2 * cd + kd) * ITH + 2 * ch + kh) * ROWP + (2 * cw + kw) * kVSB; \
                             *reinterpret_cast<u32x2*>((DST) + vo_ + q * 8) = hi;                        \
@@ -408,7 +463,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                             _Pragma("unroll") for (int kw = 0; kw < 2; ++kw) {                          \
                                 const bool ok = ((IM[IT] >> kd) & (IM[IT] >> (2 + kh)) & (IM[IT] >> (4 + kw)) & 1u) != 0; \
                                 u32x2 hi, lo;                                                           \
-                                split_bf16x4(xo[kd][kh][kw], hi, lo);                                   \
+                                split_x4<F16>(xo[kd][kh][kw], hi, lo);                                   \
                                 if (!ok) hi = lo = u32x2{0u, 0u};                                       \
                                 const int vo_ = ((2 * cd + kd) * ITH + 2 * ch + kh) * ROWP + (2 * cw + kw) * kVSB; \
                                 *reinterpret_cast<u32x2*>((DST) + vo_ + q * 8) = hi;                    \
@@ -554,7 +609,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                     hi = u32x2{__builtin_bit_cast(unsigned, PRE[IT][0] + 0.f), __builtin_bit_cast(unsigned, PRE[IT][1] + 0.f)}; \
                     lo = u32x2{__builtin_bit_cast(unsigned, PRE[IT][2] + 0.f), __builtin_bit_cast(unsigned, PRE[IT][3] + 0.f)}; \
                 } else {                                                                                \
-                    split_bf16x4(PRE[IT], hi, lo);                                                      \
+                    split_x4<F16>(PRE[IT], hi, lo);                                                      \
                 }                                                                                       \
                 const int vo_ = V32 ? (v / ITW) * ROWP + (v % ITW) * kVSB : v * kVSB;                   \
                 *reinterpret_cast<u32x2*>((DST) + vo_ + q * 8) = hi;                                    \
@@ -668,8 +723,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
         _Pragma("unroll") for (int tr = 0; tr < 3; ++tr)                                               \
             _Pragma("unroll") for (int i = 0; i < MW; ++i)                                             \
                 _Pragma("unroll") for (int j = 0; j < NW; ++j)                                         \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr == 0 ? wl[WBUFI][j] : wh[WBUFI][j], \
-                                                                         tr == 1 ? xl[BUFI][i] : xh[BUFI][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma32<F16>(tr == 0 ? wl[WBUFI][j] : wh[WBUFI][j], tr == 1 ? xl[BUFI][i] : xh[BUFI][i], acc[i][j]);
         int cb_, b_, od0, oh0, ow0;
         MVSGI_DECODE((int)blockIdx.x, cb_, b_, od0, oh0, ow0)
         MVSGI_CTILES(ctc, cb_)
@@ -852,13 +906,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
 #define MVSGI_MFMAS(WBUF, XBUF, I0, I1)                                                               \
         _Pragma("unroll") for (int i = (I0); i < (I1); ++i)                                           \
             _Pragma("unroll") for (int j = 0; j < NW; ++j)                                            \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[WBUF][j], xh[XBUF][i], acc[i][j], 0, 0, 0); \
+                acc[i][j] = mfma16<F16>(wl[WBUF][j], xh[XBUF][i], acc[i][j]); \
         _Pragma("unroll") for (int i = (I0); i < (I1); ++i)                                           \
             _Pragma("unroll") for (int j = 0; j < NW; ++j)                                            \
-                (TACC ? acc1[i][j] : acc[i][j]) = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[WBUF][j], xl[XBUF][i], TACC ? acc1[i][j] : acc[i][j], 0, 0, 0); \
+                (TACC ? acc1[i][j] : acc[i][j]) = mfma16<F16>(wh[WBUF][j], xl[XBUF][i], TACC ? acc1[i][j] : acc[i][j]); \
         _Pragma("unroll") for (int i = (I0); i < (I1); ++i)                                           \
             _Pragma("unroll") for (int j = 0; j < NW; ++j)                                            \
-                (TACC ? acc2[i][j] : acc[i][j]) = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[WBUF][j], xh[XBUF][i], TACC ? acc2[i][j] : acc[i][j], 0, 0, 0);
+                (TACC ? acc2[i][j] : acc[i][j]) = mfma16<F16>(wh[WBUF][j], xh[XBUF][i], TACC ? acc2[i][j] : acc[i][j]);
         // one or two tiles per wave: the three products of a tile would sit back to back on ONE accumulator (each waits for
         // the one before: stamps, 200 ticks per 48-cycle slot); they get an accumulator each, summed in the epilogue
         constexpr bool TACC = KD == 3 && !PLANE && !V32 && MW * NW <= 2;
@@ -901,8 +955,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
         _Pragma("unroll") for (int tr = 0; tr < 3; ++tr)                                               \
             _Pragma("unroll") for (int kd = 0; kd < 3; ++kd)                                           \
                 _Pragma("unroll") for (int i = 0; i < TD; ++i)                                         \
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr == 0 ? pwl[WBUFI][kd] : pwh[WBUFI][kd], \
-                                                                         tr == 1 ? pxl[BUFI][i + kd] : pxh[BUFI][i + kd], acc[i][0], 0, 0, 0);
+                    acc[i][0] = mfma16<F16>(tr == 0 ? pwl[WBUFI][kd] : pwh[WBUFI][kd], tr == 1 ? pxl[BUFI][i + kd] : pxh[BUFI][i + kd], acc[i][0]);
         if constexpr (PLANE) {
             unsigned l16 = lane16;
             MVSGI_PL_LOADW(0, 0, 0)
@@ -1079,7 +1132,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
                         if (a.y_split) {
                             // split-padded output: slice (ct0 + j) of the voxel record, this lane's 4 couts = 8 B of hi and 8 B of lo
                             u32x2 hi, lo;
-                            split_bf16x4(r, hi, lo);
+                            split_x4<F16>(r, hi, lo);
                             if (eoff[i] >= 0 && ct0 + j < CT) {
                                 unsigned char* q = a.y_split + (long long)b_ * ((long long)(a.Do + 2 * ypd) * (a.Ho + 2 * ypp) * (a.Wo + 2 * ypp) * a.Cout * 4) +
                                                    soff[i] + (ct0 + j) * 64;
@@ -1113,14 +1166,28 @@ __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {    
 #undef STAMP
 }
 
+// the two arithmetics of the body as two kernels (the names the profiler and mvsgi_conv3d_variant_f32 report)
 template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false, bool PLANE = false,
           bool V32 = false, bool WLDS = false>
+__global__ __launch_bounds__(512, 2) void conv3d_bf16x3_kernel(ConvArgs a) {      // 2 waves per SIMD: 256 registers
+    conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32, WLDS, false>(a);
+}
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false, bool PLANE = false,
+          bool V32 = false, bool WLDS = false>
+__global__ __launch_bounds__(512, 2) void conv3d_f16x3_kernel(ConvArgs a) {
+    conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32, WLDS, true>(a);
+}
+
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false, bool PLANE = false,
+          bool V32 = false, bool WLDS = false, bool F16 = false>
 int launch_bf16x3(ConvArgs a, hipStream_t st) {
     constexpr int ITD = (TD - 1) * (KD == 1 ? 1 : S) + KD, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
     constexpr int ROWP = V32 ? ((ITW * kVSB + 255) / 256) * 256 : ITW * kVSB;
     constexpr size_t lds_bytes = (size_t)2 * (ITD * ITH * ROWP + (WLDS ? NW * pairs_of(KD) * 2048 : 0));   // double-buffered image (+ weight slice)
     static_assert(lds_bytes <= 160 * 1024, "LDS images too large");
-    auto kern = conv3d_bf16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32, WLDS>;
+    void (*kern)(ConvArgs);
+    if constexpr (F16) kern = conv3d_f16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32, WLDS>;
+    else kern = conv3d_bf16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32, WLDS>;
     static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
     if (mvsgi::persistent_geometry(kern, 512, lds_bytes, 2, geo_cache, "conv3d(bf16x3)", geo)) return 1;

@@ -20,6 +20,8 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
 struct HeadArgs {
     const unsigned char* x;     // split-padded [B][D+2][H+2][W+2][Cin * 4 bytes]
@@ -38,23 +40,34 @@ __device__ __forceinline__ int hs_xcd_remap(int bid, int n) {
 
 // [1][Cin][27] fp32 -> [Cin/16][tt 2][A1 | A2][64 lanes][8 bf16]; lane = (kg << 4) | i, tap = tt * 16 + i (taps >= 27: zero)
 //   A1: w_hi[tap][16 cs + 8 (kg & 1) + j]  (kg 0, 1 meet x_hi, kg 2, 3 meet x_lo);  A2: kg < 2: w_lo[tap][16 cs + 8 kg + j], else 0
-__global__ void head_split_pack_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cin) {
+//   f16: the fp16 split (hi = fp16(w), lo = fp16(w - hi)) for an input written by a kernel of the fp16 split (conv3d_f16.hip)
+__global__ void head_split_pack_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cin, bool f16) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int total = (Cin / 16) * 2 * 64;
     if (idx >= total) return;
     const int lane = idx & 63, tt = (idx >> 6) & 1, cs = idx >> 7;
     const int kg = lane >> 4, tap = tt * 16 + (lane & 15);
-    bf16x8 a1, a2;
+    u16x8 a1, a2;
     for (int j = 0; j < 8; ++j) {
         const float v = tap < 27 ? w[(cs * 16 + 8 * (kg & 1) + j) * 27 + tap] : 0.f;
-        const __bf16 h = (__bf16)v;
+        unsigned short h, l;
+        if (f16) {
+            const _Float16 hh = (_Float16)v;
+            h = __builtin_bit_cast(unsigned short, hh);
+            l = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)hh));
+        } else {
+            const __bf16 hh = (__bf16)v;
+            h = __builtin_bit_cast(unsigned short, hh);
+            l = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)hh));
+        }
         a1[j] = h;
-        a2[j] = kg < 2 ? (__bf16)(v - (float)h) : (__bf16)0.f;
+        a2[j] = kg < 2 ? l : (unsigned short)0;
     }
-    wp[((cs * 2 + tt) * 2) * 64 + lane] = a1;
-    wp[((cs * 2 + tt) * 2 + 1) * 64 + lane] = a2;
+    wp[((cs * 2 + tt) * 2) * 64 + lane] = __builtin_bit_cast(bf16x8, a1);
+    wp[((cs * 2 + tt) * 2 + 1) * 64 + lane] = __builtin_bit_cast(bf16x8, a2);
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void conv3d_head_split_kernel(HeadArgs a, int dchunk, int nd) {
     constexpr int TH = 8, TW = 32, ITH = TH + 2, ITW = TW + 2, PV = ITH * ITW;     // 10 x 34 halo window = 340 voxels
     constexpr int NT = (PV + 15) / 16;               // 22 voxel tiles of 16
@@ -140,8 +153,13 @@ __global__ __launch_bounds__(256) void conv3d_head_split_kernel(HeadArgs a, int 
             if (wave + 4 * k < NT) {                 // wave-uniform
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
-                    acc[k][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cw[tt][1], cx[k], acc[k][tt], 0, 0, 0);
-                    acc[k][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cw[tt][0], cx[k], acc[k][tt], 0, 0, 0);
+                    if constexpr (F16) {
+                        acc[k][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, cw[tt][1]), __builtin_bit_cast(f16x8, cx[k]), acc[k][tt], 0, 0, 0);
+                        acc[k][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, cw[tt][0]), __builtin_bit_cast(f16x8, cx[k]), acc[k][tt], 0, 0, 0);
+                    } else {
+                        acc[k][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cw[tt][1], cx[k], acc[k][tt], 0, 0, 0);
+                        acc[k][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cw[tt][0], cx[k], acc[k][tt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -199,24 +217,21 @@ extern "C" size_t mvsgi_conv3d_head_split_packed_weight_bytes(int Cin) {
     return Cin > 0 && Cin % 16 == 0 ? (size_t)(Cin / 16) * 2 * 2 * 64 * 16 : 0;
 }
 
-// w_oidhw: [1][Cin][3][3][3] fp32 (device) -> the head's fragment layout (device)
-extern "C" int mvsgi_conv3d_head_split_pack_weights(const float* w_oidhw, void* w_packed, int Cin, mvsgi_stream_t stream) {
-    MVSGI_REQUIRE(w_oidhw && w_packed, "mvsgi_conv3d_head_split_pack_weights: null pointer");
-    MVSGI_REQUIRE(Cin > 0 && Cin % 16 == 0, "mvsgi_conv3d_head_split_pack_weights: Cin=%d must be a positive multiple of 16", Cin);
+namespace {
+int head_pack(const float* w_oidhw, void* w_packed, int Cin, bool f16, mvsgi_stream_t stream, const char* who) {
+    MVSGI_REQUIRE(w_oidhw && w_packed, "%s: null pointer", who);
+    MVSGI_REQUIRE(Cin > 0 && Cin % 16 == 0, "%s: Cin=%d must be a positive multiple of 16", who, Cin);
     const int total = (Cin / 16) * 2 * 64;
     hipLaunchKernelGGL(head_split_pack_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0, mvsgi::as_stream(stream), w_oidhw,
-                       static_cast<bf16x8*>(w_packed), Cin);
-    return mvsgi::check_launch("mvsgi_conv3d_head_split_pack_weights");
+                       static_cast<bf16x8*>(w_packed), Cin, f16);
+    return mvsgi::check_launch(who);
 }
 
-// y[b][d][h][w] = act(conv(x)[0] * scale + shift): x split-padded [B][D+2][H+2][W+2][Cin] (e.g. the output of
-// mvsgi_conv3d_up2_poly_split), scale / shift: one float each in DEVICE memory is not needed -- they are passed by value
-// (BaseConvBlk3d with NoOp norm: scale 1, shift = bias); neg_slope 1 = no activation (out_costs.1 has none).
-extern "C" int mvsgi_conv3d_head_split(const void* x_split, const void* w_packed, float scale, float shift, float* y, int B, int Cin,
-                                       int D, int H, int W, float neg_slope, mvsgi_stream_t stream) {
-    MVSGI_REQUIRE(x_split && w_packed && y, "mvsgi_conv3d_head_split: null pointer");
-    MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0, "mvsgi_conv3d_head_split: bad dims (Cin %% 16 == 0)");
-    MVSGI_REQUIRE((long long)(H + 2) * (W + 2) * Cin * 4 < (1ll << 31), "mvsgi_conv3d_head_split: plane too large for 32-bit offsets");
+int head_launch(const void* x_split, const void* w_packed, float scale, float shift, float* y, int B, int Cin, int D, int H, int W,
+                float neg_slope, bool f16, mvsgi_stream_t stream, const char* who) {
+    MVSGI_REQUIRE(x_split && w_packed && y, "%s: null pointer", who);
+    MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0, "%s: bad dims (Cin %% 16 == 0)", who);
+    MVSGI_REQUIRE((long long)(H + 2) * (W + 2) * Cin * 4 < (1ll << 31), "%s: plane too large for 32-bit offsets", who);
     HeadArgs a{};
     a.x = static_cast<const unsigned char*>(x_split);
     a.wp = static_cast<const bf16x8*>(w_packed);
@@ -232,8 +247,34 @@ extern "C" int mvsgi_conv3d_head_split(const void* x_split, const void* w_packed
     const int dchunk = (int)mvsgi::cdiv(D, nd);
     nd = mvsgi::cdiv(D, dchunk);
     const long long nt = windows * nd;
-    MVSGI_REQUIRE(nt < (1ll << 31), "mvsgi_conv3d_head_split: too many tiles");
+    MVSGI_REQUIRE(nt < (1ll << 31), "%s: too many tiles", who);
     constexpr size_t lds_bytes = (size_t)27 * 360 * sizeof(float);
-    hipLaunchKernelGGL(conv3d_head_split_kernel, dim3((unsigned)nt), dim3(256), lds_bytes, mvsgi::as_stream(stream), a, dchunk, (int)nd);
-    return mvsgi::check_launch("mvsgi_conv3d_head_split");
+    if (f16)
+        hipLaunchKernelGGL(conv3d_head_split_kernel<true>, dim3((unsigned)nt), dim3(256), lds_bytes, mvsgi::as_stream(stream), a, dchunk, (int)nd);
+    else
+        hipLaunchKernelGGL(conv3d_head_split_kernel<false>, dim3((unsigned)nt), dim3(256), lds_bytes, mvsgi::as_stream(stream), a, dchunk, (int)nd);
+    return mvsgi::check_launch(who);
+}
+}  // namespace
+
+// w_oidhw: [1][Cin][3][3][3] fp32 (device) -> the head's fragment layout (device)
+extern "C" int mvsgi_conv3d_head_split_pack_weights(const float* w_oidhw, void* w_packed, int Cin, mvsgi_stream_t stream) {
+    return head_pack(w_oidhw, w_packed, Cin, false, stream, "mvsgi_conv3d_head_split_pack_weights");
+}
+// the same in the fp16 split (for an input written by a kernel of the fp16 split; the caller pre-scales the weights by a power of
+// two and passes its inverse in `scale`, see MVSGI_CONV_F16)
+extern "C" int mvsgi_conv3d_head_split_pack_weights_f16(const float* w_oidhw, void* w_packed, int Cin, mvsgi_stream_t stream) {
+    return head_pack(w_oidhw, w_packed, Cin, true, stream, "mvsgi_conv3d_head_split_pack_weights_f16");
+}
+
+// y[b][d][h][w] = act(conv(x)[0] * scale + shift): x split-padded [B][D+2][H+2][W+2][Cin] (e.g. the output of
+// mvsgi_conv3d_up2_poly_split), scale / shift: one float each in DEVICE memory is not needed -- they are passed by value
+// (BaseConvBlk3d with NoOp norm: scale 1, shift = bias); neg_slope 1 = no activation (out_costs.1 has none).
+extern "C" int mvsgi_conv3d_head_split(const void* x_split, const void* w_packed, float scale, float shift, float* y, int B, int Cin,
+                                       int D, int H, int W, float neg_slope, mvsgi_stream_t stream) {
+    return head_launch(x_split, w_packed, scale, shift, y, B, Cin, D, H, W, neg_slope, false, stream, "mvsgi_conv3d_head_split");
+}
+extern "C" int mvsgi_conv3d_head_split_f16(const void* x_split, const void* w_packed, float scale, float shift, float* y, int B, int Cin,
+                                           int D, int H, int W, float neg_slope, mvsgi_stream_t stream) {
+    return head_launch(x_split, w_packed, scale, shift, y, B, Cin, D, H, W, neg_slope, true, stream, "mvsgi_conv3d_head_split_f16");
 }

@@ -1,0 +1,23 @@
+// Kernel variants of conv3d.hip (shared with conv3d_f16.hip, which holds the fp16-split instantiations of the split kernels).
+#pragma once
+namespace {
+enum Variant {
+    V_DIRECT1, V_DIRECT4, V_HEAD,
+    V_S1_N16_B256, V_S1_N32_B256, V_S1_N32_B64, V_S1_N64_B128, V_S1_N64_B64, V_S2_N32_B64, V_S2_N64_B64,
+    // split-bf16 kernel: 16-wide bricks (conflict-free LDS reads); N = couts per workgroup
+    B3_N16, B3_N32, B3_N48, B3_N64, B3_N64_H5, B3_N96, B3_N96_H5, B3_N128_P, B3_N128_PH5, B3_N192_PH5, B3_N32_S, B3_N64_S, B3_N16_T, B3_N32_T, B3_N16_TW, B3_S2_N32, B3_S2_N32B, B3_S2_N64, B3_S2_N96, B3_S2_N128, B3_S2_N192,
+    // split-bf16 kernel with the trilinear x2 upsample fused into its producers (even bricks only)
+    B3U_N16, B3U_N32, B3U_N32_M, B3U_N48, B3U_N64, B3U_N96,
+    // Cout == 16 plane schedule (weights from mvsgi_conv3d_pack_weights_bf16x3_c16), plain and fused-upsample
+    B3P_N16, B3PU_N16,
+    // 32x32x16 schedule (Cout % 32 == 0, stride 1; weights from mvsgi_conv3d_pack_weights_bf16x3_v32), plain / fused upsample
+    B3V_N32, B3V_N64, B3VU_N32, B3VU_N64,
+    V_COUNT
+};
+}  // namespace
+
+namespace mvsgi {
+// conv3d_f16.hip: the split kernel variants (B3*) in the fp16 split; `args` is a ConvArgs
+int conv3d_launch_b3_f16(int variant, const void* args, hipStream_t st);
+const char* conv3d_b3_f16_name(int variant);
+}  // namespace mvsgi

@@ -18,6 +18,7 @@ struct ConvArgs {
     int total_units;   // persistent bf16x3 kernel: bricks x cout blocks
     unsigned char* y_split;    // bf16x3 kernels: when set, the output goes here in the split-padded format (conv3d_rs.hip) instead of y
     unsigned long long* dbg;   // MVSGI_STAMPS diagnostic build only
+    int f16;                   // split kernels: the fp16 split (hi = fp16(x), lo = fp16(x - hi), v_mfma_*_f16) instead of the bf16 split; host-side selector
     int ys_2d;                 // y_split is the 2-D format of resblock2d_rs.hip: no border along D (= images), two pixels along H and W
 };
 

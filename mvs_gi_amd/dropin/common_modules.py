@@ -51,10 +51,18 @@ class ConvLaunch:
     """Device-resident launch arguments of one BaseConvBlk3d: PyTorch-layout weight, packed
     MFMA weight (or None), per-channel scale/shift (eval BatchNorm3d or bias), stride, slope."""
     __slots__ = ("w", "wp", "wp_b3", "wp_c16", "wp_v32", "wp_rs", "wp_s2", "wp_poly", "wp_head", "head_sc", "scale", "shift", "stride",
-                 "neg_slope", "cin", "cout", "key")
+                 "neg_slope", "cin", "cout", "key", "f16")
 
     def run(self, x_ndhwc: Tensor, res: Optional[Tensor] = None, impl: Optional[int] = None) -> Tensor:
         wp = self.wp
+        if impl is None and H.get_conv_mode() == "f16x3" and self.cin % 16 == 0 and self.cout % 16 == 0:
+            B, D, Hh, W, _ = x_ndhwc.shape
+            layout = H.CONV_BF16X3_C16 if self._c16() else \
+                (H.CONV_BF16X3_V32 if _USE_V32 and self.cout % 32 == 0 and H.conv3d_v32_applies(B, self.cin, D, Hh, W, self.cout, self.stride)
+                 else H.CONV_BF16X3)
+            wp16, sc16 = self._f16(layout)
+            return H.conv3d(x_ndhwc, self.w, wp16, sc16, self.shift, res=res, stride=self.stride, neg_slope=self.neg_slope,
+                            impl=layout | H.CONV_F16)
         if impl is None:
             impl = H.CONV_AUTO
             if H.get_conv_mode() == "bf16x3" and self.cin % 16 == 0 and self.cout % 16 == 0:
@@ -73,6 +81,16 @@ class ConvLaunch:
             wp = self.wp_b3
         return H.conv3d(x_ndhwc, self.w, wp, self.scale, self.shift, res=res, stride=self.stride,
                         neg_slope=self.neg_slope, impl=impl)
+
+    def _f16(self, layout: int):
+        """(packed weights, per-channel scale) of the fp16 split in `layout`: the weights pre-scaled per output channel by a power
+        of two, the epilogue's scale carrying the inverse (H.pack_conv_weights_f16x3)."""
+        if self.f16 is None:
+            self.f16 = {}
+        if layout not in self.f16:
+            wp, unscale = H.pack_conv_weights_f16x3(self.w, layout)
+            self.f16[layout] = (wp, (self.scale * unscale).contiguous())
+        return self.f16[layout]
 
     def _c16(self) -> bool:
         """Cout == 16, stride 1: the plane-schedule kernel (MVSGI_CONV_BF16X3_C16)."""
@@ -125,10 +143,18 @@ class ConvLaunch:
         return self.wp_poly[k]
 
     def head_split_ok(self) -> bool:
-        """The split-bf16 cost head on a split-padded input (csrc/conv3d_headsplit.hip)."""
-        return H.get_conv_mode() == "bf16x3" and self.cout == 1 and self.cin % 16 == 0 and self.stride == 1
+        """The split cost head on a split-padded input (csrc/conv3d_headsplit.hip), in either 16-bit split."""
+        return H.split_mode() and self.cout == 1 and self.cin % 16 == 0 and self.stride == 1
 
     def run_head_split(self, x_split) -> Tensor:
+        if x_split.fmt == "f16":
+            if self.f16 is None:
+                self.f16 = {}
+            if "head" not in self.f16:
+                wp, unscale = H.pack_head_split_weights_f16(self.w)
+                self.f16["head"] = (wp, float(self.scale[0]) * unscale, float(self.shift[0]))      # one host read at lowering time
+            wp, sc, sh = self.f16["head"]
+            return H.conv3d_head_split(x_split, wp, sc, sh, neg_slope=self.neg_slope, f16=True)
         if self.wp_head is None:
             self.wp_head = H.pack_head_split_weights(self.w)
             self.head_sc = (float(self.scale[0]), float(self.shift[0]))       # one host read at lowering time
@@ -143,17 +169,26 @@ class ConvLaunch:
                                  neg_slope=self.neg_slope, out=out)
 
     def run_up2_split(self, x_lowres_ndhwc: Tensor, res: Optional[Tensor], out) -> "H.SplitAct":
-        """conv(trilinear_x2(x)) (+ res) written split-padded into `out` (the polyphase layer's input)."""
+        """conv(trilinear_x2(x)) (+ res) written split-padded into `out` (the polyphase layer's input, the split head's input)."""
+        if H.get_conv_mode() == "f16x3":
+            layout = H.CONV_BF16X3_C16 if self._c16() else H.CONV_BF16X3
+            wp16, sc16 = self._f16(layout)
+            return H.conv3d_up2_out_split(x_lowres_ndhwc, wp16, sc16, self.shift, out=out, res=res, neg_slope=self.neg_slope,
+                                          w_layout=layout | H.CONV_F16)
         if self._c16():       # Cout == 16: the plane schedule (one cout tile)
             return H.conv3d_up2_out_split(x_lowres_ndhwc, self._wp_c16(), self.scale, self.shift, out=out, res=res,
                                           neg_slope=self.neg_slope, w_layout=H.CONV_BF16X3_C16)
         return H.conv3d_up2_out_split(x_lowres_ndhwc, self._wp_b3(), self.scale, self.shift, out=out, res=res, neg_slope=self.neg_slope)
 
     def can_fuse_up2(self) -> bool:
-        return H.get_conv_mode() == "bf16x3" and self.stride == 1 and self.cin % 16 == 0 and self.cout % 16 == 0
+        return H.split_mode() and self.stride == 1 and self.cin % 16 == 0 and self.cout % 16 == 0
 
     def run_up2(self, x_lowres_ndhwc: Tensor, res: Optional[Tensor] = None) -> Tensor:
         """conv(trilinear_x2(x)) in one launch (mvsgi_conv3d_up2_f32)."""
+        if H.get_conv_mode() == "f16x3":
+            layout = H.CONV_BF16X3_C16 if self._c16() else H.CONV_BF16X3
+            wp16, sc16 = self._f16(layout)
+            return H.conv3d_up2(x_lowres_ndhwc, wp16, sc16, self.shift, res=res, neg_slope=self.neg_slope, w_layout=layout | H.CONV_F16)
         if self._c16():
             return H.conv3d_up2(x_lowres_ndhwc, self._wp_c16(), self.scale, self.shift, res=res,
                                 neg_slope=self.neg_slope, w_layout=H.CONV_BF16X3_C16)
@@ -253,6 +288,7 @@ def lower_conv_block(blk) -> ConvLaunch:
     L.wp_poly = None
     L.wp_head = None
     L.head_sc = None
+    L.f16 = None
     L.scale = scale.contiguous()
     L.shift = shift.contiguous()
     L.stride = int(conv.stride[0])

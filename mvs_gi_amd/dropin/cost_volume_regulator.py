@@ -207,13 +207,31 @@ def _split_head_tail(self, x: Tensor):
     if not (_HEAD_SPLIT and Lh.head_split_ok() and Lo.can_fuse_up2() and oc.scale == 2 and oc.out_pad == 0 and Lh.cin == Lo.cout):
         return None
     B, Dl, Hl, Wl, _ = x.shape
-    if (2 * Dl + 2) * (2 * Hl + 2) * (2 * Wl + 2) * Lo.cout * 4 >= 2 ** 31:        # the split-padded frame must fit 32-bit offsets
+    if (2 * Dl + 2) * (2 * Hl + 4) * (2 * Wl + 4) * Lo.cout * 4 >= 2 ** 31:        # the launcher's bound for a split-padded output frame (32-bit offsets)
         return None
-    bufs = self.__dict__.setdefault("_mvsgi_head_bufs", {})          # one split-padded buffer per shape, never replaced
-    key = (B, 2 * Dl, 2 * Hl, 2 * Wl, Lo.cout, x.device)
-    if key not in bufs:
-        bufs[key] = H.SplitAct(B, 2 * Dl, 2 * Hl, 2 * Wl, Lo.cout, x.device)
-    return Lh.run_head_split(Lo.run_up2_split(x, None, bufs[key]))
+    return Lh.run_head_split(Lo.run_up2_split(x, None, _owned_head_buffer(self, B, 2 * Dl, 2 * Hl, 2 * Wl, Lo.cout, x.device)))
+
+
+def _owned_head_buffer(self, B, D, Hh, W, C, device):
+    """The module-owned split-padded buffer between out_costs.0 and the split head: ONE allocation per frame geometry, sized for the
+    largest batch seen, handed out as a view of its first B frames (the format is per frame: a prefix of the batch is a valid
+    buffer).  A caller that varies its batch (batch sweeps, dataset tails) therefore holds one buffer, not one per batch size; a
+    larger batch replaces it -- unless a captured hipGraph may hold its address (`_mvsgi_pinned`, set while capturing), in which
+    case the old one stays alive beside the new."""
+    import torch
+    bufs = self.__dict__.setdefault("_mvsgi_head_bufs", {})
+    key = (D, Hh, W, C, device)
+    ent = bufs.get(key)
+    if ent is None or ent[0].B < B:
+        big = H.SplitAct(B, D, Hh, W, C, device)
+        keep = ent[1] + [ent[0]] if ent is not None and (ent[2] or ent[1]) else []      # graphs may hold the old buffers
+        ent = bufs[key] = [big, keep, False]
+    if torch.cuda.is_current_stream_capturing():
+        ent[2] = True
+    big = ent[0]
+    if big.B == B:
+        return big
+    return H.SplitAct(B, D, Hh, W, C, device, buf=big.buf[:B])
 
 
 def regulator_forward(self, x: Tensor) -> Tensor:

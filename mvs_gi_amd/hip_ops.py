@@ -14,31 +14,50 @@ from . import _lib
 import os
 
 CONV_AUTO, CONV_DIRECT, CONV_MFMA, CONV_BF16X3, CONV_BF16X3_C16, CONV_BF16X3_V32 = 0, 1, 2, 3, 4, 5
+CONV_F16 = 0x100       # flag OR-ed into CONV_BF16X3 / _C16 / _V32: the same kernel in the fp16 split (include/mvsgi.h MVSGI_CONV_F16)
 
-# Arithmetic of the conv layers: "bf16x3" (default) = split-bf16 MFMA (hi*hi + hi*lo + lo*hi, fp32
-# accumulate; ~2^-16 per product; inverse distance within 3e-4 of the reference on every golden case),
-# "f32" = exact fp32 MFMA (v_mfma_f32_16x16x4_f32; bit-for-bit an fp32 fmaf chain, ~3x slower).
+# Arithmetic of the conv layers:
+#   "bf16x3" (default) = split-bf16 MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate; 8 + 8 significant bits per operand, fp32's range);
+#   "f16x3"            = the same three products in the fp16 split (11 + 11 bits per operand, operands clamped to +-65504): inverse
+#                        distance ~10x closer to the reference on a sharp softmax, on the streaming kernels (the register-stationary
+#                        kernels of the (16, 32) regulator are bf16-split only);
+#   "f32"              = exact fp32 MFMA (v_mfma_f32_16x16x4_f32; bit-for-bit an fp32 fmaf chain, ~4x slower).
+CONV_MODES = ("f32", "bf16x3", "f16x3")
 _CONV_MODE = os.environ.get("MVSGI_CONV_MODE", "bf16x3")
-if _CONV_MODE not in ("f32", "bf16x3"):
-    raise ValueError(f"MVSGI_CONV_MODE={_CONV_MODE!r} not in ('f32', 'bf16x3')")
+if _CONV_MODE not in CONV_MODES:
+    raise ValueError(f"MVSGI_CONV_MODE={_CONV_MODE!r} not in {CONV_MODES}")
 
 
 def exp_env(name: str, default: str) -> str:
     """Experiment switches -- A/B knobs whose measurement is recorded in DESIGN.md / DESIGN_HISTORY.md as neutral or slower -- are
     read only when MVSGI_EXPERIMENTAL=1; the product configuration surface is MVSGI_CONV_MODE, MVSGI_RIG_CACHE, MVSGI_POLY,
     MVSGI_S2RS, MVSGI_HEAD_SPLIT, MVSGI_FRONT_CHUNK (each covered by tests/test_gpu_parity.py::test_product_switches_off) and MVSGI_LIB."""
-    return os.environ.get(name, default) if os.environ.get("MVSGI_EXPERIMENTAL") == "1" else default
+    if os.environ.get("MVSGI_EXPERIMENTAL") == "1":
+        return os.environ.get(name, default)
+    if name in os.environ and name not in _EXP_WARNED:      # a probe / A-B script that forgot the gate would measure the default twice
+        _EXP_WARNED.add(name)
+        import warnings
+        warnings.warn(f"{name} is an experiment switch: it is read only with MVSGI_EXPERIMENTAL=1 (ignored)", RuntimeWarning, stacklevel=2)
+    return default
+
+
+_EXP_WARNED = set()
 
 
 def set_conv_mode(mode: str) -> None:
     global _CONV_MODE
-    if mode not in ("f32", "bf16x3"):
-        raise ValueError(f"conv mode {mode!r} not in ('f32', 'bf16x3')")
+    if mode not in CONV_MODES:
+        raise ValueError(f"conv mode {mode!r} not in {CONV_MODES}")
     _CONV_MODE = mode
 
 
 def get_conv_mode() -> str:
     return _CONV_MODE
+
+
+def split_mode() -> bool:
+    """The library's mode is one of the two 16-bit splits (the streaming split kernels serve the layer)."""
+    return _CONV_MODE in ("bf16x3", "f16x3")
 
 
 def _stream_ptr(t: torch.Tensor) -> int:
@@ -265,6 +284,29 @@ def pack_conv_weights_bf16x3(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
     return wp
 
 
+def pack_conv_weights_f16x3(w_oidhw: torch.Tensor, layout: int = CONV_BF16X3):
+    """[Cout, Cin, 3, 3, 3] -> (packed weights of the fp16 split in `layout` (CONV_BF16X3 | _C16 | _V32), unscale [Cout]) or None.
+    Every output channel's weights are pre-scaled by a power of two so that its largest weight lies in [512, 1024) -- the lo parts
+    (2^-11 of the weight) are then normal fp16 numbers instead of subnormals with an absolute quantum of 2^-24; `unscale` = 2^-k
+    per channel goes into the epilogue's per-channel scale (exact: powers of two)."""
+    lib = _lib.load()
+    w = _dev(w_oidhw, "conv weight")
+    Cout, Cin = w.shape[:2]
+    if tuple(w.shape[2:]) != (3, 3, 3) or Cin % 16 or Cout % 16 or (layout == CONV_BF16X3_C16 and Cout != 16) or \
+            (layout == CONV_BF16X3_V32 and Cout % 32):
+        return None
+    amax = w.abs().amax(dim=(1, 2, 3, 4))
+    k = torch.where(amax > 0, torch.floor(torch.log2(1024.0 / amax.clamp_min(1e-37))), torch.zeros_like(amax)).clamp(-100.0, 100.0)
+    ws = (w * torch.exp2(k).view(-1, 1, 1, 1, 1)).contiguous()
+    n = {CONV_BF16X3: lambda: lib.mvsgi_conv3d_packed_weight_bytes_bf16x3(Cout, Cin),
+         CONV_BF16X3_C16: lambda: lib.mvsgi_conv3d_packed_weight_bytes_bf16x3_c16(Cin),
+         CONV_BF16X3_V32: lambda: lib.mvsgi_conv3d_packed_weight_bytes_bf16x3_v32(Cout, Cin)}[layout]()
+    wp = torch.empty(n, device=w.device, dtype=torch.uint8)
+    _lib.check(lib.mvsgi_conv3d_pack_weights_split(ws.data_ptr(), wp.data_ptr(), Cout, Cin, layout | CONV_F16, _stream_ptr(w)),
+               "mvsgi_conv3d_pack_weights_split")
+    return wp, torch.exp2(-k).contiguous()
+
+
 def conv3d_v32_applies(B, Cin, Din, Hin, Win, Cout, stride=1) -> bool:
     """Whether the 32x32x16-MFMA kernel (impl / w_layout CONV_BF16X3_V32) serves this problem
     (for conv3d_up2 pass the upsampled input size)."""
@@ -350,6 +392,7 @@ def conv3d_up2_out_split(x, w_packed_b3, scale, shift, out: "SplitAct", res=None
     _lib.check(lib.mvsgi_conv3d_up2_f32_out_split(x.data_ptr(), _ptr(w_packed_b3), w_layout, scale.data_ptr(), shift.data_ptr(), _ptr(res),
                                                   out.buf.data_ptr(), B, Cin, Dl, Hl, Wl, Cout, float(neg_slope), _stream_ptr(x)),
                "mvsgi_conv3d_up2_f32_out_split")
+    out.fmt = "f16" if w_layout & CONV_F16 else "bf16"
     return out
 
 
@@ -410,14 +453,34 @@ def pack_head_split_weights(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
     return wp
 
 
-def conv3d_head_split(x: "SplitAct", w_packed, scale: float, shift: float, neg_slope=1.0, out=None) -> torch.Tensor:
-    """Cost head (Cout = 1) on a split-padded input -> fp32 [B, D, H, W, 1] = act(conv(x) * scale + shift)."""
+def pack_head_split_weights_f16(w_oidhw: torch.Tensor):
+    """[1, Cin % 16 == 0, 3, 3, 3] -> (fragment layout of conv3d_head_split in the fp16 split, unscale) or None: the weights
+    pre-scaled by a power of two (largest in [512, 1024)), `unscale` its inverse for the head's scale."""
     lib = _lib.load()
+    w = _dev(w_oidhw, "conv weight")
+    if w.shape[0] != 1 or tuple(w.shape[2:]) != (3, 3, 3) or w.shape[1] % 16:
+        return None
+    amax = float(w.abs().max())
+    k = 0.0 if amax == 0.0 else float(torch.floor(torch.log2(torch.tensor(1024.0 / amax))))
+    ws = (w * (2.0 ** k)).contiguous()
+    wp = torch.empty(lib.mvsgi_conv3d_head_split_packed_weight_bytes(int(w.shape[1])), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.mvsgi_conv3d_head_split_pack_weights_f16(ws.data_ptr(), wp.data_ptr(), int(w.shape[1]), _stream_ptr(w)),
+               "mvsgi_conv3d_head_split_pack_weights_f16")
+    return wp, 2.0 ** -k
+
+
+def conv3d_head_split(x: "SplitAct", w_packed, scale: float, shift: float, neg_slope=1.0, out=None, f16: bool = False) -> torch.Tensor:
+    """Cost head (Cout = 1) on a split-padded input -> fp32 [B, D, H, W, 1] = act(conv(x) * scale + shift).  f16: input and weights
+    in the fp16 split."""
+    lib = _lib.load()
+    if x.fmt != ("f16" if f16 else "bf16"):
+        raise AssertionError(f"conv3d_head_split(f16={f16}) on a split-padded buffer holding {x.fmt} pieces")
     y = out if out is not None else torch.empty((x.B, x.D, x.H, x.W, 1), device=x.buf.device, dtype=torch.float32)
     if tuple(y.shape) != (x.B, x.D, x.H, x.W, 1) or not y.is_contiguous():
         raise AssertionError(f"head output {tuple(y.shape)} does not match {(x.B, x.D, x.H, x.W, 1)}")
-    _lib.check(lib.mvsgi_conv3d_head_split(x.buf.data_ptr(), w_packed.data_ptr(), float(scale), float(shift), y.data_ptr(), x.B, x.C,
-                                           x.D, x.H, x.W, float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_head_split")
+    fn = lib.mvsgi_conv3d_head_split_f16 if f16 else lib.mvsgi_conv3d_head_split
+    _lib.check(fn(x.buf.data_ptr(), w_packed.data_ptr(), float(scale), float(shift), y.data_ptr(), x.B, x.C,
+                  x.D, x.H, x.W, float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_head_split")
     return y
 
 
@@ -444,10 +507,11 @@ def conv3d_variant(B, Cin, Din, Hin, Win, Cout, stride=1, impl=CONV_AUTO) -> str
 # --------------------------------------------------------------------------------------
 class SplitAct:
     """A split-padded activation buffer plus its logical geometry (B, D, H, W, C)."""
-    __slots__ = ("buf", "B", "D", "H", "W", "C")
+    __slots__ = ("buf", "B", "D", "H", "W", "C", "fmt")
 
     def __init__(self, B, D, H, W, C, device, buf=None):
         self.B, self.D, self.H, self.W, self.C = int(B), int(D), int(H), int(W), int(C)
+        self.fmt = "bf16"          # element type of the (hi | lo) pieces: set by the kernel that writes the buffer, checked by its reader
         if buf is None:
             buf = torch.zeros((self.B, self.D + 2, self.H + 2, self.W + 2, self.C), device=device, dtype=torch.int32)
         self.buf = buf

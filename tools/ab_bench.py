@@ -9,6 +9,7 @@ res = {a: [] for a in arms}
 for r in range(rounds):
     for a in arms:
         env = dict(os.environ)
+        env["MVSGI_EXPERIMENTAL"] = "1"      # the arms may name gated experiment switches (mvs_gi_amd/hip_ops.py exp_env)
         for kv in a.split(","):
             k, v = kv.split("=")
             env[k] = v

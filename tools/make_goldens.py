@@ -87,6 +87,36 @@ def run_case(name, case, full):
     np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
 
 
+def run_ladder(name, case, stop_maxprob=0.995, max_steps=10):
+    """Gain ladder of a full-size case: from the case's last gain upwards in steps of x2 until the REFERENCE's softmax over the
+    candidates has a mean maximum probability >= `stop_maxprob` (an arg-max in all but name).  Stores the reference's inv_dist
+    per rung, the rung's gain and mean max-probability -> tests/golden/<name>_ladder.npz.  The tests locate the gain at which each
+    arithmetic of the HIP path crosses the 1e-3 bar on these rows (Precision modes)."""
+    cfg = case["cfg"]
+    inp = synth.make_inputs(cfg, seed=case["seed"], batch=case["batch"], grid_kind=case["grid_kind"],
+                            grid_mask_dtype=case["grid_mask_dtype"])
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    out = {"inputs_sha256": np.asarray(synth.digest(inp))}
+    gains, probs = [], []
+    gain = float(case["gains"][-1]) if case["gains"][-1] >= case["gains"][0] else float(case["gains"][0])
+    for _ in range(max_steps):
+        gain *= 2.0
+        w = synth.make_weights(cfg, seed=case["seed"], gain=gain)
+        cvb, reg, dr = build_reference(cfg, w)
+        with torch.no_grad():
+            inv, pr = dr(reg(cvb(t["feats"], t["grids"], t["grid_masks"], t["masks"])))
+        mp = float(pr.max(1)[0].mean())
+        out[f"inv_dist_g{gain:g}"] = inv.numpy()
+        gains.append(gain)
+        probs.append(mp)
+        print(f"  {name} ladder gain={gain:g}: mean max-prob {mp:.4f}", flush=True)
+        if mp >= stop_maxprob:
+            break
+    out["gains"] = np.asarray(gains, np.float64)
+    out["mean_maxprob"] = np.asarray(probs, np.float64)
+    np.savez_compressed(os.path.join(OUT, f"{name}_ladder.npz"), **out)
+
+
 def sweep_edges():
     """Hand-built sampler/sweep corner cases: grid exactly on +-1, beyond the image,
     on texel centres; 0, 1, 2 and 3 valid cameras; bool and float grid masks; B=2."""
@@ -265,3 +295,6 @@ if __name__ == "__main__":
     if "full" in which:
         for n, c in FULL_CASES.items():
             run_case(n, c, full=True)
+    if "ladder" in which:
+        for n, c in FULL_CASES.items():
+            run_ladder(n, c)

@@ -5,7 +5,9 @@ import numpy as np, torch
 import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvs_gi_amd import hip_ops as H
-from mvs_gi_amd.dropin import polyphase as P
+from mvs_gi_amd.dropin import polyphase as P  # noqa: F401
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import polyphase_ref as R  # noqa: E402
 
 DEV = "cuda:0"
 shape = tuple(int(v) for v in (sys.argv[1:5] if len(sys.argv) >= 5 else (1, 1, 1, 1)))
@@ -31,7 +33,7 @@ def run(pl):
     return y.cpu().numpy()
 
 full = run(plan)
-ref = P.reference_up2_conv(xq, wt).transpose(0, 2, 3, 4, 1)
+ref = R.reference_up2_conv(xq, wt).transpose(0, 2, 3, 4, 1)
 print("full vs reference: max abs err", np.abs(full - ref).max(), "max ref", np.abs(ref).max())
 p2 = plan.clone()
 p2[off_facew:off_roles] = 0
