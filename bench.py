@@ -306,15 +306,15 @@ class ConvProbe:
                                  2.0 * 27 * 32 * 16 * vox, s, e, 4.0 * (x.B * x.D * x.H * x.W * 32 + vox * 16)))
             return y
 
-        def probed_heads(x, w_packed, scale, shift, neg_slope=1.0, out=None):
+        def probed_heads(x, w_packed, scale, shift, neg_slope=1.0, out=None, f16=False):
             if not self.enabled:
-                return orig_heads(x, w_packed, scale, shift, neg_slope, out)
+                return orig_heads(x, w_packed, scale, shift, neg_slope, out, f16)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            y = orig_heads(x, w_packed, scale, shift, neg_slope, out)
+            y = orig_heads(x, w_packed, scale, shift, neg_slope, out, f16)
             e.record()
             vox = x.B * x.D * x.H * x.W
-            self.records.append(("conv3d_head_split_kernel", 2.0 * 27 * x.C * vox, s, e, 4.0 * vox * (x.C + 1)))
+            self.records.append(("conv3d_head_split_kernel<%s>" % ("true" if f16 else "false"), 2.0 * 27 * x.C * vox, s, e, 4.0 * vox * (x.C + 1)))
             return y
         H.conv3d_up2_poly_split, H.conv3d_head_split = probed_polys, probed_heads
         H.conv3d_up2_poly, H.conv3d_up2_out_split = probed_poly, probed_up2s
@@ -907,6 +907,9 @@ def main(argv=None):
                         m["mode_f16x3"] = {"frames_per_s": m16.get("graph_replay_frames_per_s", m16["frames_per_s"]),
                                            "parity": m16.get("parity"), "dominant_kernel": m16["dominant_kernel"],
                                            "dominant_tflops": m16["dominant_tflops"]}
+                    except Exception as e:
+                        m["mode_f16x3"] = {"error": f"{type(e).__name__}: {e}"}
+                        torch.cuda.synchronize(dev)
                     finally:
                         H.set_conv_mode(args.mode)
                 cfgs[tag] = m

@@ -278,7 +278,7 @@ def test_conv3d_f16x3_vs_oracle(shape):
     assert err <= 5e-6, err
     yb = H.conv3d(xg, wg, H.pack_conv_weights_bf16x3(wg), _g(scale), _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3)
     eb = _rel(_ncdhw(yb), yref)                          # ... and closer than the bf16 split on the same problem (a residual of
-    assert eb >= err and (res or eb > 4 * err), (eb, err)   # O(1) beside the x 0.01 convolution hides both splits behind the final add's rounding)
+    assert eb >= err and (res or eb > 1.5 * err), (eb, err)   # O(1) beside the x 0.01 convolution hides both splits behind the final add's rounding)
     if Cout == 16 and stride == 1:
         wpc, un = H.pack_conv_weights_f16x3(wg, H.CONV_BF16X3_C16)
         yp = H.conv3d(xg, wg, wpc, _g(scale) * un, _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3_C16 | H.CONV_F16)
