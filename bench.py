@@ -221,20 +221,20 @@ class ConvProbe:
             y = self.orig_rs(x, w_packed_rs, scale, shift, res, neg_slope, out, out_f32)
             e.record()
             nv = x.B * x.D * x.H * x.W
-            self.records.append(("conv3d_rs32_kernel<%d>" % (1 if out_f32 else 0),
+            self.records.append(("conv3d_rs32_kernel<%d%s>" % (1 if out_f32 else 0, ", true" if x.fmt == "f16" else ", false"),
                                  2.0 * 27 * x.C * scale.numel() * nv, s, e, 4.0 * nv * (x.C + scale.numel() * (2 if res is not None else 1))))
             return y
 
-        def probed_os(x, w_packed_b3, scale, shift, out, res=None, stride=1, neg_slope=0.01):
+        def probed_os(x, w_packed_b3, scale, shift, out, res=None, stride=1, neg_slope=0.01, fmt="bf16"):
             if not self.enabled:
-                return self.orig_os(x, w_packed_b3, scale, shift, out, res, stride, neg_slope)
+                return self.orig_os(x, w_packed_b3, scale, shift, out, res, stride, neg_slope, fmt)
             B, D, Hh, W, Cin = x.shape
             Cout = scale.numel()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            y = self.orig_os(x, w_packed_b3, scale, shift, out, res, stride, neg_slope)
+            y = self.orig_os(x, w_packed_b3, scale, shift, out, res, stride, neg_slope, fmt)
             e.record()
-            self.records.append((self._tag(H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3) + " [split-padded out]", Cin, Cout, D, Hh, W, stride),
+            self.records.append((self._tag(H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3 | (H.CONV_F16 if fmt == "f16" else 0)) + " [split-padded out]", Cin, Cout, D, Hh, W, stride),
                                  2.0 * 27 * Cin * Cout * out.B * out.D * out.H * out.W, s, e,
                                  4.0 * (x.numel() + out.B * out.D * out.H * out.W * Cout * (2 if res is not None else 1))))
             return y
@@ -246,21 +246,21 @@ class ConvProbe:
             s.record()
             y = self.orig_rs16(x, w_packed_rs, scale, shift, neg_slope, out, out_split)
             e.record()
-            self.records.append(("conv3d_rs16_kernel<%s>" % ("true" if out_split is not None else "false"),
+            self.records.append(("conv3d_rs16_kernel<%s%s>" % ("true" if out_split is not None else "false", ", true" if x.fmt == "f16" else ", false"),
                                  2.0 * 27 * 16 * 16 * x.B * x.D * x.H * x.W, s, e, 4.0 * 32 * x.B * x.D * x.H * x.W))
             return y
 
         self.orig_s2rs = H.conv3d_s2rs
 
-        def probed_s2rs(x, w_packed, shift, out, neg_slope=0.01):
+        def probed_s2rs(x, w_packed, shift, out, neg_slope=0.01, unscale=1.0):
             if not self.enabled:
-                return self.orig_s2rs(x, w_packed, shift, out, neg_slope)
+                return self.orig_s2rs(x, w_packed, shift, out, neg_slope, unscale)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            y = self.orig_s2rs(x, w_packed, shift, out, neg_slope)
+            y = self.orig_s2rs(x, w_packed, shift, out, neg_slope, unscale)
             e.record()
             nvo = out.B * out.D * out.H * out.W
-            self.records.append(("conv3d_s2rs_kernel<4, 2>", 2.0 * 27 * 16 * 32 * nvo, s, e, 4.0 * (16 * x.B * x.D * x.H * x.W + 32 * nvo)))
+            self.records.append(("conv3d_s2rs_kernel<4, 2%s>" % (", true" if x.fmt == "f16" else ", false"), 2.0 * 27 * 16 * 32 * nvo, s, e, 4.0 * (16 * x.B * x.D * x.H * x.W + 32 * nvo)))
             return y
 
         orig_poly, orig_up2s = H.conv3d_up2_poly, H.conv3d_up2_out_split
@@ -274,7 +274,7 @@ class ConvProbe:
             y = orig_poly(x, plan, scale, shift, neg_slope, out)
             e.record()
             vox = y.numel() // 16
-            self.records.append(("conv3d_rs32_kernel<2> + up2_face_kernel + up2_edge_kernel (polyphase out_costs.0)",
+            self.records.append(("conv3d_rs32_kernel<2%s> + up2_face_kernel + up2_edge_kernel (polyphase out_costs.0)" % (", true" if x.fmt == "f16" else ", false"),
                                  2.0 * 27 * 32 * 16 * vox, s, e, 4.0 * (x.B * x.D * x.H * x.W * 32 + y.numel())))
             return y
 
@@ -302,7 +302,7 @@ class ConvProbe:
             y = orig_polys(x, plan, scale, shift, out, neg_slope)
             e.record()
             vox = out.B * out.D * out.H * out.W
-            self.records.append(("conv3d_rs32_kernel<3> + up2_face_kernel + up2_edge_kernel (polyphase out_costs.0, split-padded out)",
+            self.records.append(("conv3d_rs32_kernel<3%s> + up2_face_kernel + up2_edge_kernel (polyphase out_costs.0, split-padded out)" % (", true" if x.fmt == "f16" else ", false"),
                                  2.0 * 27 * 32 * 16 * vox, s, e, 4.0 * (x.B * x.D * x.H * x.W * 32 + vox * 16)))
             return y
 
@@ -440,7 +440,9 @@ def read_pmc_traffic(kernel_name: str):
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         d = json.load(open(p))
-        v = d.get(kernel_name.split(" [")[0], {}).get("hbm_bytes_per_launch")
+        key = kernel_name.split(" [")[0]
+        # (summaries written before the kernels carried their split as a template argument name them without the trailing ", false")
+        v = (d.get(key) or d.get(key.replace(", false>", ">")) or {}).get("hbm_bytes_per_launch")
         return v, (f"profiles/pmc_traffic.json ({d.get('_source', 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE')})"
                    if v is not None else None)
     except Exception:

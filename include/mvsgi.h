@@ -62,6 +62,9 @@ typedef void* mvsgi_stream_t;
                                   output channel's weights by a power of two (undone in `scale`) so that their lo parts are
                                   normal fp16 numbers                                                                    */
 
+#define MVSGI_SPLIT_F16 1      /* `fmt` of the *_fmt entry points: split-padded activations / packed weights hold fp16 pairs (the
+                                  "f16x3" arithmetic, see MVSGI_CONV_F16) instead of bf16 pairs (fmt 0)                     */
+
 int         mvsgi_abi_version(void);
 const char* mvsgi_last_error(void);
 
@@ -367,6 +370,36 @@ size_t mvsgi_conv3d_up2_poly_plan_bytes(int D, int H, int W);
 int mvsgi_conv3d_up2_poly_plan(const float* w_oidhw_host, void* plan_host, int D, int H, int W);
 int mvsgi_conv3d_up2_poly_f32(const void* x_split, const void* plan_dev, const float* scale, const float* shift, float* y,
                               int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream);
+
+/* ---- the split-padded kernels in either 16-bit split (round 5) ---------------------------------------------------
+ * The *_fmt forms of the entry points above: fmt = 0 runs the bf16 split (identical to the un-suffixed function), fmt =
+ * MVSGI_SPLIT_F16 the fp16 split -- every split-padded tensor the call reads or writes, its packed weights and its residual then
+ * hold fp16 pairs (x = hi + lo, 11 + 11 significant bits, values clamped to +-65504), and the products run on
+ * v_mfma_f32_16x16x32_f16.  Weights of an fp16 call are pre-scaled by the caller with a power of two per output channel and its
+ * inverse folded into `scale` (MVSGI_CONV_F16 above); mvsgi_conv3d_s2rs_fmt, whose epilogue has no per-channel multiplier, takes
+ * one power of two for the layer (`unscale`, with `scale` at packing and `shift` multiplied by 1 / unscale).  Same reference ops
+ * as the un-suffixed functions (BaseConvBlk3d / ResizeConv3d forward, common/common_modules.py:107-115, 332-355;
+ * SphericalSweepStdMasked.sweep, cost_volume_builder/spherical_sweep_avg.py:38-136). */
+int mvsgi_act_f32_to_split_fmt(const float* x, void* y_split, int B, int C, int D, int H, int W, int fmt, mvsgi_stream_t stream);
+int mvsgi_act_split_to_f32_fmt(const void* x_split, float* y, int B, int C, int D, int H, int W, int fmt, mvsgi_stream_t stream);
+int mvsgi_sweep_std_nhwc_valid_split_fmt(const float* feats, const float* grids, const unsigned char* vmask, void* vol_split,
+                                         int B, int N, int C, int Hi, int Wi, int D, int Ho, int Wo, int rig_batch, int fmt,
+                                         mvsgi_stream_t stream);
+int mvsgi_conv3d_f32_out_split_fmt(const float* x, const float* w_packed_b3, const float* scale, const float* shift,
+                                   const float* res, void* y_split, int B, int Cin, int Din, int Hin, int Win, int Cout,
+                                   int stride, float neg_slope, int fmt, mvsgi_stream_t stream);
+int mvsgi_conv3d_rs_pack_weights_fmt(const float* w_oidhw, void* w_packed, int Cout, int Cin, int fmt, mvsgi_stream_t stream);
+int mvsgi_conv3d_rs_split_fmt(const void* x_split, const void* w_packed_rs, const float* scale, const float* shift,
+                              const void* res_split, void* y, int y_is_f32, int B, int Cin, int D, int H, int W, int Cout,
+                              float neg_slope, int fmt, mvsgi_stream_t stream);
+int mvsgi_conv3d_rs16_split_fmt(const void* x_split, const void* w_packed_rs, const float* scale, const float* shift, void* y,
+                                int y_is_split, int B, int D, int H, int W, float neg_slope, int fmt, mvsgi_stream_t stream);
+int mvsgi_conv3d_s2rs_pack_weights_fmt(const float* w_oidhw, const float* scale, void* w_packed, int fmt, mvsgi_stream_t stream);
+int mvsgi_conv3d_s2rs_fmt(const void* x_split, const void* w_packed, const float* shift, void* y_split, int B, int D, int H, int W,
+                          float neg_slope, float unscale, int fmt, mvsgi_stream_t stream);
+int mvsgi_conv3d_up2_poly_plan_fmt(const float* w_oidhw_host, void* plan_host, int D, int H, int W, int fmt);
+int mvsgi_conv3d_up2_poly_fmt(const void* x_split, const void* plan_dev, const float* scale, const float* shift, void* y,
+                              int y_is_split, int B, int D, int H, int W, float neg_slope, int fmt, mvsgi_stream_t stream);
 
 #ifdef __cplusplus
 }

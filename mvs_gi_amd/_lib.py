@@ -95,6 +95,17 @@ SIGNATURES = {
     "mvsgi_conv3d_up2_poly_plan_bytes": (c_size_t, [c_int] * 3),
     "mvsgi_conv3d_up2_poly_plan": (c_int, [_P, _P] + [c_int] * 3),
     "mvsgi_conv3d_up2_poly_f32": (c_int, [_P] * 5 + [c_int] * 4 + [c_float, _P]),
+    "mvsgi_act_f32_to_split_fmt": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
+    "mvsgi_act_split_to_f32_fmt": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
+    "mvsgi_sweep_std_nhwc_valid_split_fmt": (c_int, [_P, _P, _P, _P] + [c_int] * 10 + [_P]),
+    "mvsgi_conv3d_f32_out_split_fmt": (c_int, [_P] * 6 + [c_int] * 7 + [c_float, c_int, _P]),
+    "mvsgi_conv3d_rs_pack_weights_fmt": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "mvsgi_conv3d_rs_split_fmt": (c_int, [_P] * 6 + [c_int] * 7 + [c_float, c_int, _P]),
+    "mvsgi_conv3d_rs16_split_fmt": (c_int, [_P] * 5 + [c_int] * 5 + [c_float, c_int, _P]),
+    "mvsgi_conv3d_s2rs_pack_weights_fmt": (c_int, [_P, _P, _P, c_int, _P]),
+    "mvsgi_conv3d_s2rs_fmt": (c_int, [_P] * 4 + [c_int] * 4 + [c_float, c_float, c_int, _P]),
+    "mvsgi_conv3d_up2_poly_plan_fmt": (c_int, [_P, _P] + [c_int] * 4),
+    "mvsgi_conv3d_up2_poly_fmt": (c_int, [_P] * 5 + [c_int] * 5 + [c_float, c_int, _P]),
     "mvsgi_ncv_to_nvc_f32": (c_int, [_P, _P, c_int, c_int, c_longlong, _P]),
     "mvsgi_nvc_to_ncv_f32": (c_int, [_P, _P, c_int, c_int, c_longlong, _P]),
 }

@@ -96,8 +96,8 @@ inline int device_cus() {
 
 // csrc/conv3d_rs.hip: the 32 -> 32 register-stationary kernel as the body of the polyphase ResizeConv3d (csrc/conv3d_up2poly.hip)
 constexpr size_t kRs32PackedBytes = (size_t)2 * 2 * 14 * 2 * 64 * 16;      // one weight set in the kernel's lane order
-void rs32_pack_weights_host(const float* w_oidhw_32x32x27, void* packed);
+void rs32_pack_weights_host(const float* w_oidhw_32x32x27, void* packed, bool f16);
 int rs32_up2_launch(const void* x_split, const void* w_sets, const float* scale32, const float* shift32, void* y, int y_is_split,
-                    int B, int D, int H, int W, float neg_slope, hipStream_t st);
+                    int B, int D, int H, int W, float neg_slope, bool f16, hipStream_t st);
 
 }  // namespace mvsgi

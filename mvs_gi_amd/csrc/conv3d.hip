@@ -327,6 +327,7 @@ const char* const kVariantNames[] = {
     "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, true, false, false, false>", "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, true, false, false, false>",
     "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, false, true, false, false>", "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, true, true, false, false>",
     "conv3d_bf16x3_kernel<1, 2, 4, 1, 4, 4, 16, 1, 3, false, false, true, false>", "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 16, 1, 3, false, false, true, false>",
+    "conv3d_bf16x3_kernel<1, 4, 2, 2, 4, 4, 16, 1, 3, false, false, true, false>",
     "conv3d_bf16x3_kernel<1, 2, 4, 1, 4, 4, 16, 1, 3, true, false, true, false>", "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 16, 1, 3, true, false, true, false>",
 };
 static_assert(sizeof(kVariantNames) / sizeof(kVariantNames[0]) == V_COUNT, "one name per variant");
@@ -386,6 +387,7 @@ int select_variant(const ConvArgs& a, int impl) {
             return V_COUNT;
         }
         if (!a.wp) { mvsgi::fail("mvsgi_conv3d_f32: tiled path needs w_packed"); return V_COUNT; }
+        if (a.Cout != 32 && mvsgi::exp_env("MVSGI_V32B")) return B3V_N64B;      // 128-voxel waves (experimental builds)
         return a.Cout == 32 ? B3V_N32 : B3V_N64;
     }
     if (impl == MVSGI_CONV_BF16X3 && !mfma_ok) impl = MVSGI_CONV_AUTO;   // head / odd channels: exact paths
@@ -666,9 +668,10 @@ extern "C" int mvsgi_conv3d_f32(const float* x, const float* w_oidhw, const floa
 
 // the same block with the output in the split-padded format of conv3d_rs.hip (y_split zero-bordered, interior written):
 // the hand-over from a streaming split-bf16 layer to the register-stationary layers
-extern "C" int mvsgi_conv3d_f32_out_split(const float* x, const float* w_packed_b3, const float* scale, const float* shift,
-                                          const float* res, void* y_split, int B, int Cin, int Din, int Hin, int Win, int Cout,
-                                          int stride, float neg_slope, mvsgi_stream_t stream) {
+extern "C" int mvsgi_conv3d_f32_out_split_fmt(const float* x, const float* w_packed_b3, const float* scale, const float* shift,
+                                              const float* res, void* y_split, int B, int Cin, int Din, int Hin, int Win, int Cout,
+                                              int stride, float neg_slope, int fmt, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(fmt == 0 || fmt == MVSGI_SPLIT_F16, "mvsgi_conv3d_f32_out_split: fmt %d not in {0, MVSGI_SPLIT_F16}", fmt);
     MVSGI_REQUIRE(x && y_split && scale && shift && w_packed_b3, "mvsgi_conv3d_f32_out_split: null pointer");
     MVSGI_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0, "mvsgi_conv3d_f32_out_split: Cin, Cout must be multiples of 16");
     ConvArgs a{};
@@ -676,9 +679,15 @@ extern "C" int mvsgi_conv3d_f32_out_split(const float* x, const float* w_packed_
                   stride, neg_slope))
         return 1;
     a.y_split = static_cast<unsigned char*>(y_split);
+    a.f16 = fmt != 0;      // weights (w_packed_b3 packed with MVSGI_CONV_F16) and the split-padded output in the fp16 split
     const int v = select_variant(a, MVSGI_CONV_BF16X3);
     if (v == V_COUNT) return 1;
     return launch_variant(v, a, mvsgi::as_stream(stream));
+}
+extern "C" int mvsgi_conv3d_f32_out_split(const float* x, const float* w_packed_b3, const float* scale, const float* shift,
+                                          const float* res, void* y_split, int B, int Cin, int Din, int Hin, int Win, int Cout,
+                                          int stride, float neg_slope, mvsgi_stream_t stream) {
+    return mvsgi_conv3d_f32_out_split_fmt(x, w_packed_b3, scale, shift, res, y_split, B, Cin, Din, Hin, Win, Cout, stride, neg_slope, 0, stream);
 }
 
 extern "C" const char* mvsgi_conv3d_variant_f32(int B, int Cin, int Din, int Hin, int Win, int Cout, int stride,

@@ -696,7 +696,9 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
         // register buffers: 27 taps = 3 x 9 = 9 x 3, so buffer indices are compile-time constants.  Weight
         // fragments come from L2 (~1 k cycles under load): requested LAW taps (LAW x 192 cycles) ahead;
         // activation fragments come from LDS: 2 taps ahead.
-        constexpr int VB = 3, VWB = 9, LAW = NW == 1 ? 6 : 4;
+        // activation fragments run XA taps ahead in VB rotating buffers: two ahead in three for the 64-voxel waves; ONE ahead in two
+        // for the 128-voxel waves (MW == 4: half the weight fragments per MFMA, 64 accumulator + 64 fragment registers)
+        constexpr int VB = MW >= 4 ? 2 : 3, XA = VB - 1, VWB = MW >= 4 ? 6 : 9, LAW = MW >= 4 ? 5 : NW == 1 ? 6 : 4;
         bf16x8 wh[VWB][NW], wl[VWB][NW], xh[VB][MW], xl[VB][MW];
         f32x16 acc[MW][NW];
 #pragma unroll
@@ -769,10 +771,10 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
                 }
             }
             MVSGI_V_READX(0, 0)
-            MVSGI_V_READX(1, 1)
+            if (XA == 2) { MVSGI_V_READX(1, 1) }
 #pragma unroll
             for (int t_ = 0; t_ < 27; ++t_) {
-                const int cur = t_ % VB, nx2 = (t_ + 2) % VB, wcur = t_ % VWB;
+                const int cur = t_ % VB, nx2 = (t_ + XA) % VB, wcur = t_ % VWB;
                 unsigned l16 = lane16;
                 asm volatile("" : "+v"(l16));
                 if (t_ + LAW < 27) {
@@ -780,7 +782,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
                 } else {
                     MVSGI_V_LOADW((t_ + LAW - 27) % VWB, ncc, t_ + LAW - 27, ctn)    // first taps of the next unit (unconditional)
                 }
-                if (t_ + 2 < 27) { MVSGI_V_READX(nx2, t_ + 2) }
+                if (t_ + XA < 27) { MVSGI_V_READX(nx2, t_ + XA) }
                 if (t_ == 26 && last && a.res) {
                     const float* rb = a.res + (long long)b_ * frame_elems;
 #pragma unroll
@@ -792,7 +794,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
                                 rres[i][j][g] = *reinterpret_cast<const f32x4*>(rb + (eoff[i] >= 0 ? eoff[i] + ctc[j] * 32 + 8 * g : 0));
                 }
                 MVSGI_V_MFMAS(wcur, cur)
-                if (t_ + 2 < 27) {
+                if (t_ + XA < 27) {
                     constexpr int NMEM = 2 * NW + 2 * MW, NMFMA = 3 * MW * NW;
                     constexpr int RATIO = NMFMA / NMEM > 0 ? NMFMA / NMEM : 1;
 #pragma unroll

@@ -50,31 +50,14 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
-// x = hi + lo for four fp32 values, packed two bf16 per dword (same arithmetic as conv3d_bf16x3.hpp)
-__device__ __forceinline__ void split4(const f32x4 x, u32x2& hi, u32x2& lo) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const f32x2v v = {x[2 * p], x[2 * p + 1]};
-        const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-        const f32x2v hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
-        hi[p] = hb;
-        lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, bf16x2));
-    }
-}
-__device__ __forceinline__ f32x4 join4(const u32x2 hi, const u32x2 lo) {
-    f32x4 r;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        r[2 * p] = __builtin_bit_cast(float, hi[p] << 16) + __builtin_bit_cast(float, lo[p] << 16);
-        r[2 * p + 1] = __builtin_bit_cast(float, hi[p] & 0xffff0000u) + __builtin_bit_cast(float, lo[p] & 0xffff0000u);
-    }
-    return r;
-}
+#include "split_fmt.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // format conversion (module boundaries, tests): fp32 NDHWC <-> split-padded.  One thread per (voxel, 8 channels).
 // ---------------------------------------------------------------------------------------------
+template <bool F16>
 __global__ void f32_to_split_kernel(const float* __restrict__ x, unsigned char* __restrict__ y, int B, int C, int D, int H,
                                     int W) {
     const long long n = (long long)B * D * H * W * (C / 8);
@@ -91,14 +74,15 @@ __global__ void f32_to_split_kernel(const float* __restrict__ x, unsigned char* 
     const float* src = x + ((((long long)b * D + d) * H + h) * W + w) * C + g * 8;
     const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
     u32x2 h0, l0, h1, l1;
-    split4(a0, h0, l0);
-    split4(a1, h1, l1);
+    sf_split4<F16>(a0, h0, l0);
+    sf_split4<F16>(a1, h1, l1);
     unsigned char* dst = y + ((((long long)b * (D + 2) + d + 1) * (H + 2) + h + 1) * (W + 2) + w + 1) * (C * 4) +
                          (g >> 1) * 64 + (g & 1) * 16;
     *reinterpret_cast<u32x4*>(dst) = u32x4{h0[0], h0[1], h1[0], h1[1]};
     *reinterpret_cast<u32x4*>(dst + 32) = u32x4{l0[0], l0[1], l1[0], l1[1]};
 }
 
+template <bool F16>
 __global__ void split_to_f32_kernel(const unsigned char* __restrict__ x, float* __restrict__ y, int B, int C, int D, int H,
                                     int W) {
     const long long n = (long long)B * D * H * W * (C / 8);
@@ -116,8 +100,8 @@ __global__ void split_to_f32_kernel(const unsigned char* __restrict__ x, float* 
                                (g >> 1) * 64 + (g & 1) * 16;
     const u32x4 hi = *reinterpret_cast<const u32x4*>(src), lo = *reinterpret_cast<const u32x4*>(src + 32);
     float* dst = y + ((((long long)b * D + d) * H + h) * W + w) * C + g * 8;
-    *reinterpret_cast<f32x4*>(dst) = join4(u32x2{hi[0], hi[1]}, u32x2{lo[0], lo[1]});
-    *reinterpret_cast<f32x4*>(dst + 4) = join4(u32x2{hi[2], hi[3]}, u32x2{lo[2], lo[3]});
+    *reinterpret_cast<f32x4*>(dst) = sf_join4<F16>(u32x2{hi[0], hi[1]}, u32x2{lo[0], lo[1]});
+    *reinterpret_cast<f32x4*>(dst + 4) = sf_join4<F16>(u32x2{hi[2], hi[3]}, u32x2{lo[2], lo[3]});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -174,7 +158,7 @@ __host__ __device__ constexpr int pair_kw(int p, int which) { return p < 9 ? whi
 
 // [Cout 32][Cin 32][27] -> [slice 2][cout tile 2][14 pairs][hi|lo][64 lanes][8 bf16]
 //   lane = (kg << 4) | i holds W[cout = ct*16 + i][cin = slice*16 + (kg>>1)*8 + j][tap of pair p selected by kg & 1]
-__global__ void rs_pack_weights_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp) {
+__global__ void rs_pack_weights_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, bool f16) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= 2 * 2 * rs::kPairs * 64) return;
     const int lane = idx & 63;
@@ -184,16 +168,17 @@ __global__ void rs_pack_weights_kernel(const float* __restrict__ w, bf16x8* __re
     const int ct = r & 1, sl = r >> 1;
     const int kg = lane >> 4, co = ct * 16 + (lane & 15), ci = sl * 16 + (kg >> 1) * 8;
     const int k = rs::pair_k(p, kg & 1), kw = rs::pair_kw(p, kg & 1);
-    bf16x8 hi, lo;
+    u16x8 hi, lo;
     for (int j = 0; j < 8; ++j) {
         const float v = k >= 0 ? w[((long long)co * 32 + ci + j) * 27 + k * 3 + kw] : 0.f;
-        const __bf16 h = (__bf16)v;
-        hi[j] = h;
-        lo[j] = (__bf16)(v - (float)h);
+        unsigned short h_, l_;
+        sf_split_weight(v, f16, h_, l_);
+        hi[j] = h_;
+        lo[j] = l_;
     }
     const int o = (((sl * 2 + ct) * rs::kPairs + p) * 2) * 64 + lane;
-    wp[o] = hi;
-    wp[o + 64] = lo;
+    wp[o] = __builtin_bit_cast(bf16x8, hi);
+    wp[o + 64] = __builtin_bit_cast(bf16x8, lo);
 }
 
 struct RsUnit {      // coordinates of a brick (wave-uniform)
@@ -216,7 +201,8 @@ struct RsUnit {      // coordinates of a brick (wave-uniform)
 //   need other centre taps along that axis: their difference arrives as a raw (pre-scale) correction that
 //   csrc/conv3d_up2face.hip has written into the output voxels beforehand; the epilogue reads it back (masked to face cells)
 //   where the other modes read the residual.
-template <int MODE>
+// F16: activations, weights and the residual in the fp16 split (csrc/split_fmt.hpp) -- the same schedule, v_mfma_f32_16x16x32_f16
+template <int MODE, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     using namespace rs;
     constexpr bool OUTF32 = MODE == 1 || MODE == 2;
@@ -399,11 +385,23 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 // ("a"): hipcc keeps A/B operands of the builtin form in VGPRs and would shuttle the 224 weight registers through
 // v_accvgpr_read every brick.  hipcc pads no hazards around asm: the schedule keeps >= 3 MFMAs between an accumulator's
 // last MFMA and its first read, and nothing else reads or writes MFMA operands.
-#define RS_MF(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "a"(WREG), "v"(XREG));
+#define RS_MF(ACC, WREG, XREG)                                                                                         \
+    if constexpr (F16) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }  \
+    else { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }
 // first MFMA of a brick on an accumulator: C = 0.  Declared read-write all the same ("+a"): a fresh definition would let the
 // allocator move the accumulator to other registers and reconcile with v_accvgpr_mov at the loop's back edge -- directly in
 // front of asm MFMAs whose hazards it cannot pad
-#define RS_MF0(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG));
+#define RS_MF0(ACC, WREG, XREG)                                                                                        \
+    if constexpr (F16) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }   \
+    else { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }
+// the split's conversions inside the generated schedules (tools/gen_rs*_schedule.py); RS_LRELU_MAX is LeakyReLU's max and, in the
+// fp16 split on a split output, also the upper end of the range clamp (one v_med3_f32 instead of the v_max_f32)
+#define RS_W_LO(U) sf_widen_lo<F16>(U)
+#define RS_W_HI(U) sf_widen_hi<F16>(U)
+#define RS_CVT_PK(A, B) sf_cvt_pk<F16>(A, B)
+#define RS_F_F16(...) if constexpr (F16) { __VA_ARGS__ }
+#define RS_CLAMP_LO(T) __builtin_fmaxf(T, -kF16Max)
+#define RS_LRELU_MAX(T, U) ((F16 && !OUTF32) ? __builtin_amdgcn_fmed3f(T, U, kF16Max) : __builtin_fmaxf(T, U))
 
 // diagnostic builds only: MVSGI_RS_ABL bit 1 drops the fragment reads, 2 the epilogue, 4 the LDS-DMA (results are wrong)
 #ifndef MVSGI_RS_ABL
@@ -536,6 +534,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 #undef STAMP
 #undef RS_MF
 #undef RS_MF0
+#undef RS_W_LO
+#undef RS_W_HI
+#undef RS_CVT_PK
+#undef RS_F_F16
+#undef RS_CLAMP_LO
+#undef RS_LRELU_MAX
 #undef RS_DMA
 #undef RS_DESC
 #undef RS_DESC_OUT
@@ -581,28 +585,29 @@ __host__ __device__ constexpr int pair_kw(int pp, int second) { return pp < 3 ? 
 }  // namespace rs16
 
 // [16][16][27] -> [5 pairs][3 kd][hi|lo][64 lanes][8 bf16]: lane (kg << 4) | i holds W[cout i][cin (kg>>1)*8 + j][kd][in-plane tap]
-__global__ void rs16_pack_weights_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp) {
+__global__ void rs16_pack_weights_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, bool f16) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= 5 * 3 * 64) return;
     const int lane = idx & 63, r = idx >> 6;
     const int kd = r % 3, pp = r / 3;
     const int kg = lane >> 4, co = lane & 15, ci = (kg >> 1) * 8;
     const int kh = rs16::pair_kh(pp, kg & 1), kw = rs16::pair_kw(pp, kg & 1);
-    bf16x8 hi, lo;
+    u16x8 hi, lo;
     for (int j = 0; j < 8; ++j) {
         const float v = kh >= 0 ? w[((long long)co * 16 + ci + j) * 27 + kd * 9 + kh * 3 + kw] : 0.f;
-        const __bf16 h = (__bf16)v;
-        hi[j] = h;
-        lo[j] = (__bf16)(v - (float)h);
+        unsigned short h_, l_;
+        sf_split_weight(v, f16, h_, l_);
+        hi[j] = h_;
+        lo[j] = l_;
     }
     const int o = ((pp * 3 + kd) * 2) * 64 + lane;
-    wp[o] = hi;
-    wp[o + 64] = lo;
+    wp[o] = __builtin_bit_cast(bf16x8, hi);
+    wp[o + 64] = __builtin_bit_cast(bf16x8, lo);
 }
 
 // OSPLIT: the output goes to a split-padded tensor of the input's geometry (the hand-over to csrc/conv3d_s2rs.hip, which stages
 // pre-split voxels by LDS-DMA) instead of plain fp32 channels-last.
-template <bool OSPLIT>
+template <bool OSPLIT, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
     using namespace rs16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -717,11 +722,23 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
         _Pragma("unroll") for (int o = 0; o < 4; ++o)                                                            \
             voy[o] = (hok_ & (int)(c1.od * TD + o < a.D) & (int)(c1.ow * TW + col < a.W)) ? voy0[o] : 0xffffff00u; \
     }
-#define RS_MF(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "a"(WREG), "v"(XREG));
+#define RS_MF(ACC, WREG, XREG)                                                                                         \
+    if constexpr (F16) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }  \
+    else { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }
 // first MFMA of a brick on an accumulator: C = 0.  Declared read-write all the same ("+a"): a fresh definition would let the
 // allocator move the accumulator to other registers and reconcile with v_accvgpr_mov at the loop's back edge -- directly in
 // front of asm MFMAs whose hazards it cannot pad
-#define RS_MF0(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG));
+#define RS_MF0(ACC, WREG, XREG)                                                                                        \
+    if constexpr (F16) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }   \
+    else { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }
+// the split's conversions inside the generated schedules (tools/gen_rs*_schedule.py); RS_LRELU_MAX is LeakyReLU's max and, in the
+// fp16 split on a split output, also the upper end of the range clamp (one v_med3_f32 instead of the v_max_f32)
+#define RS_W_LO(U) sf_widen_lo<F16>(U)
+#define RS_W_HI(U) sf_widen_hi<F16>(U)
+#define RS_CVT_PK(A, B) sf_cvt_pk<F16>(A, B)
+#define RS_F_F16(...) if constexpr (F16) { __VA_ARGS__ }
+#define RS_CLAMP_LO(T) __builtin_fmaxf(T, -kF16Max)
+#define RS_LRELU_MAX(T, U) ((F16 && OSPLIT) ? __builtin_amdgcn_fmed3f(T, U, kF16Max) : __builtin_fmaxf(T, U))
 #define RS_PIN_V(V) asm volatile("" : "+v"(V));
 #define RS_F_STORE16(V, D, O) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, V), D, O, 0, MVSGI_RS16_NT);
 #define RS16_F_SPL(...) if constexpr (OSPLIT) { __VA_ARGS__ }
@@ -777,6 +794,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
 #undef RS16_VOY
 #undef RS_MF
 #undef RS_MF0
+#undef RS_W_LO
+#undef RS_W_HI
+#undef RS_CVT_PK
+#undef RS_F_F16
+#undef RS_CLAMP_LO
+#undef RS_LRELU_MAX
 #undef RS_PIN_V
 #undef RS_F_STORE16
 #undef RS16_F_SPL
@@ -789,24 +812,41 @@ extern "C" size_t mvsgi_act_split_bytes(int B, int C, int D, int H, int W) {
     return (size_t)B * (D + 2) * (H + 2) * (W + 2) * (size_t)C * 4;
 }
 
-extern "C" int mvsgi_act_f32_to_split(const float* x, void* y, int B, int C, int D, int H, int W, mvsgi_stream_t stream) {
+// fmt: 0 = the bf16 split, MVSGI_SPLIT_F16 = the fp16 split (csrc/split_fmt.hpp)
+extern "C" int mvsgi_act_f32_to_split_fmt(const float* x, void* y, int B, int C, int D, int H, int W, int fmt, mvsgi_stream_t stream) {
     MVSGI_REQUIRE(x && y, "mvsgi_act_f32_to_split: null pointer");
     MVSGI_REQUIRE(B > 0 && C > 0 && C % 16 == 0 && D > 0 && H > 0 && W > 0, "mvsgi_act_f32_to_split: bad dims (C %% 16 == 0)");
+    MVSGI_REQUIRE(fmt == 0 || fmt == MVSGI_SPLIT_F16, "mvsgi_act_f32_to_split: fmt %d not in {0, MVSGI_SPLIT_F16}", fmt);
     const long long n = (long long)B * D * H * W * (C / 8);
     MVSGI_REQUIRE(mvsgi::cdiv(n, 256) < (1ll << 31), "mvsgi_act_f32_to_split: tensor too large");
-    hipLaunchKernelGGL(f32_to_split_kernel, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, mvsgi::as_stream(stream), x,
-                       static_cast<unsigned char*>(y), B, C, D, H, W);
+    if (fmt)
+        hipLaunchKernelGGL(f32_to_split_kernel<true>, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, mvsgi::as_stream(stream), x,
+                           static_cast<unsigned char*>(y), B, C, D, H, W);
+    else
+        hipLaunchKernelGGL(f32_to_split_kernel<false>, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, mvsgi::as_stream(stream), x,
+                           static_cast<unsigned char*>(y), B, C, D, H, W);
     return mvsgi::check_launch("mvsgi_act_f32_to_split");
 }
+extern "C" int mvsgi_act_f32_to_split(const float* x, void* y, int B, int C, int D, int H, int W, mvsgi_stream_t stream) {
+    return mvsgi_act_f32_to_split_fmt(x, y, B, C, D, H, W, 0, stream);
+}
 
-extern "C" int mvsgi_act_split_to_f32(const void* x, float* y, int B, int C, int D, int H, int W, mvsgi_stream_t stream) {
+extern "C" int mvsgi_act_split_to_f32_fmt(const void* x, float* y, int B, int C, int D, int H, int W, int fmt, mvsgi_stream_t stream) {
     MVSGI_REQUIRE(x && y, "mvsgi_act_split_to_f32: null pointer");
     MVSGI_REQUIRE(B > 0 && C > 0 && C % 16 == 0 && D > 0 && H > 0 && W > 0, "mvsgi_act_split_to_f32: bad dims (C %% 16 == 0)");
+    MVSGI_REQUIRE(fmt == 0 || fmt == MVSGI_SPLIT_F16, "mvsgi_act_split_to_f32: fmt %d not in {0, MVSGI_SPLIT_F16}", fmt);
     const long long n = (long long)B * D * H * W * (C / 8);
     MVSGI_REQUIRE(mvsgi::cdiv(n, 256) < (1ll << 31), "mvsgi_act_split_to_f32: tensor too large");
-    hipLaunchKernelGGL(split_to_f32_kernel, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, mvsgi::as_stream(stream),
-                       static_cast<const unsigned char*>(x), y, B, C, D, H, W);
+    if (fmt)
+        hipLaunchKernelGGL(split_to_f32_kernel<true>, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, mvsgi::as_stream(stream),
+                           static_cast<const unsigned char*>(x), y, B, C, D, H, W);
+    else
+        hipLaunchKernelGGL(split_to_f32_kernel<false>, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, mvsgi::as_stream(stream),
+                           static_cast<const unsigned char*>(x), y, B, C, D, H, W);
     return mvsgi::check_launch("mvsgi_act_split_to_f32");
+}
+extern "C" int mvsgi_act_split_to_f32(const void* x, float* y, int B, int C, int D, int H, int W, mvsgi_stream_t stream) {
+    return mvsgi_act_split_to_f32_fmt(x, y, B, C, D, H, W, 0, stream);
 }
 
 extern "C" size_t mvsgi_conv3d_rs_packed_weight_bytes(int Cout, int Cin) {
@@ -814,23 +854,28 @@ extern "C" size_t mvsgi_conv3d_rs_packed_weight_bytes(int Cout, int Cin) {
     return Cout == 32 && Cin == 32 ? (size_t)2 * 2 * rs::kPairs * 2 * 64 * 16 : 0;
 }
 
-extern "C" int mvsgi_conv3d_rs_pack_weights(const float* w_oidhw, void* w_packed, int Cout, int Cin, mvsgi_stream_t stream) {
+extern "C" int mvsgi_conv3d_rs_pack_weights_fmt(const float* w_oidhw, void* w_packed, int Cout, int Cin, int fmt, mvsgi_stream_t stream) {
     MVSGI_REQUIRE(w_oidhw && w_packed, "mvsgi_conv3d_rs_pack_weights: null pointer");
+    MVSGI_REQUIRE(fmt == 0 || fmt == MVSGI_SPLIT_F16, "mvsgi_conv3d_rs_pack_weights: fmt %d not in {0, MVSGI_SPLIT_F16}", fmt);
     if (Cout == 16 && Cin == 16) {
         hipLaunchKernelGGL(rs16_pack_weights_kernel, dim3((5 * 3 * 64 + 255) / 256), dim3(256), 0, mvsgi::as_stream(stream), w_oidhw,
-                           static_cast<bf16x8*>(w_packed));
+                           static_cast<bf16x8*>(w_packed), fmt != 0);
         return mvsgi::check_launch("mvsgi_conv3d_rs_pack_weights");
     }
     MVSGI_REQUIRE(Cout == 32 && Cin == 32, "mvsgi_conv3d_rs_pack_weights: only 32 -> 32 and 16 -> 16 channels (got %d -> %d)", Cin, Cout);
     hipLaunchKernelGGL(rs_pack_weights_kernel, dim3((2 * 2 * rs::kPairs * 64 + 255) / 256), dim3(256), 0, mvsgi::as_stream(stream),
-                       w_oidhw, static_cast<bf16x8*>(w_packed));
+                       w_oidhw, static_cast<bf16x8*>(w_packed), fmt != 0);
     return mvsgi::check_launch("mvsgi_conv3d_rs_pack_weights");
 }
+extern "C" int mvsgi_conv3d_rs_pack_weights(const float* w_oidhw, void* w_packed, int Cout, int Cin, mvsgi_stream_t stream) {
+    return mvsgi_conv3d_rs_pack_weights_fmt(w_oidhw, w_packed, Cout, Cin, 0, stream);
+}
 
-extern "C" int mvsgi_conv3d_rs_split(const void* x, const void* w_packed_rs, const float* scale, const float* shift,
-                                     const void* res, void* y, int y_is_f32, int B, int Cin, int D, int H, int W, int Cout,
-                                     float neg_slope, mvsgi_stream_t stream) {
+extern "C" int mvsgi_conv3d_rs_split_fmt(const void* x, const void* w_packed_rs, const float* scale, const float* shift,
+                                         const void* res, void* y, int y_is_f32, int B, int Cin, int D, int H, int W, int Cout,
+                                         float neg_slope, int fmt, mvsgi_stream_t stream) {
     MVSGI_REQUIRE(x && y && w_packed_rs && scale && shift, "mvsgi_conv3d_rs_split: null pointer");
+    MVSGI_REQUIRE(fmt == 0 || fmt == MVSGI_SPLIT_F16, "mvsgi_conv3d_rs_split: fmt %d not in {0, MVSGI_SPLIT_F16}", fmt);
     MVSGI_REQUIRE(Cin == 32 && Cout == 32, "mvsgi_conv3d_rs_split: only 32 -> 32 channels (got %d -> %d)", Cin, Cout);
     MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_conv3d_rs_split: bad dims");
     MVSGI_REQUIRE(x != y, "mvsgi_conv3d_rs_split: in-place operation is not supported");
@@ -869,33 +914,27 @@ extern "C" int mvsgi_conv3d_rs_split(const void* x, const void* w_packed_rs, con
         }
     }
 #endif
-    static mvsgi::PersistentGeom geo_cache[2][mvsgi::kMaxDevices] = {};
+    static mvsgi::PersistentGeom geo_cache[4][mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
-    auto kern = y_is_f32 ? conv3d_rs32_kernel<1> : conv3d_rs32_kernel<0>;
-    if (mvsgi::persistent_geometry(kern, 256, rs::LDS_BYTES, 1, geo_cache[y_is_f32 ? 1 : 0], "mvsgi_conv3d_rs_split", geo)) return 1;
+    void (*kern)(RsArgs) = fmt ? (y_is_f32 ? conv3d_rs32_kernel<1, true> : conv3d_rs32_kernel<0, true>)
+                               : (y_is_f32 ? conv3d_rs32_kernel<1, false> : conv3d_rs32_kernel<0, false>);
+    if (mvsgi::persistent_geometry(kern, 256, rs::LDS_BYTES, 1, geo_cache[(y_is_f32 ? 1 : 0) + (fmt ? 2 : 0)], "mvsgi_conv3d_rs_split", geo)) return 1;
     const long long resident = (long long)geo.cus / 8 * 8 > 0 ? (long long)geo.cus / 8 * 8 : 8;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), rs::LDS_BYTES,
                        mvsgi::as_stream(stream), a);
     return mvsgi::check_launch("mvsgi_conv3d_rs_split");
 }
+extern "C" int mvsgi_conv3d_rs_split(const void* x, const void* w_packed_rs, const float* scale, const float* shift,
+                                     const void* res, void* y, int y_is_f32, int B, int Cin, int D, int H, int W, int Cout,
+                                     float neg_slope, mvsgi_stream_t stream) {
+    return mvsgi_conv3d_rs_split_fmt(x, w_packed_rs, scale, shift, res, y, y_is_f32, B, Cin, D, H, W, Cout, neg_slope, 0, stream);
+}
 
 // ---- polyphase ResizeConv3d on the 32 -> 32 kernel (MODE 2): internal entry points used by csrc/conv3d_up2poly.hip ----
 namespace mvsgi {
 
-static inline unsigned short host_bf16_rne(float v) {      // round to nearest even, as the device's (__bf16) cast
-    unsigned u;
-    memcpy(&u, &v, 4);
-    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-static inline float host_bf16_to_f32(unsigned short h) {
-    const unsigned u = (unsigned)h << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-
 // the host statement of rs_pack_weights_kernel: [32][32][27] fp32 -> kRs32PackedBytes in the register-stationary lane order
-void rs32_pack_weights_host(const float* w, void* packed) {
+void rs32_pack_weights_host(const float* w, void* packed, bool f16) {
     unsigned short* out = static_cast<unsigned short*>(packed);
     for (int sl = 0; sl < 2; ++sl)
         for (int ct = 0; ct < 2; ++ct)
@@ -906,15 +945,16 @@ void rs32_pack_weights_host(const float* w, void* packed) {
                     const size_t o = ((((size_t)(sl * 2 + ct) * rs::kPairs + p) * 2) * 64 + lane) * 8;
                     for (int j = 0; j < 8; ++j) {
                         const float v = k >= 0 ? w[((size_t)co * 32 + ci + j) * 27 + k * 3 + kw] : 0.f;
-                        const unsigned short h = host_bf16_rne(v);
+                        unsigned short h, l;
+                        sf_split_weight(v, f16, h, l);
                         out[o + j] = h;
-                        out[o + 64 * 8 + j] = host_bf16_rne(v - host_bf16_to_f32(h));
+                        out[o + 64 * 8 + j] = l;
                     }
                 }
 }
 
 int rs32_up2_launch(const void* x_split, const void* w_sets, const float* scale32, const float* shift32, void* y, int y_is_split,
-                    int B, int D, int H, int W, float neg_slope, hipStream_t st) {
+                    int B, int D, int H, int W, float neg_slope, bool f16, hipStream_t st) {
     MVSGI_REQUIRE((long long)(D + 2) * (H + 2) * (W + 2) * 128 < (1ll << 31) && (long long)D * H * W * 512 < (1ll << 31),
                   "mvsgi_conv3d_up2_poly_f32: frame too large for 32-bit offsets");
     RsArgs a{};
@@ -934,10 +974,11 @@ int rs32_up2_launch(const void* x_split, const void* w_sets, const float* scale3
     a.total_units = (int)per_role;
     a.wp_set = (long long)(kRs32PackedBytes / 16);
     MVSGI_REQUIRE((long long)(2 * D + 2) * (2 * H + 2) * (2 * W + 2) * 64 < (1ll << 31), "mvsgi_conv3d_up2_poly: output frame too large for 32-bit offsets");
-    static PersistentGeom geo_cache[2][kMaxDevices] = {};
+    static PersistentGeom geo_cache[4][kMaxDevices] = {};
     PersistentGeom geo;
-    auto kern = y_is_split ? conv3d_rs32_kernel<3> : conv3d_rs32_kernel<2>;
-    if (persistent_geometry(kern, 256, rs::LDS_BYTES, 1, geo_cache[y_is_split ? 1 : 0], "mvsgi_conv3d_up2_poly_f32", geo)) return 1;
+    void (*kern)(RsArgs) = f16 ? (y_is_split ? conv3d_rs32_kernel<3, true> : conv3d_rs32_kernel<2, true>)
+                               : (y_is_split ? conv3d_rs32_kernel<3, false> : conv3d_rs32_kernel<2, false>);
+    if (persistent_geometry(kern, 256, rs::LDS_BYTES, 1, geo_cache[(y_is_split ? 1 : 0) + (f16 ? 2 : 0)], "mvsgi_conv3d_up2_poly_f32", geo)) return 1;
     // grid = 8 XCDs x R roles x walkers; one workgroup per CU when the roles fit, never fewer than one walker per (XCD, role)
     const int R = 4 * a.tiles_d;
     long long walkers = geo.cus / (8 * R);
@@ -955,7 +996,8 @@ int rs32_up2_launch(const void* x_split, const void* w_sets, const float* scale3
 // split-padded input, fp32 [B][D][H][W][16] output; w_packed_rs from mvsgi_conv3d_rs_pack_weights(16, 16).
 namespace {
 int rs16_run(const void* x, const void* w_packed_rs, const float* scale, const float* shift, void* y, int y_is_split,
-             int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream) {
+             int B, int D, int H, int W, float neg_slope, int fmt, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(fmt == 0 || fmt == MVSGI_SPLIT_F16, "mvsgi_conv3d_rs16_split: fmt %d not in {0, MVSGI_SPLIT_F16}", fmt);
     MVSGI_REQUIRE(x && y && w_packed_rs && scale && shift, "mvsgi_conv3d_rs16_split: null pointer");
     MVSGI_REQUIRE(x != y, "mvsgi_conv3d_rs16_split: in-place operation is not supported");
     MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_conv3d_rs16_split: bad dims");
@@ -975,30 +1017,32 @@ int rs16_run(const void* x, const void* w_packed_rs, const float* scale, const f
     const long long nb = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
     MVSGI_REQUIRE(nb < (1ll << 31), "mvsgi_conv3d_rs16_split: too many units");
     a.total_units = (int)nb;
-    static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
+    static mvsgi::PersistentGeom geo_cache[4][mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
-    static mvsgi::PersistentGeom geo_cache_s[mvsgi::kMaxDevices] = {};
-    if (y_is_split ? mvsgi::persistent_geometry(conv3d_rs16_kernel<true>, 256, rs16::LDS_BYTES, 1, geo_cache_s, "mvsgi_conv3d_rs16_split", geo)
-                   : mvsgi::persistent_geometry(conv3d_rs16_kernel<false>, 256, rs16::LDS_BYTES, 1, geo_cache, "mvsgi_conv3d_rs16_split", geo))
+    void (*kern)(Rs16Args) = fmt ? (y_is_split ? conv3d_rs16_kernel<true, true> : conv3d_rs16_kernel<false, true>)
+                                 : (y_is_split ? conv3d_rs16_kernel<true, false> : conv3d_rs16_kernel<false, false>);
+    if (mvsgi::persistent_geometry(kern, 256, rs16::LDS_BYTES, 1, geo_cache[(y_is_split ? 1 : 0) + (fmt ? 2 : 0)], "mvsgi_conv3d_rs16_split", geo))
         return 1;
     const long long resident = (long long)geo.cus / 8 * 8 > 0 ? (long long)geo.cus / 8 * 8 : 8;
-    if (y_is_split)
-        hipLaunchKernelGGL(conv3d_rs16_kernel<true>, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), rs16::LDS_BYTES,
-                           mvsgi::as_stream(stream), a);
-    else
-        hipLaunchKernelGGL(conv3d_rs16_kernel<false>, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), rs16::LDS_BYTES,
-                           mvsgi::as_stream(stream), a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), rs16::LDS_BYTES, mvsgi::as_stream(stream), a);
     return mvsgi::check_launch("mvsgi_conv3d_rs16_split");
 }
 }  // namespace
 
 extern "C" int mvsgi_conv3d_rs16_split(const void* x, const void* w_packed_rs, const float* scale, const float* shift, float* y,
                                        int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream) {
-    return rs16_run(x, w_packed_rs, scale, shift, y, 0, B, D, H, W, neg_slope, stream);
+    return rs16_run(x, w_packed_rs, scale, shift, y, 0, B, D, H, W, neg_slope, 0, stream);
 }
 
 // the same layer writing a split-padded [B][D+2][H+2][W+2][16] tensor (zero-bordered by the caller, interior written)
 extern "C" int mvsgi_conv3d_rs16_split_out_split(const void* x, const void* w_packed_rs, const float* scale, const float* shift, void* y_split,
                                                  int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream) {
-    return rs16_run(x, w_packed_rs, scale, shift, y_split, 1, B, D, H, W, neg_slope, stream);
+    return rs16_run(x, w_packed_rs, scale, shift, y_split, 1, B, D, H, W, neg_slope, 0, stream);
+}
+
+// either output (y_is_split: 0 = fp32 [B][D][H][W][16], 1 = split-padded) in either split (fmt: 0 | MVSGI_SPLIT_F16: input, weights
+// and a split output all in that split)
+extern "C" int mvsgi_conv3d_rs16_split_fmt(const void* x, const void* w_packed_rs, const float* scale, const float* shift, void* y,
+                                           int y_is_split, int B, int D, int H, int W, float neg_slope, int fmt, mvsgi_stream_t stream) {
+    return rs16_run(x, w_packed_rs, scale, shift, y, y_is_split ? 1 : 0, B, D, H, W, neg_slope, fmt, stream);
 }

@@ -33,17 +33,10 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void split4(const f32x4 x, u32x2& hi, u32x2& lo) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const f32x2v v = {x[2 * p], x[2 * p + 1]};
-        const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-        const f32x2v hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
-        hi[p] = hb;
-        lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, bf16x2));
-    }
-}
+#include "split_fmt.hpp"
+
 // LeakyReLU for slopes in [0, 1] as mul + max (plain asm max: __builtin_fmaxf first canonicalises an MFMA result with a third op)
 __device__ __forceinline__ float lrelu(const float v, const float slope) {
     const float m = v * slope;
@@ -66,16 +59,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t s2_desc(const unsigned char* b
 __device__ __forceinline__ void s2_store16(const u32x4 v, const __amdgpu_buffer_rsrc_t dsc, const unsigned voff, const int soff) {
     __builtin_amdgcn_raw_buffer_store_b128(v, dsc, voff, soff, MVSGI_S2RS_ST_AUX);
 }
+template <bool F16>
 __device__ __forceinline__ u32x4 s2_pack_split(const f32x4 v) {
     // hi | lo of four channels; lanes kg and kg ^ 1 trade halves: kg even ends up with hi / lo of channels 8 (kg >> 1) .. + 7
     u32x2 hi, lo;
-    split4(v, hi, lo);
+    sf_split4<F16>(v, hi, lo);
     const u32x2 sa = __builtin_amdgcn_permlane16_swap(hi[0], lo[0], false, false);
     const u32x2 sb = __builtin_amdgcn_permlane16_swap(hi[1], lo[1], false, false);
     return u32x4{sa[0], sb[0], sa[1], sb[1]};
 }
+template <bool F16>
 __device__ __forceinline__ f32x4 s2_mfma(const bf16x8 a, const bf16x8 b, const f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    return sf_mfma16<F16>(a, b, c);
 }
 
 #ifndef MVSGI_S2RS_DMA_SPREAD
@@ -100,21 +95,22 @@ struct Geo {
 
 // [Cout 32][Cin 16][27] x scale[Cout] -> [cout tile 2][14 pairs][hi | lo][64 lanes][8 bf16]
 //   lane = (kg << 4) | i holds scale[co] * W[co = 16 ct + i][cin = (kg & 1) * 8 + j][tap = 2 p + (kg >> 1)]  (tap 27: zeros)
-__global__ void s2rs_pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale, bf16x8* __restrict__ wp) {
+__global__ void s2rs_pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale, bf16x8* __restrict__ wp, bool f16) {
     const int idx = blockIdx.x * 64 + threadIdx.x;
     if (idx >= 2 * s2::kPairs * 64) return;
     const int lane = idx & 63, r = idx >> 6;
     const int p = r % s2::kPairs, ct = r / s2::kPairs;
     const int kg = lane >> 4, co = ct * 16 + (lane & 15), ci = (kg & 1) * 8, tap = 2 * p + (kg >> 1);
-    bf16x8 hi, lo;
+    u16x8 hi, lo;
     for (int j = 0; j < 8; ++j) {
         const float v = tap < 27 ? w[((long long)co * 16 + ci + j) * 27 + tap] * scale[co] : 0.f;
-        const __bf16 h = (__bf16)v;
-        hi[j] = h;
-        lo[j] = (__bf16)(v - (float)h);
+        unsigned short h_, l_;
+        sf_split_weight(v, f16, h_, l_);
+        hi[j] = h_;
+        lo[j] = l_;
     }
-    wp[((ct * s2::kPairs + p) * 2) * 64 + lane] = hi;
-    wp[((ct * s2::kPairs + p) * 2 + 1) * 64 + lane] = lo;
+    wp[((ct * s2::kPairs + p) * 2) * 64 + lane] = __builtin_bit_cast(bf16x8, hi);
+    wp[((ct * s2::kPairs + p) * 2 + 1) * 64 + lane] = __builtin_bit_cast(bf16x8, lo);
 }
 
 struct S2Args {
@@ -125,6 +121,8 @@ struct S2Args {
     int B, D, H, W, Do, Ho, Wo;
     int tiles_h, tiles_w, total_units;
     float neg_slope;
+    float unscale;             // fp16 split: the packed weights and `shift` carry a power of two 1 / unscale (so that the weights' lo parts
+                               // are normal fp16 numbers); the accumulators are multiplied by it in front of the activation
 };
 
 __device__ __forceinline__ int s2_xcd_remap(int bid, int n) {
@@ -136,7 +134,7 @@ __device__ __forceinline__ int s2_xcd_remap(int bid, int n) {
 // two workgroups per CU -- the next window is requested when the workgroup is done with the current one, and the partner workgroup's
 // request is in flight meanwhile (~1.6 windows in flight per CU instead of 1).  Measured the same within 2 % (565 vs 577 us per 64
 // frames): the kernel is not short of requests in flight; NBUF = 2 is the default, MVSGI_S2RS_NBUF=1 selects the other.
-template <int TH, int NBUF>
+template <int TH, int NBUF, bool F16 = false>
 __global__ __launch_bounds__(256, (TH == 4 && NBUF == 2) ? 1 : 2) void conv3d_s2rs_kernel(S2Args a) {
     using namespace s2;
     using G = Geo<TH>;
@@ -254,11 +252,11 @@ __global__ __launch_bounds__(256, (TH == 4 && NBUF == 2) ? 1 : 2) void conv3d_s2
             }
             if (p + 1 < kPairs) S2_READ(p + 1, (p + 1) & 1)
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) acc1[i] = s2_mfma(wl[p], xh[p & 1][i], acc1[i]);
+            for (int i = 0; i < TPW; ++i) acc1[i] = s2_mfma<F16>(wl[p], xh[p & 1][i], acc1[i]);
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) acc2[i] = s2_mfma(wh[p], xl[p & 1][i], acc2[i]);
+            for (int i = 0; i < TPW; ++i) acc2[i] = s2_mfma<F16>(wh[p], xl[p & 1][i], acc2[i]);
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) acc[i] = s2_mfma(wh[p], xh[p & 1][i], acc[i]);
+            for (int i = 0; i < TPW; ++i) acc[i] = s2_mfma<F16>(wh[p], xh[p & 1][i], acc[i]);
         }
 #undef S2_READ
         if constexpr (NBUF == 1) {                       // every wave has its fragments: the window is free for brick u + 1
@@ -272,8 +270,8 @@ __global__ __launch_bounds__(256, (TH == 4 && NBUF == 2) ? 1 : 2) void conv3d_s2
             for (int i = 0; i < TPW; ++i) {
                 f32x4 v = acc[i] + (acc1[i] + acc2[i]);          // the small terms first
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], a.neg_slope);
-                const u32x4 o = s2_pack_split(v);
+                for (int e = 0; e < 4; ++e) v[e] = lrelu(F16 ? v[e] * a.unscale : v[e], a.neg_slope);
+                const u32x4 o = s2_pack_split<F16>(v);
                 if (okc && oh0 + t0 + i < a.Ho) s2_store16(o, dsc_, vst, i * Wop * 128);
             }
         }
@@ -283,7 +281,7 @@ __global__ __launch_bounds__(256, (TH == 4 && NBUF == 2) ? 1 : 2) void conv3d_s2
 #undef S2_STAGE
 }
 
-template <int TH, int NBUF>
+template <int TH, int NBUF, bool F16 = false>
 int s2_launch(S2Args a, hipStream_t st) {
     constexpr int lds_bytes = NBUF * s2::Geo<TH>::IMG;
     constexpr int wgs = (TH == 4 && NBUF == 2) ? 1 : 2;
@@ -295,10 +293,10 @@ int s2_launch(S2Args a, hipStream_t st) {
     a.total_units = (int)nb;
     static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
-    if (mvsgi::persistent_geometry(conv3d_s2rs_kernel<TH, NBUF>, 256, lds_bytes, wgs, geo_cache, "mvsgi_conv3d_s2rs", geo)) return 1;
+    if (mvsgi::persistent_geometry(conv3d_s2rs_kernel<TH, NBUF, F16>, 256, lds_bytes, wgs, geo_cache, "mvsgi_conv3d_s2rs", geo)) return 1;
     long long resident = ((long long)geo.cus * geo.wgs_per_cu) / 8 * 8;
     if (resident < 8) resident = 8;
-    hipLaunchKernelGGL((conv3d_s2rs_kernel<TH, NBUF>), dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), lds_bytes, st, a);
+    hipLaunchKernelGGL((conv3d_s2rs_kernel<TH, NBUF, F16>), dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), lds_bytes, st, a);
     return mvsgi::check_launch("mvsgi_conv3d_s2rs");
 }
 
@@ -306,19 +304,28 @@ int s2_launch(S2Args a, hipStream_t st) {
 
 extern "C" size_t mvsgi_conv3d_s2rs_packed_weight_bytes(void) { return (size_t)2 * s2::kPairs * 2 * 64 * 16; }
 
-extern "C" int mvsgi_conv3d_s2rs_pack_weights(const float* w_oidhw, const float* scale, void* w_packed, mvsgi_stream_t stream) {
+extern "C" int mvsgi_conv3d_s2rs_pack_weights_fmt(const float* w_oidhw, const float* scale, void* w_packed, int fmt, mvsgi_stream_t stream) {
     MVSGI_REQUIRE(w_oidhw && scale && w_packed, "mvsgi_conv3d_s2rs_pack_weights: null pointer");
+    MVSGI_REQUIRE(fmt == 0 || fmt == MVSGI_SPLIT_F16, "mvsgi_conv3d_s2rs_pack_weights: fmt %d not in {0, MVSGI_SPLIT_F16}", fmt);
     hipLaunchKernelGGL(s2rs_pack_weights_kernel, dim3(2 * s2::kPairs), dim3(64), 0, mvsgi::as_stream(stream), w_oidhw, scale,
-                       static_cast<bf16x8*>(w_packed));
+                       static_cast<bf16x8*>(w_packed), fmt != 0);
     return mvsgi::check_launch("mvsgi_conv3d_s2rs_pack_weights");
+}
+extern "C" int mvsgi_conv3d_s2rs_pack_weights(const float* w_oidhw, const float* scale, void* w_packed, mvsgi_stream_t stream) {
+    return mvsgi_conv3d_s2rs_pack_weights_fmt(w_oidhw, scale, w_packed, 0, stream);
 }
 
 // y = act( conv3d(x, w, stride 2, padding 1) * scale + shift ), 16 -> 32 channels, on split-padded activations:
 // x_split [B][D+2][H+2][W+2][64 B], y_split [B][Do+2][Ho+2][Wo+2][128 B] with Do = (D - 1) / 2 + 1 (likewise Ho, Wo); both
 // zero-bordered, only y's interior is written.  w_packed from mvsgi_conv3d_s2rs_pack_weights (scale folded in).
-extern "C" int mvsgi_conv3d_s2rs(const void* x_split, const void* w_packed, const float* shift, void* y_split, int B, int D, int H,
-                                 int W, float neg_slope, mvsgi_stream_t stream) {
+// _fmt: fmt = MVSGI_SPLIT_F16 runs the layer in the fp16 split; `scale` (at packing) and `shift` then carry a power of two 1 / unscale
+// chosen by the caller (the epilogue has no per-channel multiplier to hide it in), and the accumulators are multiplied by `unscale`
+extern "C" int mvsgi_conv3d_s2rs_fmt(const void* x_split, const void* w_packed, const float* shift, void* y_split, int B, int D, int H,
+                                     int W, float neg_slope, float unscale, int fmt, mvsgi_stream_t stream) {
     MVSGI_REQUIRE(x_split && w_packed && shift && y_split, "mvsgi_conv3d_s2rs: null pointer");
+    MVSGI_REQUIRE(fmt == 0 || fmt == MVSGI_SPLIT_F16, "mvsgi_conv3d_s2rs: fmt %d not in {0, MVSGI_SPLIT_F16}", fmt);
+    MVSGI_REQUIRE(fmt != 0 || unscale == 1.f, "mvsgi_conv3d_s2rs: unscale is a parameter of the fp16 split");
+    MVSGI_REQUIRE(unscale > 0.f, "mvsgi_conv3d_s2rs: unscale must be positive");
     MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_conv3d_s2rs: non-positive dimension");
     MVSGI_REQUIRE(neg_slope >= 0.f && neg_slope <= 1.f, "mvsgi_conv3d_s2rs: negative slope %g outside [0, 1]", (double)neg_slope);
     MVSGI_REQUIRE((long long)(D + 2) * (H + 2) * (W + 2) * 64 < 0x7fffff00ll, "mvsgi_conv3d_s2rs: input frame too large for 32-bit window offsets");
@@ -331,7 +338,9 @@ extern "C" int mvsgi_conv3d_s2rs(const void* x_split, const void* w_packed, cons
     a.Do = (D - 1) / 2 + 1; a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
     MVSGI_REQUIRE((long long)(a.Do + 2) * (a.Ho + 2) * (a.Wo + 2) * 128 < 0x7fffff00ll, "mvsgi_conv3d_s2rs: output frame too large for 32-bit offsets");
     a.neg_slope = neg_slope;
+    a.unscale = unscale;
     hipStream_t st = mvsgi::as_stream(stream);
+    if (fmt) return s2_launch<4, 2, true>(a, st);
 #ifdef MVSGI_EXPERIMENTAL      // measured equal or slower (DESIGN_HISTORY.md): 2-row bricks with two workgroups per CU, single-window workgroups
     const char* th_e = mvsgi::exp_env("MVSGI_S2RS_TH");          // brick height: 4 output rows (one workgroup per CU) or 2 (two)
     const char* nb_e = mvsgi::exp_env("MVSGI_S2RS_NBUF");        // windows per workgroup: 1 (two workgroups per CU) or 2 (TH = 4: one)
@@ -339,4 +348,8 @@ extern "C" int mvsgi_conv3d_s2rs(const void* x_split, const void* w_packed, cons
     if (nb_e && atoi(nb_e) == 1) return s2_launch<4, 1>(a, st);
 #endif
     return s2_launch<4, 2>(a, st);
+}
+extern "C" int mvsgi_conv3d_s2rs(const void* x_split, const void* w_packed, const float* shift, void* y_split, int B, int D, int H,
+                                 int W, float neg_slope, mvsgi_stream_t stream) {
+    return mvsgi_conv3d_s2rs_fmt(x_split, w_packed, shift, y_split, B, D, H, W, neg_slope, 1.f, 0, stream);
 }

@@ -24,6 +24,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#include "split_fmt.hpp"
 
 enum { FIRST = 0, INT = 1, LAST = 2, ONLY = 3 };
 
@@ -166,7 +167,7 @@ PolyHeader layout(int D, int H, int W) {
 }
 
 // face-role weights: wsrc [8 phases][16][32][27] (folded), taps[9] = indices into the 27 -> [tap][phase][hi|lo][lane][8]
-void pack_face_weights(const float* wsrc, const int* taps, unsigned short* out) {
+void pack_face_weights(const float* wsrc, const int* taps, unsigned short* out, bool f16) {
     for (int t = 0; t < 9; ++t)
         for (int ph = 0; ph < 8; ++ph)
             for (int lane = 0; lane < 64; ++lane) {
@@ -174,17 +175,7 @@ void pack_face_weights(const float* wsrc, const int* taps, unsigned short* out) 
                 const size_t o = (((size_t)(t * 8 + ph) * 2) * 64 + lane) * 8;
                 for (int e = 0; e < 8; ++e) {
                     const float v = wsrc[(((size_t)ph * 16 + co) * 32 + kg * 8 + e) * 27 + taps[t]];
-                    unsigned u;
-                    memcpy(&u, &v, 4);
-                    const unsigned short hi = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-                    const unsigned hu = (unsigned)hi << 16;
-                    float hf;
-                    memcpy(&hf, &hu, 4);
-                    const float r = v - hf;
-                    unsigned ru;
-                    memcpy(&ru, &r, 4);
-                    out[o + e] = hi;
-                    out[o + 64 * 8 + e] = (unsigned short)((ru + 0x7fffu + ((ru >> 16) & 1u)) >> 16);
+                    sf_split_weight(v, f16, out[o + e], out[o + 64 * 8 + e]);
                 }
             }
 }
@@ -201,6 +192,7 @@ struct FaceGrid {          // workgroups of role r: [first[r], first[r + 1]) of 
     int n_roles;           // a workgroup needs the CU's whole LDS, so idle ones would queue for a CU only to exit)
     int first[13];
 };
+template <bool F16>
 __global__ __launch_bounds__(512, 2) void up2_face_kernel(const unsigned char* __restrict__ x, const unsigned char* __restrict__ plan,
                                                           unsigned char* __restrict__ y, int B, long long x_frame, long long y_frame,
                                                           long long off_facew, long long off_roles, FaceGrid fg) {
@@ -264,11 +256,11 @@ __global__ __launch_bounds__(512, 2) void up2_face_kernel(const unsigned char* _
             }
             const bf16x8 xh = __builtin_bit_cast(bf16x8, fh[k]), xl = __builtin_bit_cast(bf16x8, fl[k]);
 #pragma unroll
-            for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[k & 1][2 * p + 1], xh, acc[p], 0, 0, 0);
+            for (int p = 0; p < 8; ++p) acc[p] = sf_mfma16<F16>(wb[k & 1][2 * p + 1], xh, acc[p]);
 #pragma unroll
-            for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[k & 1][2 * p], xl, acc[p], 0, 0, 0);
+            for (int p = 0; p < 8; ++p) acc[p] = sf_mfma16<F16>(wb[k & 1][2 * p], xl, acc[p]);
 #pragma unroll
-            for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[k & 1][2 * p], xh, acc[p], 0, 0, 0);
+            for (int p = 0; p < 8; ++p) acc[p] = sf_mfma16<F16>(wb[k & 1][2 * p], xh, acc[p]);
         }
         const int mode = run == 0 ? m_first : (run == nrun - 1 ? m_last : ST_WRITE);
         if (ok && mode != ST_SKIP) {
@@ -284,6 +276,7 @@ __global__ __launch_bounds__(512, 2) void up2_face_kernel(const unsigned char* _
 
 // the edge lines (cells on an H face AND a W face), every plane, all 8 phases: fp32 dot products of 9 taps (td, th) x 32 channels.
 // thread = (b, plane, edge cell, phase, cout); writes (the H-face roles accumulate onto it afterwards).
+template <bool F16>
 __global__ __launch_bounds__(256) void up2_edge_kernel(const unsigned char* __restrict__ x, const unsigned char* __restrict__ plan,
                                                        float* __restrict__ y, int B, int D, int H, int W, int n_cells, int n_groups,
                                                        long long off_edgew, long long off_edgecells, int ob) {
@@ -312,8 +305,8 @@ __global__ __launch_bounds__(256) void up2_edge_kernel(const unsigned char* __re
 #pragma unroll
                 for (int p = 0; p < 8; ++p) {
                     const unsigned hi = rec[p], lo = rec[p + 8];
-                    const float a0 = __builtin_bit_cast(float, hi << 16) + __builtin_bit_cast(float, lo << 16);
-                    const float a1 = __builtin_bit_cast(float, hi & 0xffff0000u) + __builtin_bit_cast(float, lo & 0xffff0000u);
+                    const float a0 = sf_widen_lo<F16>(hi) + sf_widen_lo<F16>(lo);
+                    const float a1 = sf_widen_hi<F16>(hi) + sf_widen_hi<F16>(lo);
                     s = fmaf(a0, wk[(sl * 16 + 2 * p) * 16], s);
                     s = fmaf(a1, wk[(sl * 16 + 2 * p + 1) * 16], s);
                 }
@@ -336,8 +329,12 @@ extern "C" size_t mvsgi_conv3d_up2_poly_plan_bytes(int D, int H, int W) {
 
 // HOST function (no GPU call): w_oidhw_host [16][32][3][3][3] fp32 in host memory -> plan_host (mvsgi_conv3d_up2_poly_plan_bytes
 // bytes, position independent: copy it to the device as it is).  D, H, W: the LOW-resolution size of the layer's input.
-extern "C" int mvsgi_conv3d_up2_poly_plan(const float* w_oidhw_host, void* plan_host, int D, int H, int W) {
+// _fmt: the folded weights in either split (0 = bf16, MVSGI_SPLIT_F16; the caller pre-scales the weights of an fp16 plan, see
+// MVSGI_CONV_F16); the plan is run by the *_fmt launchers with the same fmt
+extern "C" int mvsgi_conv3d_up2_poly_plan_fmt(const float* w_oidhw_host, void* plan_host, int D, int H, int W, int fmt) {
     MVSGI_REQUIRE(w_oidhw_host && plan_host, "mvsgi_conv3d_up2_poly_plan: null pointer");
+    MVSGI_REQUIRE(fmt == 0 || fmt == MVSGI_SPLIT_F16, "mvsgi_conv3d_up2_poly_plan: fmt %d not in {0, MVSGI_SPLIT_F16}", fmt);
+    const bool f16 = fmt != 0;
     MVSGI_REQUIRE(D > 0 && H > 0 && W > 0, "mvsgi_conv3d_up2_poly_plan: bad dims");
     MVSGI_REQUIRE((long long)(D + 2) * (H + 2) * (W + 2) * 128 < (1ll << 31) && (long long)D * H * W * 512 < (1ll << 31),
                   "mvsgi_conv3d_up2_poly_plan: frame too large for 32-bit offsets");
@@ -355,7 +352,7 @@ extern "C" int mvsgi_conv3d_up2_poly_plan(const float* w_oidhw_host, void* plan_
                     fold(class_matrix(pd, cls), class_matrix(ph, INT), class_matrix(pw, INT), w, f0.data());
                     memcpy(w32.data() + (size_t)pw * 16 * 32 * 27, f0.data(), f0.size() * 4);
                 }
-                mvsgi::rs32_pack_weights_host(w32.data(), P + h.off_main + (size_t)((pd * 4 + cls) * 2 + ph) * mvsgi::kRs32PackedBytes);
+                mvsgi::rs32_pack_weights_host(w32.data(), P + h.off_main + (size_t)((pd * 4 + cls) * 2 + ph) * mvsgi::kRs32PackedBytes, f16);
             }
     // ---- face roles ----
     const int Hp = H + 2, Wp = W + 2, Hh = 2 * H, Wh = 2 * W;
@@ -369,7 +366,7 @@ extern "C" int mvsgi_conv3d_up2_poly_plan(const float* w_oidhw_host, void* plan_
     // index + 1, rows of 2W + 2, planes of (2H + 2) rows); the weights are shared
     auto emit = [&](const int* taps27, const int* tap_off, int x_base, int x_s0, int x_srun, int n0, int nrun, const int (*yb)[8],
                     const int* y_s0, const int* y_srun, int m_first, int m_last) {
-        pack_face_weights(w8.data(), taps27, reinterpret_cast<unsigned short*>(P + h.off_facew + (size_t)r * kFaceRoleWBytes));
+        pack_face_weights(w8.data(), taps27, reinterpret_cast<unsigned short*>(P + h.off_facew + (size_t)r * kFaceRoleWBytes), f16);
         for (int geo = 0; geo < 2; ++geo) {
             int* R = (geo ? roles_split : roles) + (size_t)r * kRoleInts;
             R[R_WOFF] = (int)((size_t)r * kFaceRoleWBytes / 16);
@@ -448,6 +445,9 @@ extern "C" int mvsgi_conv3d_up2_poly_plan(const float* w_oidhw_host, void* plan_
         }
     return 0;
 }
+extern "C" int mvsgi_conv3d_up2_poly_plan(const float* w_oidhw_host, void* plan_host, int D, int H, int W) {
+    return mvsgi_conv3d_up2_poly_plan_fmt(w_oidhw_host, plan_host, D, H, W, 0);
+}
 
 namespace {
 
@@ -455,8 +455,9 @@ namespace {
 // output is a split-padded tensor [B][2D+2][2H+2][2W+2][64 B] (the corrections use its voxel records as fp32 until the main
 // kernel overwrites them with the split result)
 int poly_launch(const void* x_split, const void* plan_dev, const float* scale, const float* shift, void* y, int ob, int B, int D, int H,
-                int W, float neg_slope, hipStream_t st) {
+                int W, float neg_slope, int fmt, hipStream_t st) {
     MVSGI_REQUIRE(x_split && plan_dev && scale && shift && y, "mvsgi_conv3d_up2_poly: null pointer");
+    MVSGI_REQUIRE(fmt == 0 || fmt == MVSGI_SPLIT_F16, "mvsgi_conv3d_up2_poly: fmt %d not in {0, MVSGI_SPLIT_F16}", fmt);
     MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_conv3d_up2_poly: bad dims");
     MVSGI_REQUIRE(neg_slope >= 0.f && neg_slope <= 1.f, "mvsgi_conv3d_up2_poly: neg_slope %g not in [0, 1]", (double)neg_slope);
     MVSGI_REQUIRE((long long)(D + 2) * (H + 2) * (W + 2) * 128 < (1ll << 31) &&
@@ -468,16 +469,23 @@ int poly_launch(const void* x_split, const void* plan_dev, const float* scale, c
     const long long y_frame = (long long)(2 * D + 2 * ob) * (2 * H + 2 * ob) * (2 * W + 2 * ob) * 64;
     const long long n = (long long)B * D * h.n_edge_cells * 128;
     MVSGI_REQUIRE(mvsgi::cdiv(n, 256) < (1ll << 31), "mvsgi_conv3d_up2_poly: too many edge threads");
-    hipLaunchKernelGGL(up2_edge_kernel, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, st, static_cast<const unsigned char*>(x_split), P,
-                       static_cast<float*>(y), B, D, H, W, h.n_edge_cells, h.n_groups, h.off_edgew, h.off_edgecells, ob);
+    if (fmt)
+        hipLaunchKernelGGL(up2_edge_kernel<true>, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, st, static_cast<const unsigned char*>(x_split), P,
+                           static_cast<float*>(y), B, D, H, W, h.n_edge_cells, h.n_groups, h.off_edgew, h.off_edgecells, ob);
+    else
+        hipLaunchKernelGGL(up2_edge_kernel<false>, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, st, static_cast<const unsigned char*>(x_split), P,
+                           static_cast<float*>(y), B, D, H, W, h.n_edge_cells, h.n_groups, h.off_edgew, h.off_edgecells, ob);
     if (mvsgi::check_launch("mvsgi_conv3d_up2_poly(edges)")) return 1;
     // one workgroup per CU is resident (its LDS holds a role's weights): size the roles' workgroups so that all of them fit one round
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     static bool attr_set[mvsgi::kMaxDevices] = {};
     if (dev >= 0 && dev < mvsgi::kMaxDevices && !attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(up2_face_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(up2_face_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)kFaceRoleWBytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(up2_face_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kFaceRoleWBytes);
         MVSGI_REQUIRE(e == hipSuccess, "mvsgi_conv3d_up2_poly: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set[dev] = true;
     }
@@ -500,11 +508,16 @@ int poly_launch(const void* x_split, const void* plan_dev, const float* scale, c
         }
         fg.first[r] = acc;
     }
-    hipLaunchKernelGGL(up2_face_kernel, dim3((unsigned)fg.first[h.n_roles]), dim3(512), kFaceRoleWBytes, st,
-                       static_cast<const unsigned char*>(x_split), P, static_cast<unsigned char*>(y), B, x_frame, y_frame, h.off_facew,
-                       ob ? h.off_roles_split : h.off_roles, fg);
+    if (fmt)
+        hipLaunchKernelGGL(up2_face_kernel<true>, dim3((unsigned)fg.first[h.n_roles]), dim3(512), kFaceRoleWBytes, st,
+                           static_cast<const unsigned char*>(x_split), P, static_cast<unsigned char*>(y), B, x_frame, y_frame, h.off_facew,
+                           ob ? h.off_roles_split : h.off_roles, fg);
+    else
+        hipLaunchKernelGGL(up2_face_kernel<false>, dim3((unsigned)fg.first[h.n_roles]), dim3(512), kFaceRoleWBytes, st,
+                           static_cast<const unsigned char*>(x_split), P, static_cast<unsigned char*>(y), B, x_frame, y_frame, h.off_facew,
+                           ob ? h.off_roles_split : h.off_roles, fg);
     if (mvsgi::check_launch("mvsgi_conv3d_up2_poly(faces)")) return 1;
-    return mvsgi::rs32_up2_launch(x_split, P + h.off_main, scale, shift, y, ob, B, D, H, W, neg_slope, st);
+    return mvsgi::rs32_up2_launch(x_split, P + h.off_main, scale, shift, y, ob, B, D, H, W, neg_slope, fmt != 0, st);
 }
 
 }  // namespace
@@ -514,12 +527,18 @@ int poly_launch(const void* x_split, const void* plan_dev, const float* scale, c
 // mvsgi_conv3d_up2_poly_plan(D, H, W) in device memory; neg_slope in [0, 1].
 extern "C" int mvsgi_conv3d_up2_poly_f32(const void* x_split, const void* plan_dev, const float* scale, const float* shift, float* y,
                                          int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream) {
-    return poly_launch(x_split, plan_dev, scale, shift, y, 0, B, D, H, W, neg_slope, mvsgi::as_stream(stream));
+    return poly_launch(x_split, plan_dev, scale, shift, y, 0, B, D, H, W, neg_slope, 0, mvsgi::as_stream(stream));
 }
 
 // The same with the result in the split-padded format, [B][2D+2][2H+2][2W+2][16] (zero border, never written): the input of
 // mvsgi_conv3d_head_split (the cost head reads hi | lo fragments straight from it).
 extern "C" int mvsgi_conv3d_up2_poly_split(const void* x_split, const void* plan_dev, const float* scale, const float* shift, void* y_split,
                                            int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream) {
-    return poly_launch(x_split, plan_dev, scale, shift, y_split, 1, B, D, H, W, neg_slope, mvsgi::as_stream(stream));
+    return poly_launch(x_split, plan_dev, scale, shift, y_split, 1, B, D, H, W, neg_slope, 0, mvsgi::as_stream(stream));
+}
+
+// either output (y_is_split: 0 = fp32 [B][2D][2H][2W][16], 1 = split-padded) in either split: input, plan and a split output all in `fmt`
+extern "C" int mvsgi_conv3d_up2_poly_fmt(const void* x_split, const void* plan_dev, const float* scale, const float* shift, void* y,
+                                         int y_is_split, int B, int D, int H, int W, float neg_slope, int fmt, mvsgi_stream_t stream) {
+    return poly_launch(x_split, plan_dev, scale, shift, y, y_is_split ? 1 : 0, B, D, H, W, neg_slope, fmt, mvsgi::as_stream(stream));
 }

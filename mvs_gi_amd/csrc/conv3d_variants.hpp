@@ -11,7 +11,7 @@ enum Variant {
     // Cout == 16 plane schedule (weights from mvsgi_conv3d_pack_weights_bf16x3_c16), plain and fused-upsample
     B3P_N16, B3PU_N16,
     // 32x32x16 schedule (Cout % 32 == 0, stride 1; weights from mvsgi_conv3d_pack_weights_bf16x3_v32), plain / fused upsample
-    B3V_N32, B3V_N64, B3VU_N32, B3VU_N64,
+    B3V_N32, B3V_N64, B3V_N64B, B3VU_N32, B3VU_N64,
     V_COUNT
 };
 }  // namespace

@@ -21,6 +21,8 @@
 
 namespace {
 
+#include "split_fmt.hpp"
+
 struct Bilin {
     int o00, o01, o10, o11;     // plane offsets y*W+x, or -1 when the tap is outside
     float w00, w01, w10, w11;   // weights of (x0,y0), (x0,y1), (x1,y0), (x1,y1)
@@ -429,7 +431,9 @@ __device__ __forceinline__ Bilin quad_bcast(const Bilin& m) {
 #ifndef MVSGI_SWEEP_WAVES
 #define MVSGI_SWEEP_WAVES 5      // waves per SIMD the register allocation aims at (experiment knob; 92 registers -> 5)
 #endif
-template <int NCAM, bool C16>
+// F16: a split-padded output (vol_split) holds fp16 pairs instead of bf16 pairs (csrc/split_fmt.hpp; the variance is >= 0 and clamped
+// to fp16's range)
+template <int NCAM, bool C16, bool F16 = false>
 __global__ __launch_bounds__(256, MVSGI_SWEEP_WAVES) void sweep_std_nhwc_v_kernel(const float* __restrict__ feats,
                                                                const float* __restrict__ grids,
                                                                const unsigned char* __restrict__ vmask,
@@ -604,12 +608,19 @@ __global__ __launch_bounds__(256, MVSGI_SWEEP_WAVES) void sweep_std_nhwc_v_kerne
                 unsigned hi[2], lo[2];
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
-                    const f32x2_t v = {r[2 * p], r[2 * p + 1]};
-                    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2_t));
-                    const f32x2_t hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
-                    hi[p] = hb;
-                    lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, b2_t));
+                    if constexpr (F16) {
+                        const float a_ = sf_clamp<true>(r[2 * p]), b_ = sf_clamp<true>(r[2 * p + 1]);
+                        const unsigned hb = sf_cvt_pk<true>(a_, b_);
+                        hi[p] = hb;
+                        lo[p] = sf_cvt_pk<true>(a_ - sf_widen_lo<true>(hb), b_ - sf_widen_hi<true>(hb));
+                    } else {
+                        typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+                        const f32x2_t v = {r[2 * p], r[2 * p + 1]};
+                        const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2_t));
+                        const f32x2_t hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+                        hi[p] = hb;
+                        lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, b2_t));
+                    }
                 }
                 // even lanes keep their hi and take the odd neighbour's hi; odd lanes take the even neighbour's lo
                 const bool odd = (q & 1) != 0;
@@ -811,7 +822,8 @@ extern "C" int mvsgi_sweep_validity_u8(const float* grids, const void* grid_mask
 namespace {
 int sweep_std_nhwc_valid_impl(const float* feats, const float* grids, const unsigned char* vmask, float* vol, int B, int N, int C,
                               int Hi, int Wi, int D, int Ho, int Wo, int rig_shared, mvsgi_stream_t stream,
-                              unsigned char* vol_split = nullptr) {
+                              unsigned char* vol_split = nullptr, int fmt = 0) {
+    MVSGI_REQUIRE(fmt == 0 || (fmt == MVSGI_SPLIT_F16 && vol_split), "mvsgi_sweep_std_nhwc_valid_split: fmt %d not in {0, MVSGI_SPLIT_F16}", fmt);
     SweepDims s{B, N, C, Hi, Wi, 1, 1, D, Ho, Wo};
     if (check_dims(s, "mvsgi_sweep_std_nhwc_valid_f32")) return 1;
     MVSGI_REQUIRE(feats && grids && vmask && (vol || vol_split), "mvsgi_sweep_std_nhwc_valid_f32: null pointer");
@@ -834,6 +846,15 @@ int sweep_std_nhwc_valid_impl(const float* feats, const float* grids, const unsi
                   "mvsgi_sweep_std_nhwc_valid_f32: dimensions exceed the launch geometry (image bytes < 2^31, row bytes < 2^23)");
     hipStream_t st = mvsgi::as_stream(stream);
     const dim3 grid((unsigned)nblk), block(256);
+    if (fmt) {      // split-padded output in the fp16 split (C == 16 checked above)
+        switch (N) {
+            case 1: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1, true, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split); break;
+            case 2: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<2, true, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split); break;
+            case 3: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<3, true, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split); break;
+            case 4: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<4, true, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split); break;
+        }
+        return mvsgi::check_launch("mvsgi_sweep_std_nhwc_valid_split");
+    }
     switch (N) {
         case 1: if (C == 16) hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
                 else hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1, false>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
@@ -866,6 +887,13 @@ extern "C" int mvsgi_sweep_std_nhwc_valid_split(const float* feats, const float*
     MVSGI_REQUIRE(rig_batch == 1 || rig_batch == B, "mvsgi_sweep_std_nhwc_valid_split: rig_batch %d not in {1, B}", rig_batch);
     return sweep_std_nhwc_valid_impl(feats, grids, vmask, nullptr, B, N, C, Hi, Wi, D, Ho, Wo, rig_batch == 1 && B > 1 ? 1 : 0, stream,
                                      static_cast<unsigned char*>(vol_split));
+}
+extern "C" int mvsgi_sweep_std_nhwc_valid_split_fmt(const float* feats, const float* grids, const unsigned char* vmask,
+                                                    void* vol_split, int B, int N, int C, int Hi, int Wi, int D, int Ho, int Wo,
+                                                    int rig_batch, int fmt, mvsgi_stream_t stream) {
+    MVSGI_REQUIRE(rig_batch == 1 || rig_batch == B, "mvsgi_sweep_std_nhwc_valid_split: rig_batch %d not in {1, B}", rig_batch);
+    return sweep_std_nhwc_valid_impl(feats, grids, vmask, nullptr, B, N, C, Hi, Wi, D, Ho, Wo, rig_batch == 1 && B > 1 ? 1 : 0, stream,
+                                     static_cast<unsigned char*>(vol_split), fmt);
 }
 
 // The same with ONE rig for the whole batch: grids [1][N][D][Ho][Wo][2], vmask [1][D][Ho][Wo] (frame-independent rig

@@ -115,14 +115,40 @@ class ConvLaunch:
             self.wp_rs = H.pack_conv_weights_rs(self.w)
         return self.wp_rs
 
+    def _rs(self, fmt: str):
+        """(packed weights, per-channel scale) of the register-stationary kernels in the split `fmt` of the activations."""
+        if fmt == "bf16":
+            return self._wp_rs(), self.scale
+        if self.f16 is None:
+            self.f16 = {}
+        if "rs" not in self.f16:
+            wp, unscale = H.pack_conv_weights_rs(self.w, "f16")
+            self.f16["rs"] = (wp, (self.scale * unscale).contiguous())
+        return self.f16["rs"]
+
+    def _b3(self, fmt: str):
+        """(packed weights, per-channel scale) of the streaming split kernel (generic layout) in the split `fmt`."""
+        return (self._wp_b3(), self.scale) if fmt == "bf16" else self._f16(H.CONV_BF16X3)
+
     def s2rs_ok(self) -> bool:
         """The stride-2 16 -> 32 kernel on split-padded activations (csrc/conv3d_s2rs.hip) serves this layer."""
-        return H.get_conv_mode() == "bf16x3" and H.conv3d_s2rs_applies(self.cin, self.cout, self.stride, self.neg_slope)
+        return H.split_mode() and H.conv3d_s2rs_applies(self.cin, self.cout, self.stride, self.neg_slope)
 
     def _wp_s2(self):
         if self.wp_s2 is None:
             self.wp_s2 = H.pack_conv_weights_s2rs(self.w, self.scale)
         return self.wp_s2
+
+    def _s2(self, fmt: str):
+        """(packed weights with the scale folded in, shift, unscale) of the stride-2 kernel on split-padded activations."""
+        if fmt == "bf16":
+            return self._wp_s2(), self.shift, 1.0
+        if self.f16 is None:
+            self.f16 = {}
+        if "s2" not in self.f16:
+            wp, up, un = H.pack_conv_weights_s2rs(self.w, self.scale, "f16")
+            self.f16["s2"] = (wp, (self.shift * up).contiguous(), un)
+        return self.f16["s2"]
 
     def _wp_v32(self):
         if self.wp_v32 is None:
@@ -131,15 +157,20 @@ class ConvLaunch:
 
     def poly_ok(self) -> bool:
         """ResizeConv3d in polyphase form on the register-stationary kernel (csrc/conv3d_up2poly.hip)."""
-        return H.get_conv_mode() == "bf16x3" and self.stride == 1 and H.conv3d_up2_poly_applies(self.cin, self.cout, self.neg_slope)
+        return H.split_mode() and self.stride == 1 and H.conv3d_up2_poly_applies(self.cin, self.cout, self.neg_slope)
 
-    def _poly_plan(self, D: int, Hh: int, W: int):
-        """Folded phase weights + face tables for a low-resolution input of D x Hh x W (built once per size, kept)."""
+    def _poly_plan(self, D: int, Hh: int, W: int, fmt: str = "bf16"):
+        """(folded phase weights + face tables for a low-resolution input of D x Hh x W in the split `fmt`, the layer's scale):
+        built once per size and split, kept."""
         if self.wp_poly is None:
             self.wp_poly = {}
-        k = (int(D), int(Hh), int(W))
+        k = (int(D), int(Hh), int(W), fmt)
         if k not in self.wp_poly:
-            self.wp_poly[k] = H.conv3d_up2_poly_plan(self.w, *k)
+            if fmt == "f16":
+                plan, unscale = H.conv3d_up2_poly_plan(self.w, *k[:3], fmt="f16")
+                self.wp_poly[k] = (plan, (self.scale * unscale).contiguous())
+            else:
+                self.wp_poly[k] = (H.conv3d_up2_poly_plan(self.w, *k[:3]), self.scale)
         return self.wp_poly[k]
 
     def head_split_ok(self) -> bool:
@@ -161,12 +192,12 @@ class ConvLaunch:
         return H.conv3d_head_split(x_split, self.wp_head, self.head_sc[0], self.head_sc[1], neg_slope=self.neg_slope)
 
     def run_up2_poly_split(self, x_split, out) -> "H.SplitAct":
-        return H.conv3d_up2_poly_split(x_split, self._poly_plan(x_split.D, x_split.H, x_split.W), self.scale, self.shift, out=out,
-                                       neg_slope=self.neg_slope)
+        plan, sc = self._poly_plan(x_split.D, x_split.H, x_split.W, x_split.fmt)
+        return H.conv3d_up2_poly_split(x_split, plan, sc, self.shift, out=out, neg_slope=self.neg_slope)
 
     def run_up2_poly(self, x_split, out=None) -> Tensor:
-        return H.conv3d_up2_poly(x_split, self._poly_plan(x_split.D, x_split.H, x_split.W), self.scale, self.shift,
-                                 neg_slope=self.neg_slope, out=out)
+        plan, sc = self._poly_plan(x_split.D, x_split.H, x_split.W, x_split.fmt)
+        return H.conv3d_up2_poly(x_split, plan, sc, self.shift, neg_slope=self.neg_slope, out=out)
 
     def run_up2_split(self, x_lowres_ndhwc: Tensor, res: Optional[Tensor], out) -> "H.SplitAct":
         """conv(trilinear_x2(x)) (+ res) written split-padded into `out` (the polyphase layer's input, the split head's input)."""

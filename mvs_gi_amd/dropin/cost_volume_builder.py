@@ -97,7 +97,7 @@ def std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=None, split_out: bool
         full = _owned_split_buffer(owner, "_mvsgi_rs_vol", (nb, D, Ho, Wo, feats.device),
                                    lambda: H.SplitAct(nb, D, Ho, Wo, 16, feats.device))
         out = full if nb == B else H.SplitAct(B, D, Ho, Wo, 16, feats.device, buf=full.buf[:B])
-        return H.sweep_std_valid_split(feats, g_use, cached[2], out=out)
+        return H.sweep_std_valid_split(feats, g_use, cached[2], out=out, fmt=H.mode_fmt())
     return H.sweep_std_valid(feats, g_use, cached[2])
 
 
@@ -119,12 +119,13 @@ def _std_front(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Te
     regulator's stride-2 first layer stages by LDS-DMA (csrc/conv3d_s2rs.hip) -- or None when the layer shapes / mode do not
     put post_vol on that kernel."""
     L = cm.lower_conv_block(self.post_vol)
-    if not (_USE_RS and H.get_conv_mode() == "bf16x3" and L.cin == 16 and L.cout == 16 and L.stride == 1
+    if not (_USE_RS and H.split_mode() and L.cin == 16 and L.cout == 16 and L.stride == 1
             and 0.0 <= L.neg_slope <= 1.0 and feats.dim() == 5 and feats.shape[2] == 16 and grids.dim() == 6):
         return None
     B, D, Ho, Wo = feats.shape[0], grids.shape[2], grids.shape[3], grids.shape[4]
     if not (B * ((D + 3) // 4) * ((Ho + 3) // 4) * ((Wo + 15) // 16) >= _RS_MIN_UNITS and _rig_cache_usable(self, feats, grids)):
         return None
+    wp_rs, sc_rs = L._rs(H.mode_fmt())      # post_vol's weights / scale in the split the sweep writes
     xs = None
     if hand_over_split:      # one buffer per shape, never replaced while the module lives (a captured hipGraph holds the address)
         xs = _owned_split_buffer(self, "_mvsgi_rs_x0", (B, D, Ho, Wo, feats.device), lambda: H.SplitAct(B, D, Ho, Wo, 16, feats.device))
@@ -138,15 +139,17 @@ def _std_front(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Te
             j = min(i + k, B)
             vs = std_sweep_ndhwc(feats[i:j], grids, grid_masks, masks, owner=self, split_out=True, buf_frames=k)    # the rig tensors whole: cache identity
             if hand_over_split:
-                H.conv3d_rs16(vs, L._wp_rs(), L.scale, L.shift, neg_slope=L.neg_slope,
+                H.conv3d_rs16(vs, wp_rs, sc_rs, L.shift, neg_slope=L.neg_slope,
                               out_split=H.SplitAct(j - i, D, Ho, Wo, 16, feats.device, buf=xs.buf[i:j]))
             else:
-                H.conv3d_rs16(vs, L._wp_rs(), L.scale, L.shift, neg_slope=L.neg_slope, out=y[i:j])
+                H.conv3d_rs16(vs, wp_rs, sc_rs, L.shift, neg_slope=L.neg_slope, out=y[i:j])
+        if hand_over_split:
+            xs.fmt = H.mode_fmt()      # written chunk by chunk through views
         return xs if hand_over_split else y
     vs = std_sweep_ndhwc(feats, grids, grid_masks, masks, owner=self, split_out=True)
     if hand_over_split:
-        return H.conv3d_rs16(vs, L._wp_rs(), L.scale, L.shift, neg_slope=L.neg_slope, out_split=xs)
-    return H.conv3d_rs16(vs, L._wp_rs(), L.scale, L.shift, neg_slope=L.neg_slope)
+        return H.conv3d_rs16(vs, wp_rs, sc_rs, L.shift, neg_slope=L.neg_slope, out_split=xs)
+    return H.conv3d_rs16(vs, wp_rs, sc_rs, L.shift, neg_slope=L.neg_slope)
 
 
 def std_forward(self, feats: Tensor, grids: Tensor, grid_masks: Tensor, masks: Tensor) -> Tensor:

@@ -43,7 +43,7 @@ _RS_MIN_UNITS = int(H.exp_env("MVSGI_RS_MIN_UNITS", "0"))      # measured faster
 def _rs_chain(blk, x: Tensor):
     """The residual convs of a UNetDownBlk as launch records if ALL of them can run register-stationary on split-padded
     activations (32 -> 32 channels: UNet level 0 of the (16, 32) regulator), else None."""
-    if not (_USE_RS and H.get_conv_mode() == "bf16x3" and len(blk.blks) > 0):
+    if not (_USE_RS and H.split_mode() and len(blk.blks) > 0):
         return None
     L0 = cm.lower_conv_block(blk.first)
     if L0.cin % 16 or L0.cout != 32:
@@ -75,18 +75,24 @@ def _down_block_rs(blk, x: Tensor, L0, chain, dims) -> Tensor:
     if key not in sets:
         sets[key] = [H.SplitAct(B, Do, Ho, Wo, 32, x.device) for _ in range(3)]
     b = sets[key]
+    fmt = H.mode_fmt()              # the split of this chain's activations and weights (the library's mode)
     if isinstance(x, H.SplitAct):      # the builder handed post_vol's output over split-padded: staged by LDS-DMA (csrc/conv3d_s2rs.hip)
-        H.conv3d_s2rs(x, L0._wp_s2(), L0.shift, out=b[0], neg_slope=L0.neg_slope)
+        if x.fmt != fmt:
+            raise RuntimeError(f"split-padded cost volume holds {x.fmt} pieces, the library's mode writes {fmt}")
+        wp0, sh0, un0 = L0._s2(fmt)
+        H.conv3d_s2rs(x, wp0, sh0, out=b[0], neg_slope=L0.neg_slope, unscale=un0)
     else:
-        H.conv3d_out_split(x, L0._wp_b3(), L0.scale, L0.shift, out=b[0], stride=L0.stride, neg_slope=L0.neg_slope)
+        wp0, sc0 = L0._b3(fmt)
+        H.conv3d_out_split(x, wp0, sc0, L0.shift, out=b[0], stride=L0.stride, neg_slope=L0.neg_slope, fmt=fmt)
     cur, out = 0, None
     for i, (L1, L2) in enumerate(chain):
         r, y = (cur + 1) % 3, (cur + 2) % 3
-        H.conv3d_rs(b[cur], L1._wp_rs(), L1.scale, L1.shift, neg_slope=L1.neg_slope, out=b[r])
+        (wp1, sc1), (wp2, sc2) = L1._rs(fmt), L2._rs(fmt)
+        H.conv3d_rs(b[cur], wp1, sc1, L1.shift, neg_slope=L1.neg_slope, out=b[r])
         if i == len(chain) - 1:
-            out = H.conv3d_rs(b[r], L2._wp_rs(), L2.scale, L2.shift, res=b[cur], neg_slope=L2.neg_slope, out_f32=True)
+            out = H.conv3d_rs(b[r], wp2, sc2, L2.shift, res=b[cur], neg_slope=L2.neg_slope, out_f32=True)
         else:
-            H.conv3d_rs(b[r], L2._wp_rs(), L2.scale, L2.shift, res=b[cur], neg_slope=L2.neg_slope, out=b[y])
+            H.conv3d_rs(b[r], wp2, sc2, L2.shift, res=b[cur], neg_slope=L2.neg_slope, out=b[y])
             cur = y
     return out
 
@@ -108,7 +114,7 @@ def regulator_takes_split(self, shape) -> bool:
     """True when forward_split_in() can take a split-padded cost volume of geometry `shape` = (B, D, H, W, C): the (16, 32)
     regulator in split-bf16 mode, whose first layer (16 -> 32, stride 2) then stages pre-split voxels by LDS-DMA and whose
     level-0 residual blocks run register-stationary."""
-    if not (_USE_S2RS and H.get_conv_mode() == "bf16x3" and len(self.down_blks) > 0 and len(shape) == 5 and shape[4] == 16
+    if not (_USE_S2RS and H.split_mode() and len(self.down_blks) > 0 and len(shape) == 5 and shape[4] == 16
             and shape[0] >= _S2RS_MIN_FRAMES):
         return False
     blk = self.down_blks[0]

@@ -14,6 +14,7 @@ from . import _lib
 import os
 
 CONV_AUTO, CONV_DIRECT, CONV_MFMA, CONV_BF16X3, CONV_BF16X3_C16, CONV_BF16X3_V32 = 0, 1, 2, 3, 4, 5
+SPLIT_F16 = 1          # `fmt` of the *_fmt entry points (include/mvsgi.h MVSGI_SPLIT_F16): split-padded data / weights hold fp16 pairs
 CONV_F16 = 0x100       # flag OR-ed into CONV_BF16X3 / _C16 / _V32: the same kernel in the fp16 split (include/mvsgi.h MVSGI_CONV_F16)
 
 # Arithmetic of the conv layers:
@@ -58,6 +59,23 @@ def get_conv_mode() -> str:
 def split_mode() -> bool:
     """The library's mode is one of the two 16-bit splits (the streaming split kernels serve the layer)."""
     return _CONV_MODE in ("bf16x3", "f16x3")
+
+
+def mode_fmt() -> str:
+    """Element type of the (hi | lo) pieces the library's mode writes into split-padded buffers."""
+    return "f16" if _CONV_MODE == "f16x3" else "bf16"
+
+
+def _fmt_code(fmt: str) -> int:
+    if fmt not in ("bf16", "f16"):
+        raise ValueError(f"split format {fmt!r} not in ('bf16', 'f16')")
+    return SPLIT_F16 if fmt == "f16" else 0
+
+
+def _pow2_unscale(amax: torch.Tensor):
+    """k per entry such that amax * 2^k lies in [512, 1024) (0 for a zero entry) -> (2^k, 2^-k) as fp32 tensors."""
+    k = torch.where(amax > 0, torch.floor(torch.log2(1024.0 / amax.clamp_min(1e-37))), torch.zeros_like(amax)).clamp(-100.0, 100.0)
+    return torch.exp2(k), torch.exp2(-k)
 
 
 def _stream_ptr(t: torch.Tensor) -> int:
@@ -147,8 +165,8 @@ def sweep_std_valid(feats, grids, vmask) -> torch.Tensor:
     return vol
 
 
-def sweep_std_valid_split(feats, grids, vmask, out: "SplitAct") -> "SplitAct":
-    """sweep_std_valid with vol_raw written split-padded (C == 16) into `out` (B, D, Ho, Wo, 16)."""
+def sweep_std_valid_split(feats, grids, vmask, out: "SplitAct", fmt: str = "bf16") -> "SplitAct":
+    """sweep_std_valid with vol_raw written split-padded (C == 16) into `out` (B, D, Ho, Wo, 16), its pieces in the split `fmt`."""
     lib = _lib.load()
     B, N, C, Hi, Wi = feats.shape
     f = _feats_nhwc(feats)
@@ -159,8 +177,9 @@ def sweep_std_valid_split(feats, grids, vmask, out: "SplitAct") -> "SplitAct":
         raise AssertionError(f"grids {tuple(grids.shape)} / vmask {tuple(vmask.shape)} do not match feats {tuple(feats.shape)}")
     if out.shape != (B, D, Ho, Wo, C):
         raise AssertionError(f"split output {out.shape} does not match {(B, D, Ho, Wo, C)}")
-    _lib.check(lib.mvsgi_sweep_std_nhwc_valid_split(f.data_ptr(), grids.data_ptr(), vmask.data_ptr(), out.buf.data_ptr(), B, N, C, Hi,
-                                                    Wi, D, Ho, Wo, Bg, _stream_ptr(f)), "mvsgi_sweep_std_nhwc_valid_split")
+    _lib.check(lib.mvsgi_sweep_std_nhwc_valid_split_fmt(f.data_ptr(), grids.data_ptr(), vmask.data_ptr(), out.buf.data_ptr(), B, N, C, Hi,
+                                                        Wi, D, Ho, Wo, Bg, _fmt_code(fmt), _stream_ptr(f)), "mvsgi_sweep_std_nhwc_valid_split")
+    out.fmt = fmt
     return out
 
 
@@ -401,9 +420,11 @@ def conv3d_up2_poly_applies(cin: int, cout: int, neg_slope: float) -> bool:
     return cin == 32 and cout == 16 and 0.0 <= neg_slope <= 1.0
 
 
-def conv3d_up2_poly_plan(w_oidhw: torch.Tensor, D: int, H: int, W: int) -> torch.Tensor:
+def conv3d_up2_poly_plan(w_oidhw: torch.Tensor, D: int, H: int, W: int, fmt: str = "bf16"):
     """Lowering of a [16, 32, 3, 3, 3] ResizeConv3d weight for a low-resolution input of D x H x W voxels: folded phase weights in
-    the register-stationary layout, face-correction weights and role tables (built on the host by the library, float64)."""
+    the register-stationary layout, face-correction weights and role tables (built on the host by the library, float64).
+    fmt = 'f16': the plan in the fp16 split -> (plan, unscale [16]): the weights are pre-scaled per output channel by a power of two
+    (the folded phase weights are linear in them) and `unscale` goes into the layer's scale."""
     lib = _lib.load()
     if tuple(w_oidhw.shape) != (16, 32, 3, 3, 3):
         raise AssertionError(f"polyphase plan needs a [16, 32, 3, 3, 3] weight, got {tuple(w_oidhw.shape)}")
@@ -411,9 +432,15 @@ def conv3d_up2_poly_plan(w_oidhw: torch.Tensor, D: int, H: int, W: int) -> torch
     if not n:
         raise RuntimeError("mvsgi_conv3d_up2_poly_plan_bytes: bad dims")
     wh = w_oidhw.detach().to("cpu", torch.float32).contiguous()
+    unscale = None
+    if fmt == "f16":
+        up, un = _pow2_unscale(wh.abs().amax(dim=(1, 2, 3, 4)))
+        wh = (wh * up.view(-1, 1, 1, 1, 1)).contiguous()
+        unscale = un.to(w_oidhw.device)
     plan = torch.empty(n, dtype=torch.uint8)
-    _lib.check(lib.mvsgi_conv3d_up2_poly_plan(wh.data_ptr(), plan.data_ptr(), D, H, W), "mvsgi_conv3d_up2_poly_plan")
-    return plan.to(w_oidhw.device)
+    _lib.check(lib.mvsgi_conv3d_up2_poly_plan_fmt(wh.data_ptr(), plan.data_ptr(), D, H, W, _fmt_code(fmt)), "mvsgi_conv3d_up2_poly_plan")
+    plan = plan.to(w_oidhw.device)
+    return (plan, unscale) if fmt == "f16" else plan
 
 
 def conv3d_up2_poly(x: "SplitAct", plan: torch.Tensor, scale, shift, neg_slope=0.01, out=None) -> torch.Tensor:
@@ -426,8 +453,9 @@ def conv3d_up2_poly(x: "SplitAct", plan: torch.Tensor, scale, shift, neg_slope=0
     y = out if out is not None else torch.empty(shp, device=x.buf.device, dtype=torch.float32)
     if tuple(y.shape) != shp or not y.is_contiguous():
         raise AssertionError(f"output {tuple(y.shape)} does not match {shp}")
-    _lib.check(lib.mvsgi_conv3d_up2_poly_f32(x.buf.data_ptr(), plan.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(),
-                                             x.B, x.D, x.H, x.W, float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_up2_poly_f32")
+    _lib.check(lib.mvsgi_conv3d_up2_poly_fmt(x.buf.data_ptr(), plan.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), 0,
+                                             x.B, x.D, x.H, x.W, float(neg_slope), _fmt_code(x.fmt), _stream_ptr(x.buf)),
+               "mvsgi_conv3d_up2_poly_f32")
     return y
 
 
@@ -436,8 +464,10 @@ def conv3d_up2_poly_split(x: "SplitAct", plan: torch.Tensor, scale, shift, out: 
     lib = _lib.load()
     if x.C != 32 or scale.numel() != 16 or out.shape != (x.B, 2 * x.D, 2 * x.H, 2 * x.W, 16):
         raise AssertionError(f"conv3d_up2_poly_split: input {x.shape}, output {out.shape}")
-    _lib.check(lib.mvsgi_conv3d_up2_poly_split(x.buf.data_ptr(), plan.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.buf.data_ptr(),
-                                               x.B, x.D, x.H, x.W, float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_up2_poly_split")
+    _lib.check(lib.mvsgi_conv3d_up2_poly_fmt(x.buf.data_ptr(), plan.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.buf.data_ptr(), 1,
+                                             x.B, x.D, x.H, x.W, float(neg_slope), _fmt_code(x.fmt), _stream_ptr(x.buf)),
+               "mvsgi_conv3d_up2_poly_split")
+    out.fmt = x.fmt
     return out
 
 
@@ -525,37 +555,45 @@ class SplitAct:
         return self.buf.device
 
 
-def act_to_split(x_ndhwc: torch.Tensor, out: Optional[SplitAct] = None) -> SplitAct:
+def act_to_split(x_ndhwc: torch.Tensor, out: Optional[SplitAct] = None, fmt: str = "bf16") -> SplitAct:
     lib = _lib.load()
     x = _dev(x_ndhwc, "x")
     B, D, Hh, W, C = x.shape
     y = out if out is not None else SplitAct(B, D, Hh, W, C, x.device)
     if y.shape != (B, D, Hh, W, C):
         raise AssertionError(f"split buffer {y.shape} does not match {tuple(x.shape)}")
-    _lib.check(lib.mvsgi_act_f32_to_split(x.data_ptr(), y.buf.data_ptr(), B, C, D, Hh, W, _stream_ptr(x)), "mvsgi_act_f32_to_split")
+    _lib.check(lib.mvsgi_act_f32_to_split_fmt(x.data_ptr(), y.buf.data_ptr(), B, C, D, Hh, W, _fmt_code(fmt), _stream_ptr(x)),
+               "mvsgi_act_f32_to_split")
+    y.fmt = fmt
     return y
 
 
 def act_from_split(x: SplitAct, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
     y = out if out is not None else torch.empty(x.shape, device=x.buf.device, dtype=torch.float32)
-    _lib.check(lib.mvsgi_act_split_to_f32(x.buf.data_ptr(), y.data_ptr(), x.B, x.C, x.D, x.H, x.W, _stream_ptr(x.buf)),
+    _lib.check(lib.mvsgi_act_split_to_f32_fmt(x.buf.data_ptr(), y.data_ptr(), x.B, x.C, x.D, x.H, x.W, _fmt_code(x.fmt), _stream_ptr(x.buf)),
                "mvsgi_act_split_to_f32")
     return y
 
 
-def pack_conv_weights_rs(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
-    """[32, 32, 3, 3, 3] or [16, 16, 3, 3, 3] -> register-stationary layout (tap pairs in the kernel's own order), or None."""
+def pack_conv_weights_rs(w_oidhw: torch.Tensor, fmt: str = "bf16"):
+    """[32, 32, 3, 3, 3] or [16, 16, 3, 3, 3] -> register-stationary layout (tap pairs in the kernel's own order), or None.
+    fmt = 'f16': -> (packed weights of the fp16 split, unscale [Cout]) with the per-channel power-of-two pre-scaling of
+    pack_conv_weights_f16x3."""
     lib = _lib.load()
     w = _dev(w_oidhw, "conv weight")
+    unscale = None
+    if fmt == "f16":
+        up, unscale = _pow2_unscale(w.abs().amax(dim=(1, 2, 3, 4)))
+        w = (w * up.view(-1, 1, 1, 1, 1)).contiguous()
     Cout, Cin = w.shape[:2]
     nbytes = lib.mvsgi_conv3d_rs_packed_weight_bytes(Cout, Cin) if tuple(w.shape[2:]) == (3, 3, 3) else 0
     if not nbytes:
         return None
     wp = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
-    _lib.check(lib.mvsgi_conv3d_rs_pack_weights(w.data_ptr(), wp.data_ptr(), Cout, Cin, _stream_ptr(w)),
+    _lib.check(lib.mvsgi_conv3d_rs_pack_weights_fmt(w.data_ptr(), wp.data_ptr(), Cout, Cin, _fmt_code(fmt), _stream_ptr(w)),
                "mvsgi_conv3d_rs_pack_weights")
-    return wp
+    return (wp, unscale.contiguous()) if fmt == "f16" else wp
 
 
 def conv3d_rs(x: SplitAct, w_packed_rs, scale, shift, res: Optional[SplitAct] = None, neg_slope=0.01,
@@ -574,16 +612,19 @@ def conv3d_rs(x: SplitAct, w_packed_rs, scale, shift, res: Optional[SplitAct] = 
         yp = y.buf.data_ptr()
         if y.shape != (x.B, x.D, x.H, x.W, Cout):
             raise AssertionError(f"split output {y.shape} does not match {(x.B, x.D, x.H, x.W, Cout)}")
-    if res is not None and res.shape != (x.B, x.D, x.H, x.W, Cout):
-        raise AssertionError(f"residual {res.shape} does not match the output")
-    _lib.check(lib.mvsgi_conv3d_rs_split(x.buf.data_ptr(), w_packed_rs.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                         None if res is None else res.buf.data_ptr(), yp, int(out_f32), x.B, x.C, x.D, x.H,
-                                         x.W, Cout, float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_rs_split")
+    if res is not None and (res.shape != (x.B, x.D, x.H, x.W, Cout) or res.fmt != x.fmt):
+        raise AssertionError(f"residual {res.shape} ({res.fmt}) does not match the output ({x.fmt})")
+    _lib.check(lib.mvsgi_conv3d_rs_split_fmt(x.buf.data_ptr(), w_packed_rs.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                             None if res is None else res.buf.data_ptr(), yp, int(out_f32), x.B, x.C, x.D, x.H,
+                                             x.W, Cout, float(neg_slope), _fmt_code(x.fmt), _stream_ptr(x.buf)), "mvsgi_conv3d_rs_split")
+    if not out_f32:
+        y.fmt = x.fmt
     return y
 
 
-def conv3d_out_split(x, w_packed_b3, scale, shift, out: "SplitAct", res=None, stride=1, neg_slope=0.01) -> "SplitAct":
-    """mvsgi_conv3d_f32 (split-bf16 streaming kernel) with the output written split-padded into `out`."""
+def conv3d_out_split(x, w_packed_b3, scale, shift, out: "SplitAct", res=None, stride=1, neg_slope=0.01, fmt: str = "bf16") -> "SplitAct":
+    """mvsgi_conv3d_f32 (streaming split kernel) with the output written split-padded into `out`; fmt = 'f16': weights packed by
+    pack_conv_weights_f16x3 (scale carrying the unscale) and the output in the fp16 split."""
     lib = _lib.load()
     x = _dev(x, "x")
     B, Din, Hin, Win, Cin = x.shape
@@ -593,9 +634,10 @@ def conv3d_out_split(x, w_packed_b3, scale, shift, out: "SplitAct", res=None, st
         raise AssertionError(f"split output {out.shape} does not match {(B, Do, Ho, Wo, Cout)}")
     if res is not None:
         res = _dev(res, "res")
-    _lib.check(lib.mvsgi_conv3d_f32_out_split(x.data_ptr(), w_packed_b3.data_ptr(), scale.data_ptr(), shift.data_ptr(), _ptr(res),
-                                              out.buf.data_ptr(), B, Cin, Din, Hin, Win, Cout, stride, float(neg_slope),
-                                              _stream_ptr(x)), "mvsgi_conv3d_f32_out_split")
+    _lib.check(lib.mvsgi_conv3d_f32_out_split_fmt(x.data_ptr(), w_packed_b3.data_ptr(), scale.data_ptr(), shift.data_ptr(), _ptr(res),
+                                                  out.buf.data_ptr(), B, Cin, Din, Hin, Win, Cout, stride, float(neg_slope),
+                                                  _fmt_code(fmt), _stream_ptr(x)), "mvsgi_conv3d_f32_out_split")
+    out.fmt = fmt
     return out
 
 
@@ -608,13 +650,15 @@ def conv3d_rs16(x: "SplitAct", w_packed_rs, scale, shift, neg_slope=0.01, out=No
     if out_split is not None:
         if out_split.shape != x.shape or out_split.buf.data_ptr() == x.buf.data_ptr():
             raise AssertionError(f"split output {out_split.shape} must match the input {x.shape} and be another buffer")
-        _lib.check(lib.mvsgi_conv3d_rs16_split_out_split(x.buf.data_ptr(), w_packed_rs.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                                         out_split.buf.data_ptr(), x.B, x.D, x.H, x.W, float(neg_slope),
-                                                         _stream_ptr(x.buf)), "mvsgi_conv3d_rs16_split_out_split")
+        _lib.check(lib.mvsgi_conv3d_rs16_split_fmt(x.buf.data_ptr(), w_packed_rs.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                   out_split.buf.data_ptr(), 1, x.B, x.D, x.H, x.W, float(neg_slope), _fmt_code(x.fmt),
+                                                   _stream_ptr(x.buf)), "mvsgi_conv3d_rs16_split_out_split")
+        out_split.fmt = x.fmt
         return out_split
     y = out if out is not None else torch.empty((x.B, x.D, x.H, x.W, 16), device=x.buf.device, dtype=torch.float32)
-    _lib.check(lib.mvsgi_conv3d_rs16_split(x.buf.data_ptr(), w_packed_rs.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(),
-                                           x.B, x.D, x.H, x.W, float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_rs16_split")
+    _lib.check(lib.mvsgi_conv3d_rs16_split_fmt(x.buf.data_ptr(), w_packed_rs.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), 0,
+                                               x.B, x.D, x.H, x.W, float(neg_slope), _fmt_code(x.fmt), _stream_ptr(x.buf)),
+               "mvsgi_conv3d_rs16_split")
     return y
 
 
@@ -622,27 +666,36 @@ def conv3d_s2rs_applies(cin: int, cout: int, stride: int, neg_slope: float) -> b
     return cin == 16 and cout == 32 and stride == 2 and 0.0 <= neg_slope <= 1.0
 
 
-def pack_conv_weights_s2rs(w_oidhw: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
-    """[32, 16, 3, 3, 3] weights with the per-channel scale folded in, in the lane order of csrc/conv3d_s2rs.hip."""
+def pack_conv_weights_s2rs(w_oidhw: torch.Tensor, scale: torch.Tensor, fmt: str = "bf16"):
+    """[32, 16, 3, 3, 3] weights with the per-channel scale folded in, in the lane order of csrc/conv3d_s2rs.hip.
+    fmt = 'f16': -> (packed weights, up, unscale): the kernel's epilogue has no per-channel multiplier, so ONE power of two `up` for
+    the layer (the largest |weight * scale| in [512, 1024)) is folded into the packed weights; the caller multiplies `shift` by `up`
+    and passes `unscale` = 1 / up to conv3d_s2rs."""
     lib = _lib.load()
     w = _dev(w_oidhw, "w")
     scale = _dev(scale, "scale")
     if tuple(w.shape) != (32, 16, 3, 3, 3) or scale.numel() != 32:
         raise AssertionError(f"conv3d_s2rs is the 16 -> 32 channel stride-2 layer, got weights {tuple(w.shape)}")
+    up = un = None
+    if fmt == "f16":
+        up_t, un_t = _pow2_unscale((w.abs().amax(dim=(1, 2, 3, 4)) * scale.abs()).max().reshape(1))
+        up, un = float(up_t[0]), float(un_t[0])
+        scale = (scale * up).contiguous()
     wp = torch.empty(lib.mvsgi_conv3d_s2rs_packed_weight_bytes(), device=w.device, dtype=torch.uint8)
-    _lib.check(lib.mvsgi_conv3d_s2rs_pack_weights(w.data_ptr(), scale.data_ptr(), wp.data_ptr(), _stream_ptr(w)),
+    _lib.check(lib.mvsgi_conv3d_s2rs_pack_weights_fmt(w.data_ptr(), scale.data_ptr(), wp.data_ptr(), _fmt_code(fmt), _stream_ptr(w)),
                "mvsgi_conv3d_s2rs_pack_weights")
-    return wp
+    return (wp, up, un) if fmt == "f16" else wp
 
 
-def conv3d_s2rs(x: "SplitAct", w_packed, shift, out: "SplitAct", neg_slope=0.01) -> "SplitAct":
+def conv3d_s2rs(x: "SplitAct", w_packed, shift, out: "SplitAct", neg_slope=0.01, unscale: float = 1.0) -> "SplitAct":
     """16 -> 32 channel 3x3x3 stride-2 conv + scale / shift + LeakyReLU, split-padded in and out (LDS-DMA staging)."""
     lib = _lib.load()
     Do, Ho, Wo = (x.D - 1) // 2 + 1, (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
     if x.C != 16 or out.shape != (x.B, Do, Ho, Wo, 32) or shift.numel() != 32:
         raise AssertionError(f"conv3d_s2rs: input {x.shape} -> output {out.shape}, expected {(x.B, Do, Ho, Wo, 32)}")
-    _lib.check(lib.mvsgi_conv3d_s2rs(x.buf.data_ptr(), w_packed.data_ptr(), shift.data_ptr(), out.buf.data_ptr(), x.B, x.D, x.H, x.W,
-                                     float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_s2rs")
+    _lib.check(lib.mvsgi_conv3d_s2rs_fmt(x.buf.data_ptr(), w_packed.data_ptr(), shift.data_ptr(), out.buf.data_ptr(), x.B, x.D, x.H, x.W,
+                                         float(neg_slope), float(unscale), _fmt_code(x.fmt), _stream_ptr(x.buf)), "mvsgi_conv3d_s2rs")
+    out.fmt = x.fmt
     return out
 
 

@@ -1907,6 +1907,121 @@ def test_cost_head_on_split_padded_input_vs_conv3d(shape):
     assert _rel(y.cpu().numpy(), ref) <= 1e-4
 
 
+# ------------------------------------------------------------------------------ the split-padded kernels in the fp16 split
+def _bn(rng, c):
+    return rng.uniform(0.5, 1.5, c).astype(np.float32), (rng.standard_normal(c) * 0.1).astype(np.float32)
+
+
+def _conv_ref64(xq, wt, sc, sh, slope, stride=1, res=None):
+    """conv3d + scale / shift (+ res) + LeakyReLU in float64 on NDHWC device tensors -> NDHWC numpy."""
+    y = F.conv3d(xq.cpu().double().permute(0, 4, 1, 2, 3), torch.from_numpy(wt).double(), padding=1, stride=stride)
+    y = y * torch.from_numpy(sc).double().view(1, -1, 1, 1, 1) + torch.from_numpy(sh).double().view(1, -1, 1, 1, 1)
+    if res is not None:
+        y = y + res.cpu().double().permute(0, 4, 1, 2, 3)
+    return torch.where(y > 0, y, y * slope).permute(0, 2, 3, 4, 1).float().numpy()
+
+
+def test_split_padded_format_in_the_fp16_split_round_trip_range_and_border():
+    """fp32 -> split-padded fp16 pairs -> fp32: 22 significant bits (the bf16 split keeps 16-17), values beyond +-65504 clamped, never
+    inf / nan, the zero border untouched; a buffer's split is a tag its readers check."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 3, 5, 7, 32), dtype=np.float32) * np.float32(10.0)
+    x[0, 0, 0, 0, :4] = [1e5, -3e9, 65504.0, 6.1e-5]
+    xs16, xsb = H.act_to_split(_g(x), fmt="f16"), H.act_to_split(_g(x))
+    assert xs16.fmt == "f16" and xsb.fmt == "bf16"
+    back16, backb = H.act_from_split(xs16).cpu().numpy(), H.act_from_split(xsb).cpu().numpy()
+    ref = np.clip(x, -65504.0, 65504.0)
+    assert np.isfinite(back16).all()
+    assert np.abs(back16 - ref).max() <= 2.0 ** -21 * np.abs(ref).max() and np.abs(backb - x)[0, 1:].max() > 50 * np.abs(back16 - ref)[0, 1:].max()
+    assert float(back16[0, 0, 0, 0, 0]) == 65504.0 and float(back16[0, 0, 0, 0, 1]) == -65504.0
+    for sl in (xs16.buf[:, 0], xs16.buf[:, -1], xs16.buf[:, :, 0], xs16.buf[:, :, -1], xs16.buf[:, :, :, 0], xs16.buf[:, :, :, -1]):
+        assert int(sl.abs().max()) == 0
+    wp = H.pack_conv_weights_rs(_g((rng.standard_normal((32, 32, 3, 3, 3)) * 0.05).astype(np.float32)))
+    with pytest.raises(AssertionError, match="does not match"):       # a residual of the other split
+        H.conv3d_rs(xs16, wp, torch.ones(32, device=DEV), torch.zeros(32, device=DEV), res=xsb)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 4, 16), (2, 5, 7, 37), (1, 8, 12, 48), (3, 10, 30, 150)])
+@pytest.mark.parametrize("res,slope,out_f32", [(True, 0.01, False), (False, 0.01, True), (True, 1.0, False)])
+def test_conv3d_rs_in_the_fp16_split_vs_oracle(shape, res, slope, out_f32):
+    """The register-stationary 32 -> 32 kernel in the fp16 split (conv3d_rs32_kernel<MODE, true>: the same generated schedule, the
+    fp16 matrix instruction, fp16 residual and epilogue split): 20x inside the bf16 split's 1e-4 against float64 on what it multiplied."""
+    B, d, h, w = shape
+    rng = np.random.default_rng(sum(shape) + 16)
+    x, r = _g(rng.standard_normal((B, d, h, w, 32), dtype=np.float32)), _g(rng.standard_normal((B, d, h, w, 32), dtype=np.float32))
+    wt = (rng.standard_normal((32, 32, 3, 3, 3)) / np.sqrt(27 * 32)).astype(np.float32) * np.float32(0.02)
+    sc, sh = _bn(rng, 32)
+    xs, rs = H.act_to_split(x, fmt="f16"), (H.act_to_split(r, fmt="f16") if res else None)
+    wp, un = H.pack_conv_weights_rs(_g(wt), "f16")
+    y = H.conv3d_rs(xs, wp, _g(sc) * un, _g(sh), res=rs, neg_slope=slope, out_f32=out_f32)
+    assert out_f32 or y.fmt == "f16"
+    got = (y if out_f32 else H.act_from_split(y)).cpu().numpy()
+    ref = _conv_ref64(H.act_from_split(xs), wt, sc, sh, slope, res=H.act_from_split(rs) if res else None)
+    assert _rel(got, ref) <= 5e-6
+    if not out_f32:
+        for sl in (y.buf[:, 0], y.buf[:, -1], y.buf[:, :, 0], y.buf[:, :, -1], y.buf[:, :, :, 0], y.buf[:, :, :, -1]):
+            assert int(sl.abs().max()) == 0
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 4, 16), (2, 5, 7, 37), (3, 10, 30, 150)])
+def test_front_end_kernels_in_the_fp16_split_vs_oracle(shape):
+    """post_vol (16 -> 16, both outputs) and the stride-2 first layer (16 -> 32, LDS-DMA staging, one power of two for the layer) in
+    the fp16 split; post_vol's split-padded output is bit for bit the fp16 split of its fp32 output."""
+    B, d, h, w = shape
+    rng = np.random.default_rng(sum(shape) + 17)
+    x = _g(rng.standard_normal((B, d, h, w, 16), dtype=np.float32))
+    w16 = (rng.standard_normal((16, 16, 3, 3, 3)) / np.sqrt(27 * 16)).astype(np.float32)
+    sc, sh = _bn(rng, 16)
+    xs = H.act_to_split(x, fmt="f16")
+    wp, un = H.pack_conv_weights_rs(_g(w16), "f16")
+    y = H.conv3d_rs16(xs, wp, _g(sc) * un, _g(sh), neg_slope=0.01)
+    assert _rel(y.cpu().numpy(), _conv_ref64(H.act_from_split(xs), w16, sc, sh, 0.01)) <= 5e-6
+    ys = H.conv3d_rs16(xs, wp, _g(sc) * un, _g(sh), neg_slope=0.01, out_split=H.SplitAct(B, d, h, w, 16, x.device))
+    assert ys.fmt == "f16" and torch.equal(ys.buf, H.act_to_split(y, fmt="f16").buf)
+    w32 = (rng.standard_normal((32, 16, 3, 3, 3)) / np.sqrt(27 * 16)).astype(np.float32)
+    sc2, sh2 = _bn(rng, 32)
+    wp2, up, un2 = H.pack_conv_weights_s2rs(_g(w32), _g(sc2), "f16")
+    assert 512.0 <= float((np.abs(w32).reshape(32, -1).max(1) * np.abs(sc2)).max()) * up < 1024.0 and up * un2 == 1.0
+    do, ho, wo = (d - 1) // 2 + 1, (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    z = H.conv3d_s2rs(ys, wp2, _g(sh2) * up, H.SplitAct(B, do, ho, wo, 32, x.device), neg_slope=0.01, unscale=un2)
+    assert z.fmt == "f16"
+    assert _rel(H.act_from_split(z).cpu().numpy(), _conv_ref64(H.act_from_split(ys), w32, sc2, sh2, 0.01, stride=2)) <= 5e-6
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (2, 2, 4, 16), (3, 5, 9, 33), (2, 8, 40, 160)])
+def test_conv3d_up2_polyphase_in_the_fp16_split_vs_interpolate_then_conv(shape):
+    """The polyphase ResizeConv3d (main kernel, face and edge corrections, plan) in the fp16 split against interpolate -> conv in
+    float64 on the low-resolution input it staged; its split-padded output is the fp16 split of its fp32 output."""
+    B, d, h, w = shape
+    rng = np.random.default_rng(sum(shape) + 18)
+    x = _g(rng.standard_normal((B, d, h, w, 32), dtype=np.float32))
+    wt = (rng.standard_normal((16, 32, 3, 3, 3)) / np.sqrt(27 * 32)).astype(np.float32)
+    sc, sh = _bn(rng, 16)
+    xs = H.act_to_split(x, fmt="f16")
+    plan, un = H.conv3d_up2_poly_plan(_g(wt), d, h, w, fmt="f16")
+    y = H.conv3d_up2_poly(xs, plan, _g(sc) * un, _g(sh), neg_slope=0.01)
+    up = F.interpolate(H.act_from_split(xs).cpu().double().permute(0, 4, 1, 2, 3), scale_factor=2, mode="trilinear", align_corners=False)
+    ref = F.conv3d(up, torch.from_numpy(wt).double(), padding=1) * torch.from_numpy(sc).double().view(1, -1, 1, 1, 1) \
+        + torch.from_numpy(sh).double().view(1, -1, 1, 1, 1)
+    ref = torch.where(ref > 0, ref, ref * 0.01).permute(0, 2, 3, 4, 1).float().numpy()
+    assert _rel(y.cpu().numpy(), ref) <= 5e-6
+    ys = H.conv3d_up2_poly_split(xs, plan, _g(sc) * un, _g(sh), out=H.SplitAct(B, 2 * d, 2 * h, 2 * w, 16, x.device), neg_slope=0.01)
+    assert ys.fmt == "f16" and torch.equal(ys.buf, H.act_to_split(y, fmt="f16").buf)
+
+
+def test_sweep_split_padded_output_in_the_fp16_split(golden_dir):
+    """The sweep writing vol_raw as fp16 pairs: the fp16 split of the bit-exact fp32 volume."""
+    case = SMALL_CASES["std_d16_rand"]
+    cfg = case["cfg"]
+    inp = synth.make_inputs(cfg, seed=case["seed"], batch=case["batch"], grid_kind=case["grid_kind"], grid_mask_dtype=case["grid_mask_dtype"])
+    feats, grids = _g(inp["feats"]), _g(inp["grids"])
+    vm = H.sweep_validity(grids, _g(inp["grid_masks"]), _g(inp["masks"]))
+    vol = H.sweep_std_valid(feats, grids, vm)
+    B, D, Ho, Wo, C = vol.shape
+    vs = H.sweep_std_valid_split(feats, grids, vm, out=H.SplitAct(B, D, Ho, Wo, C, feats.device), fmt="f16")
+    assert vs.fmt == "f16" and torch.equal(vs.buf, H.act_to_split(vol, fmt="f16").buf)
+
+
 @pytest.mark.parametrize("shape", [(1, 32, 16, 1, 1, 1), (2, 32, 16, 3, 5, 9), (1, 96, 16, 2, 4, 20), (1, 64, 48, 2, 5, 17)])
 def test_cost_head_in_the_fp16_split_behind_a_streaming_layer(shape):
     """The tail of a regulator in f16x3 mode: ResizeConv3d on the streaming kernel writing fp16 pairs split-padded, the split cost

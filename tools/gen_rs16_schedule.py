@@ -179,16 +179,18 @@ def build(with_pairs, split=False):
         items = [(1, f"fin[{op}][{e}] = __builtin_fmaf(fin[{op}][{e}], esc[{e}], esh[{e}]);") for e in range(4)]
         for e in range(4):
             items.append((1, f"u{op} = fin[{op}][{e}] * a.neg_slope;"))
-            items.append((1, f"fin[{op}][{e}] = __builtin_fmaxf(fin[{op}][{e}], u{op});"))
+            items.append((1, f"fin[{op}][{e}] = RS_LRELU_MAX(fin[{op}][{e}], u{op});"))
+            if split:      # fp16 split only (cost 0: the bf16 schedule keeps its placement): the lower end of the range clamp
+                items.append((0, f"RS16_F_SPL(RS_F_F16(fin[{op}][{e}] = RS_CLAMP_LO(fin[{op}][{e}]);))"))
         # split-padded output (the stride-2 kernel behind post_vol stages pre-split voxels by LDS-DMA): hi | lo, lanes kg and
         # kg ^ 1 trade halves so that a lane stores 16 contiguous bytes of the voxel record
         for p in range(2 if split else 0):
-            items.append((1, f"RS16_F_SPL(hb{op}[{p}] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{{fin[{op}][{2 * p}], fin[{op}][{2 * p + 1}]}}, bf16x2));)"))
-            items.append((1, f"RS16_F_SPL(hf{op}[0] = __builtin_bit_cast(float, hb{op}[{p}] << 16);)"))
-            items.append((1, f"RS16_F_SPL(hf{op}[1] = __builtin_bit_cast(float, hb{op}[{p}] & 0xffff0000u);)"))
+            items.append((1, f"RS16_F_SPL(hb{op}[{p}] = RS_CVT_PK(fin[{op}][{2 * p}], fin[{op}][{2 * p + 1}]);)"))
+            items.append((1, f"RS16_F_SPL(hf{op}[0] = RS_W_LO(hb{op}[{p}]);)"))
+            items.append((1, f"RS16_F_SPL(hf{op}[1] = RS_W_HI(hb{op}[{p}]);)"))
             items.append((1, f"RS16_F_SPL(hf{op}[0] = fin[{op}][{2 * p}] - hf{op}[0];)"))
             items.append((1, f"RS16_F_SPL(hf{op}[1] = fin[{op}][{2 * p + 1}] - hf{op}[1];)"))
-            items.append((1, f"RS16_F_SPL(lb{op}[{p}] = __builtin_bit_cast(unsigned, __builtin_convertvector(hf{op}, bf16x2));)"))
+            items.append((1, f"RS16_F_SPL(lb{op}[{p}] = RS_CVT_PK(hf{op}[0], hf{op}[1]);)"))
         if split:
             items.append((2.0, f"RS16_F_SPL(sa{op} = __builtin_amdgcn_permlane16_swap(hb{op}[0], lb{op}[0], false, false);)"))
             items.append((2.0, f"RS16_F_SPL(sb{op} = __builtin_amdgcn_permlane16_swap(hb{op}[1], lb{op}[1], false, false);)"))

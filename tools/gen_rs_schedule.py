@@ -85,22 +85,23 @@ def epilogue_items(k):
     s.append((2.0, f"RS_F_NUP2(sa{k} = __builtin_amdgcn_permlane16_swap(rresB[{k}][0], rresB[{k}][2], false, false);)"))
     s.append((2.0, f"RS_F_NUP2(sb{k} = __builtin_amdgcn_permlane16_swap(rresB[{k}][1], rresB[{k}][3], false, false);)"))
     for e, (src, sh) in enumerate((("sa", True), ("sa", False), ("sb", True), ("sb", False))):
-        hi = f"{src}{k}[0] << 16" if sh else f"{src}{k}[0] & 0xffff0000u"
-        lo = f"{src}{k}[1] << 16" if sh else f"{src}{k}[1] & 0xffff0000u"
-        s.append((1, f"RS_F_NUP2(rh{k} = __builtin_bit_cast(float, {hi});)"))
-        s.append((1, f"RS_F_NUP2(rl{k} = __builtin_bit_cast(float, {lo});)"))
+        wid = "RS_W_LO" if sh else "RS_W_HI"      # the low / high 16-bit half of a dword as fp32, in the kernel's split (csrc/split_fmt.hpp)
+        s.append((1, f"RS_F_NUP2(rh{k} = {wid}({src}{k}[0]);)"))
+        s.append((1, f"RS_F_NUP2(rl{k} = {wid}({src}{k}[1]);)"))
         s.append((1, f"RS_F_NUP2(rh{k} = rh{k} + rl{k};)"))
         s.append((1, f"RS_F_NUP2(t{k}[{e}] = t{k}[{e}] + rh{k};)"))
     for e in range(4):
         s.append((1, f"u{k} = t{k}[{e}] * a.neg_slope;"))
-        s.append((1, f"t{k}[{e}] = __builtin_fmaxf(t{k}[{e}], u{k});"))
+        s.append((1, f"t{k}[{e}] = RS_LRELU_MAX(t{k}[{e}], u{k});"))
+        # fp16 split only (cost 0: the bf16 schedule keeps its placement): the lower end of the range clamp (RS_LRELU_MAX holds the upper)
+        s.append((0, f"RS_F_SPL(RS_F_F16(t{k}[{e}] = RS_CLAMP_LO(t{k}[{e}]);))"))
     for p in range(2):
-        s.append((1, f"RS_F_SPL(hb{k}[{p}] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{{t{k}[{2 * p}], t{k}[{2 * p + 1}]}}, bf16x2));)"))
-        s.append((1, f"RS_F_SPL(hf{k}[0] = __builtin_bit_cast(float, hb{k}[{p}] << 16);)"))
-        s.append((1, f"RS_F_SPL(hf{k}[1] = __builtin_bit_cast(float, hb{k}[{p}] & 0xffff0000u);)"))
+        s.append((1, f"RS_F_SPL(hb{k}[{p}] = RS_CVT_PK(t{k}[{2 * p}], t{k}[{2 * p + 1}]);)"))
+        s.append((1, f"RS_F_SPL(hf{k}[0] = RS_W_LO(hb{k}[{p}]);)"))
+        s.append((1, f"RS_F_SPL(hf{k}[1] = RS_W_HI(hb{k}[{p}]);)"))
         s.append((1, f"RS_F_SPL(hf{k}[0] = t{k}[{2 * p}] - hf{k}[0];)"))
         s.append((1, f"RS_F_SPL(hf{k}[1] = t{k}[{2 * p + 1}] - hf{k}[1];)"))
-        s.append((1, f"RS_F_SPL(lb{k}[{p}] = __builtin_bit_cast(unsigned, __builtin_convertvector(hf{k}, bf16x2));)"))
+        s.append((1, f"RS_F_SPL(lb{k}[{p}] = RS_CVT_PK(hf{k}[0], hf{k}[1]);)"))
     s.append((2.0, f"RS_F_SPL(sa{k} = __builtin_amdgcn_permlane16_swap(hb{k}[0], lb{k}[0], false, false);)"))
     s.append((2.0, f"RS_F_SPL(sb{k} = __builtin_amdgcn_permlane16_swap(hb{k}[1], lb{k}[1], false, false);)"))
     s.append((0.5, f"RS_F_SPL(outp[{k}] = u32x4{{sa{k}[0], sb{k}[0], sa{k}[1], sb{k}[1]}};)"))
