@@ -95,6 +95,36 @@ class HotPath:
         """inverse-distance index -> 1/m, on the host (api/inference_class.py:111-114)."""
         return (inv_dist / self.cfg.bf).cpu().numpy()
 
+    @torch.no_grad()
+    def precision_check(self, feats: torch.Tensor, bar: float = 5e-4) -> Dict[str, object]:
+        """Which conv arithmetic does THIS checkpoint need?  Runs `feats` (one or a few real frames) through the path in the
+        bf16 split and in the fp16 split and returns their inverse-distance discrepancy, max |d| / max |inv_dist| -- the fp16
+        split's own error is 7-11x smaller (Precision modes), so the discrepancy IS the bf16 split's error to ~15 % --
+        and the cheapest mode that keeps it under `bar` (default: half the north star's 1e-3).  The error of either split grows
+        with the sharpness of the checkpoint's softmax over the candidates, which only the trained weights know: this is the
+        measurement a deployer makes once per checkpoint instead of guessing it.
+        -> {"bf16x3_vs_f16x3": e, "f16x3_vs_f32": e (only when the first exceeds the bar), "recommended": mode, "bar": bar}"""
+        from . import hip_ops as H
+        old = H.get_conv_mode()
+        outs = {}
+        try:
+            for mode in ("bf16x3", "f16x3"):
+                H.set_conv_mode(mode)
+                outs[mode] = self(feats)[0].clone()
+            den = float(outs["f16x3"].abs().max()) or 1.0
+            e_b = float((outs["bf16x3"] - outs["f16x3"]).abs().max()) / den
+            res = {"bf16x3_vs_f16x3": e_b, "bar": bar, "recommended": "bf16x3"}
+            if e_b > bar:
+                H.set_conv_mode("f32")
+                e_f = float((self(feats)[0] - outs["f16x3"]).abs().max()) / den
+                res["f16x3_vs_f32"] = e_f
+                # the two agree to ~2x their own errors: past the bar no fp32-accumulating arithmetic pins inv_dist to it (the
+                # reference's own summation order is then one answer among several)
+                res["recommended"] = "f16x3" if e_f <= bar else "f16x3 (the bar itself is ill-conditioned for this checkpoint: fp32 orders differ by more)"
+            return res
+        finally:
+            H.set_conv_mode(old)
+
 
 class StreamedHotPath:
     """The batch of one step cut into `n_streams` independent parts, each through its own HotPath replica (own module-owned

@@ -708,6 +708,35 @@ def test_full_size_gain_ladder_vs_reference_goldens(golden_dir, name, conv_mode)
     torch.cuda.empty_cache()
 
 
+def test_precision_check_estimates_the_bf16_split_error(golden_dir):
+    """HotPath.precision_check -- the deployer's per-checkpoint measurement: its bf16x3-vs-f16x3 discrepancy tracks the bf16
+    split's TRUE error against the reference golden (within 25 %) up the gain ladder, and its recommendation flips to f16x3 where
+    that error crosses the bar."""
+    case = FULL_CASES["full_G16V"]
+    cfg = case["cfg"]
+    z = np.load(os.path.join(golden_dir, "full_G16V_ladder.npz"))
+    inp = synth.make_inputs(cfg, seed=case["seed"], batch=1, grid_kind=case["grid_kind"], grid_mask_dtype=case["grid_mask_dtype"])
+    assert synth.digest(inp) == str(z["inputs_sha256"])
+    feats = _g(inp["feats"])
+    old = H.get_conv_mode()
+    try:
+        seen = set()
+        for gain in (2.0, 4.0):
+            hp = HotPath(cfg, synth.make_weights(cfg, seed=case["seed"], gain=gain), inp, device=DEV)
+            chk = hp.precision_check(feats)
+            H.set_conv_mode("bf16x3")
+            true = _rel(hp(feats)[0].cpu().numpy(), z[f"inv_dist_g{gain:g}"])
+            assert abs(chk["bf16x3_vs_f16x3"] - true) <= 0.25 * true, (gain, chk, true)
+            assert chk["recommended"] == ("bf16x3" if true <= 5e-4 else "f16x3"), (gain, chk, true)
+            seen.add(chk["recommended"])
+            assert H.get_conv_mode() == "bf16x3"
+            del hp
+        assert seen == {"bf16x3", "f16x3"}
+    finally:
+        H.set_conv_mode(old)
+        torch.cuda.empty_cache()
+
+
 def test_unpickled_reference_modules_run_on_hip(golden_dir):
     import mvs_gi_amd
     assert mvs_gi_amd.install() in ("alias", "patch")
