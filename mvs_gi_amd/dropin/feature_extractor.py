@@ -25,12 +25,15 @@ _SPLIT_CHAIN = H.exp_env("MVSGI_EXTRACTOR_SPLIT", "1") != "0"  # 0: the round-2 
 _STEM_MFMA = H.exp_env("MVSGI_STEM_MFMA", "1") != "0"      # 0: the LDS-tiled VALU stem for uint8 images too
 
 
+# The extractor's arithmetic: its split kernels are bf16-split in BOTH split modes of the library (bf16x3, f16x3) -- its output, the
+# feature maps, is the INPUT of the path whose 1e-3 bar the modes are about (the sweep consumes them bit-exactly); MVSGI_CONV_MODE=f32
+# runs it on the exact-fp32 kernels.
 class Conv2dLaunch:
     __slots__ = ("w", "wp_b3", "wp_f32", "wp_stem", "wp_rs", "scale", "shift", "stride", "neg_slope", "k", "cin", "cout", "key")
 
     def run(self, x: Tensor, res: Optional[Tensor] = None, in_nchw: bool = False, out_split: Optional[Tensor] = None) -> Tensor:
         impl, wp = H.CONV_AUTO, None
-        if H.get_conv_mode() == "bf16x3" and self.k == 3 and self.cin % 16 == 0 and self.cout % 16 == 0 and not in_nchw:
+        if H.split_mode() and self.k == 3 and self.cin % 16 == 0 and self.cout % 16 == 0 and not in_nchw:
             if self.wp_b3 is None:
                 self.wp_b3 = H.pack_conv2d_weights_bf16x3(self.w)
             impl, wp = H.CONV_BF16X3, self.wp_b3
@@ -155,7 +158,7 @@ def res_block2d_nhwc(blk, x: Tensor) -> Tensor:
     if not _is_identity(blk.one_by_one) or getattr(blk, "out_pad", 0) != 0:
         raise NotImplementedError("ResConvBlk2d with projection / out_pad is not on the extractor path")
     L1, L2 = lower_conv2d_block(blk.blk1), lower_conv2d_block(blk.blk2)
-    if _FUSE_RESBLOCK and H.get_conv_mode() == "bf16x3" and L1.k == 3 and L2.k == 3 and L1.stride == 1 and L2.stride == 1 \
+    if _FUSE_RESBLOCK and H.split_mode() and L1.k == 3 and L2.k == 3 and L1.stride == 1 and L2.stride == 1 \
             and (L1.cin, L1.cout, L2.cin, L2.cout) == (16, 16, 16, 16) and L1.neg_slope == L2.neg_slope:
         # both convs in one launch, the intermediate stays in LDS (mvsgi_resblock2d_f32)
         for L in (L1, L2):
@@ -222,7 +225,7 @@ def _split_chain_forward(self, xin: Tensor, with_final: bool = True) -> Optional
     residual blocks writes the 2-D split-padded format, the blocks hand it on, a stride-2 layer between two runs reads and
     writes it (mvsgi_conv2d_s2_split), the last block in front of any other layer writes fp32.  None when this mode / recipe
     has no such run."""
-    if not (_SPLIT_CHAIN and H.get_conv_mode() == "bf16x3"):
+    if not (_SPLIT_CHAIN and H.split_mode()):
         return None
     layers = [self.first] + list(self.blks) + ([self.final_layer] if with_final else [])
     fus = [hasattr(m, "blk1") and _fusable_resblock(m) for m in layers]
