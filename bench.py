@@ -1165,6 +1165,15 @@ def run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, 
         return m
     guarded("mode_f16x3", mode_f16x3)
 
+    def precision_check():
+        # the deployer's per-checkpoint measurement (HotPath.precision_check) on the benchmark's own weights and one synthetic frame:
+        # which arithmetic this checkpoint needs for inv_dist within half the north star's bar
+        try:
+            return hp.precision_check(feats[:1].contiguous())
+        finally:
+            H.set_conv_mode(args.mode)
+    guarded("precision_check", precision_check)
+
     # ---- images -> inverse distance (HIP feature extractor in front), HBM-resident and host-fed
     Hi, Wi = cfg.feat_hw
     N = cfg.num_cams

@@ -73,7 +73,7 @@ def _fmt_code(fmt: str) -> int:
 
 
 def _pow2_unscale(amax: torch.Tensor):
-    """k per entry such that amax * 2^k lies in [512, 1024) (0 for a zero entry) -> (2^k, 2^-k) as fp32 tensors."""
+    """k per entry such that amax * 2^k lies in (512, 1024] (0 for a zero entry) -> (2^k, 2^-k) as fp32 tensors."""
     k = torch.where(amax > 0, torch.floor(torch.log2(1024.0 / amax.clamp_min(1e-37))), torch.zeros_like(amax)).clamp(-100.0, 100.0)
     return torch.exp2(k), torch.exp2(-k)
 
@@ -305,7 +305,7 @@ def pack_conv_weights_bf16x3(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
 
 def pack_conv_weights_f16x3(w_oidhw: torch.Tensor, layout: int = CONV_BF16X3):
     """[Cout, Cin, 3, 3, 3] -> (packed weights of the fp16 split in `layout` (CONV_BF16X3 | _C16 | _V32), unscale [Cout]) or None.
-    Every output channel's weights are pre-scaled by a power of two so that its largest weight lies in [512, 1024) -- the lo parts
+    Every output channel's weights are pre-scaled by a power of two so that its largest weight lies in (512, 1024] -- the lo parts
     (2^-11 of the weight) are then normal fp16 numbers instead of subnormals with an absolute quantum of 2^-24; `unscale` = 2^-k
     per channel goes into the epilogue's per-channel scale (exact: powers of two)."""
     lib = _lib.load()
@@ -485,7 +485,7 @@ def pack_head_split_weights(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
 
 def pack_head_split_weights_f16(w_oidhw: torch.Tensor):
     """[1, Cin % 16 == 0, 3, 3, 3] -> (fragment layout of conv3d_head_split in the fp16 split, unscale) or None: the weights
-    pre-scaled by a power of two (largest in [512, 1024)), `unscale` its inverse for the head's scale."""
+    pre-scaled by a power of two (largest in (512, 1024]), `unscale` its inverse for the head's scale."""
     lib = _lib.load()
     w = _dev(w_oidhw, "conv weight")
     if w.shape[0] != 1 or tuple(w.shape[2:]) != (3, 3, 3) or w.shape[1] % 16:
@@ -669,7 +669,7 @@ def conv3d_s2rs_applies(cin: int, cout: int, stride: int, neg_slope: float) -> b
 def pack_conv_weights_s2rs(w_oidhw: torch.Tensor, scale: torch.Tensor, fmt: str = "bf16"):
     """[32, 16, 3, 3, 3] weights with the per-channel scale folded in, in the lane order of csrc/conv3d_s2rs.hip.
     fmt = 'f16': -> (packed weights, up, unscale): the kernel's epilogue has no per-channel multiplier, so ONE power of two `up` for
-    the layer (the largest |weight * scale| in [512, 1024)) is folded into the packed weights; the caller multiplies `shift` by `up`
+    the layer (the largest |weight * scale| in (512, 1024]) is folded into the packed weights; the caller multiplies `shift` by `up`
     and passes `unscale` = 1 / up to conv3d_s2rs."""
     lib = _lib.load()
     w = _dev(w_oidhw, "w")

@@ -221,3 +221,27 @@ def test_build_and_regulate_hand_over_decision():
     for bs, rs in ((False, True), (True, False), (False, False)):     # a foreign module on either side
         out, c = run(bs, True, rs, True)
         assert out == "COSTS_T" and c == ["builder", ("regulator", "VOL")]
+
+
+def test_power_of_two_prescale_of_the_fp16_split():
+    """hip_ops._pow2_unscale: the per-channel power of two that puts a channel's largest weight into (512, 1024] (its fp16 lo part is
+    then a normal number), exactly invertible; a zero channel is left alone; 'f16x3' is a mode, 'bf16x3' the default."""
+    import torch
+    from mvs_gi_amd import hip_ops as H
+    amax = torch.tensor([0.0, 1e-9, 3.7e-3, 0.11, 0.5, 1.0, 511.9, 512.0, 1023.9, 1024.0, 5e4, 3e30])
+    up, un = H._pow2_unscale(amax)
+    assert float(up[0]) == 1.0 and float(un[0]) == 1.0
+    assert torch.equal(up * un, torch.ones_like(up))
+    assert torch.equal(torch.log2(up), torch.round(torch.log2(up)))              # powers of two
+    m = amax[1:-1] * up[1:-1]
+    assert bool(((m > 512.0) & (m <= 1024.0)).all())
+    assert float(up[-1]) == 2.0 ** -90 or float(amax[-1] * up[-1]) < 1024.0       # clamped exponent: finite, never 0 / inf
+    assert "f16x3" in H.CONV_MODES and H.mode_fmt() in ("bf16", "f16")
+    old = H.get_conv_mode()
+    try:
+        H.set_conv_mode("f16x3")
+        assert H.split_mode() and H.mode_fmt() == "f16"
+        H.set_conv_mode("f32")
+        assert not H.split_mode() and H.mode_fmt() == "bf16"
+    finally:
+        H.set_conv_mode(old)

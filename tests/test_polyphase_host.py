@@ -34,14 +34,14 @@ def test_class_matrices_depend_on_phase_and_class_only():
             assert np.abs(d[1]).max() > 0 and not d[0].any() and not d[2].any()
 
 
-def _unpack_rs32(buf):
-    """inverse of rs32_pack_weights_host: 114,688 bytes -> (hi, lo) [32 cout][32 cin][27] as float (bf16 values)."""
+def _unpack_rs32(buf, f16=False):
+    """inverse of rs32_pack_weights_host: 114,688 bytes -> (hi, lo) [32 cout][32 cin][27] as float (bf16 values, or fp16 with f16)."""
     u = buf.view(np.uint16).reshape(2, 2, 14, 2, 64, 8)         # [slice][cout tile][pair][hi|lo][lane][8]
     hi = np.zeros((32, 32, 27), np.float32)
     lo = np.zeros((32, 32, 27), np.float32)
 
     def f32(h):
-        return (h.astype(np.uint32) << 16).view(np.float32)
+        return h.view(np.float16).astype(np.float32) if f16 else (h.astype(np.uint32) << 16).view(np.float32)
     for sl in range(2):
         for ct in range(2):
             for p in range(14):
@@ -94,3 +94,25 @@ def test_host_plan_matches_the_python_algebra(dims):
                 want = np.transpose(We[:, :, :, :, 1], (2, 3, 1, 0)).reshape(9, 32, 16)
                 assert np.abs(ew[gi, e, phase] - want).max() <= 1e-6
     assert lib.mvsgi_conv3d_up2_poly_plan(None, plan.ctypes.data, D, H, W) != 0 and b"null pointer" in lib.mvsgi_last_error()
+
+
+def test_host_plan_in_the_fp16_split():
+    """mvsgi_conv3d_up2_poly_plan_fmt(MVSGI_SPLIT_F16): the folded main weight sets as fp16 pairs -- hi + lo reproduces the folded fp32
+    weights to 2^-20 (the bf16 plan: 2^-15) once the weights are in fp16's comfortable range (the caller pre-scales them); fmt 0 is the
+    un-suffixed function byte for byte; a bad fmt is refused."""
+    lib = _lib.load()
+    D, H, W = 2, 3, 5
+    rng = np.random.default_rng(9)
+    w = (rng.standard_normal((16, 32, 3, 3, 3)) * 200).astype(np.float32)        # pre-scaled: largest weight ~ 2^9..2^10
+    n = lib.mvsgi_conv3d_up2_poly_plan_bytes(D, H, W)
+    p0, pb, pf = np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    assert lib.mvsgi_conv3d_up2_poly_plan(w.ctypes.data, p0.ctypes.data, D, H, W) == 0
+    assert lib.mvsgi_conv3d_up2_poly_plan_fmt(w.ctypes.data, pb.ctypes.data, D, H, W, 0) == 0
+    assert lib.mvsgi_conv3d_up2_poly_plan_fmt(w.ctypes.data, pf.ctypes.data, D, H, W, 1) == 0
+    assert np.array_equal(p0, pb) and not np.array_equal(p0, pf)
+    off_main = int(pf[32:80].view(np.int64)[0])
+    for (pd, cd, ph), want in P.main_weight_sets(w).items():
+        o = off_main + ((pd * 4 + cd) * 2 + ph) * 114688
+        hi, lo = _unpack_rs32(pf[o:o + 114688], f16=True)
+        assert np.abs((hi + lo).reshape(32, 32, 3, 3, 3) - want).max() <= 2.0 ** -20 * np.abs(want).max()
+    assert lib.mvsgi_conv3d_up2_poly_plan_fmt(w.ctypes.data, pf.ctypes.data, D, H, W, 7) != 0 and b"fmt" in lib.mvsgi_last_error()
