@@ -1222,7 +1222,7 @@ def test_sphere_feature_extractor_vs_oracle(conv_mode):
     with torch.no_grad():
         ref = O.sphere_feature_extractor(torch.from_numpy(imgs), p).numpy()
     assert f.shape == ref.shape
-    assert _rel(f.cpu().numpy(), ref) <= (2e-4 if conv_mode == "bf16x3" else 2e-5)
+    assert _rel(f.cpu().numpy(), ref) <= (2e-5 if conv_mode == "f32" else 2e-4)      # the extractor is bf16-split in both split modes
     # module-level pieces keep the reference's call signatures
     blk = fe.final_layer
     x = torch.from_numpy(rng.standard_normal((2, 16, Hh // 4, W // 4)).astype(np.float32))
