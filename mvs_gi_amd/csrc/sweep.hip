@@ -693,7 +693,11 @@ __global__ __launch_bounds__(256) void sweep_cat_nhwc_kernel(const float* __rest
         const_cast<float*>(feats + (long long)(b * s.N + cam) * HWi * s.C), 0, HWi * s.C * 4, 0x00020000);
     // (skipping the taps that lie outside the image for a whole wave, as the masked-variance kernel skips cameras, measured 2-4 %
     // SLOWER here: 1628 vs 1590 us per 16 4cam-32 frames, 1358 vs 1303 us per 64 E8 frames -- few waves of these rigs are
-    // entirely outside a camera and the four wave-uniform branches cost more than they save)
+    // entirely outside a camera and the four wave-uniform branches cost more than they save.  Round 5: chunks of 2 / 3 / 4 consecutive
+    // candidates per thread quad that INHERIT the previous candidate's texels -- the same cell 62 % of the steps on the 32-candidate
+    // rig -- with the inherited requests sent outside the descriptor's range: 1679 / 1900 / 1703 us against this kernel's 1508 per 16
+    // 4cam-32 frames, 1301 / 1487 / 1514 against 1201 per 64 E8 frames (profiles/r05_sweep_cat_variants.txt): a request that moves no
+    // data still costs its instruction, and the instruction count is what bounds the texture path)
     for (int c = q * 4; c < s.C; c += 16)
         *reinterpret_cast<f32x4_t*>(out + c) = bilin_fetch4_buf(img, c, s.C, ft);
 }
