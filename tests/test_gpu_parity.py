@@ -737,6 +737,24 @@ def test_precision_check_estimates_the_bf16_split_error(golden_dir):
         torch.cuda.empty_cache()
 
 
+def test_precision_check_prefers_the_bf16_split_outside_fp16_range():
+    """Features 300x too large: the cost volume (a variance) leaves fp16's range, the fp16 split clamps it, the bf16 split does not
+    care -- precision_check sees the two splits disagree, lets the exact mode arbitrate and recommends bf16x3."""
+    case = SMALL_CASES["std_d16_rand"]
+    cfg = case["cfg"]
+    inp = synth.make_inputs(cfg, seed=case["seed"], batch=case["batch"], grid_kind="smooth", grid_mask_dtype="bool")
+    feats = _g(inp["feats"] * np.float32(300.0))
+    hp = HotPath(cfg, synth.make_weights(cfg, seed=case["seed"], gain=1e-5), inp, device=DEV)
+    old = H.get_conv_mode()
+    try:
+        chk = hp.precision_check(feats)
+        print(chk)
+        assert chk["bf16x3_vs_f16x3"] > chk["bar"] and chk["f16x3_vs_f32"] > 4 * chk["bf16x3_vs_f32"]
+        assert chk["recommended"] == "bf16x3" and H.get_conv_mode() == old
+    finally:
+        H.set_conv_mode(old)
+
+
 def test_unpickled_reference_modules_run_on_hip(golden_dir):
     import mvs_gi_amd
     assert mvs_gi_amd.install() in ("alias", "patch")
