@@ -640,8 +640,9 @@ def test_full_size_vs_oracle(name, conv_mode):
 BENCH_PARTS = [("full_G16VV", 32), ("full_E8", 64), ("full_4cam-32", 16)]
 
 
+@pytest.mark.parametrize("split", ["bf16x3", "f16x3"])
 @pytest.mark.parametrize("name,part", BENCH_PARTS)
-def test_full_size_at_bench_batch_streamed_vs_reference_golden(golden_dir, name, part):
+def test_full_size_at_bench_batch_streamed_vs_reference_golden(golden_dir, name, part, split):
     """The other three BASELINE.json configurations at bench.py's operating point -- two parts of `part` frames on two HIP
     streams inside one hipGraph (StreamedHotPath), where the dispatcher picks other units than at one frame (96 / 128 / 192-cout
     units, the >= 384 / 512-unit rules): the first and the last frame of the step reproduce the single-frame REFERENCE golden,
@@ -654,7 +655,7 @@ def test_full_size_at_bench_batch_streamed_vs_reference_golden(golden_dir, name,
     assert synth.digest(inp) == str(z["inputs_sha256"]), "regenerated inputs differ from the golden run's (host libm)"
     old = H.get_conv_mode()
     try:
-        H.set_conv_mode("bf16x3")
+        H.set_conv_mode(split)
         gain = max(case["gains"])
         ref = z[f"inv_dist_g{gain:g}"]
         shp = StreamedHotPath(cfg, synth.make_weights(cfg, seed=case["seed"], gain=gain), inp, device=DEV, n_streams=2)
@@ -668,9 +669,9 @@ def test_full_size_at_bench_batch_streamed_vs_reference_golden(golden_dir, name,
         for fr in (0, n - 1):
             assert (fr - 3) % 8 != 0
             err = _rel(got[fr:fr + 1], ref)
-            parity_log.record(f"{name}(2x{part} streamed)[{fr}]", "bf16x3", gain, err, _l1(got[fr:fr + 1], ref), "golden")
-            print(f"{name} 2x{part} streamed frame {fr} gain {gain}: max-rel {err:.3e} (ref=golden)")
-            assert err <= 1e-3, (fr, err)
+            parity_log.record(f"{name}(2x{part} streamed)[{fr}]", split, gain, err, _l1(got[fr:fr + 1], ref), "golden")
+            print(f"{name} 2x{part} streamed [{split}] frame {fr} gain {gain}: max-rel {err:.3e} (ref=golden)")
+            assert err <= (1e-3 if split == "bf16x3" else 2e-4), (fr, err)      # the fp16 split: 5x inside the bar on these rows
         assert np.array_equal(got[0], got[n - 1]) and np.array_equal(got[3], got[n - 5]) and not np.array_equal(got[3], got[0])
         del shp, parts, f
     finally:
@@ -1586,9 +1587,11 @@ def test_split_padded_hand_over_between_builder_and_regulator(golden_dir):
         cr._USE_S2RS = old_use
 
 
-def test_full_size_batch8_register_stationary_path_vs_reference_golden(golden_dir):
+@pytest.mark.parametrize("split", ["bf16x3", "f16x3"])
+def test_full_size_batch8_register_stationary_path_vs_reference_golden(golden_dir, split):
     """G16V at full size with 8 frames per launch: the batch at which bench.py's path (register-stationary level-0 convs)
-    is active; every frame must reproduce the single-frame reference golden."""
+    is active; every frame must reproduce the single-frame reference golden -- in both 16-bit splits (the fp16 split runs the
+    same kernels: split-padded buffers tagged 'f16' all the way from the sweep to the cost head)."""
     import parity_log
     case = FULL_CASES["full_G16V"]
     cfg, z = case["cfg"], _load(golden_dir, "full_G16V")
@@ -1596,11 +1599,14 @@ def test_full_size_batch8_register_stationary_path_vs_reference_golden(golden_di
     assert synth.digest(inp) == str(z["inputs_sha256"]), "regenerated inputs differ from the golden run's (host libm)"
     old = H.get_conv_mode()
     try:
-        H.set_conv_mode("bf16x3")
+        H.set_conv_mode(split)
         gain = case["gains"][-1]
         hp = HotPath(cfg, synth.make_weights(cfg, seed=case["seed"], gain=gain), inp, device=DEV)
         inv = hp(_g(inp["feats"]).expand(8, -1, -1, -1, -1).contiguous())[0]
         assert "_mvsgi_rs_bufs" in hp.cv_regulator.down_blks[0].__dict__
+        fmt = "f16" if split == "f16x3" else "bf16"      # every split-padded buffer of the path carries the mode's split
+        assert all(b.fmt == fmt for bufs in hp.cv_regulator.down_blks[0].__dict__["_mvsgi_rs_bufs"].values() for b in bufs)
+        assert all(b.fmt == fmt for b in hp.cv_regulator.__dict__["_mvsgi_poly_bufs"].values())
         # the sweep -> post_vol front end in chunks of frames (bench.py's B=64 runs chunks of 16): same bits
         from mvs_gi_amd.dropin import cost_volume_builder as cvb_mod
         old_chunk, cvb_mod._FRONT_CHUNK = cvb_mod._FRONT_CHUNK, 3
@@ -1613,8 +1619,8 @@ def test_full_size_batch8_register_stationary_path_vs_reference_golden(golden_di
         got = inv.cpu().numpy()
         for f in (0, 7):
             err = _rel(got[f:f + 1], ref)
-            parity_log.record(f"full_G16V(B=8,rs)[{f}]", "bf16x3", gain, err, _l1(got[f:f + 1], ref), "golden")
-            assert err <= 1e-3
+            parity_log.record(f"full_G16V(B=8,rs)[{f}]", split, gain, err, _l1(got[f:f + 1], ref), "golden")
+            assert err <= (1e-3 if split == "bf16x3" else 1e-4)
         assert np.array_equal(got[0], got[7])
         # bench.py's batch: 64 frames per launch (front end in chunks of 16, split-padded hand-over, hipGraph replay), every
         # 8th frame scaled so that the frames differ: frames 0 and 63 reproduce the golden, a scaled frame its own single run
@@ -1624,8 +1630,8 @@ def test_full_size_batch8_register_stationary_path_vs_reference_golden(golden_di
         g64 = inv64.cpu().numpy()
         for f in (0, 63):
             err = _rel(g64[f:f + 1], ref)
-            parity_log.record(f"full_G16V(B=64)[{f}]", "bf16x3", gain, err, _l1(g64[f:f + 1], ref), "golden")
-            assert err <= 1e-3
+            parity_log.record(f"full_G16V(B=64)[{f}]", split, gain, err, _l1(g64[f:f + 1], ref), "golden")
+            assert err <= (1e-3 if split == "bf16x3" else 1e-4)
         # equal inputs -> equal bits wherever the frame sits in the batch (chunks of 16, persistent walks); the scaled frames differ.
         # (A batch of 4 or 1 takes other kernel variants -- other fp32 summation orders -- and lands 1.4e-4 away: not compared.)
         assert np.array_equal(g64[0], g64[8]) and np.array_equal(g64[0], g64[63]) and np.array_equal(g64[5], g64[61])
@@ -1642,8 +1648,8 @@ def test_full_size_batch8_register_stationary_path_vs_reference_golden(golden_di
         torch.cuda.synchronize()
         assert len(parts) == 2 and torch.equal(parts[0][0], inv64) and torch.equal(parts[1][0], inv64)
         err = _rel(parts[1][0][63:64].cpu().numpy(), ref)
-        parity_log.record("full_G16V(2x64 streamed)[127]", "bf16x3", gain, err, _l1(parts[1][0][63:64].cpu().numpy(), ref), "golden")
-        assert err <= 1e-3
+        parity_log.record("full_G16V(2x64 streamed)[127]", split, gain, err, _l1(parts[1][0][63:64].cpu().numpy(), ref), "golden")
+        assert err <= (1e-3 if split == "bf16x3" else 1e-4)
         del shp, parts, f128
     finally:
         H.set_conv_mode(old)
