@@ -9,6 +9,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
 #define MFA(ACC, W, X) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "a"(W), "v"(X));
 #define MFV(ACC, W, X) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(W), "v"(X));
+#define MFAV(ACC, W, X) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(ACC) : "a"(W), "v"(X));
 #define MFVV(ACC, W, X) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(W), "v"(X));
 
 template <int MODE>
@@ -30,7 +31,9 @@ __global__ __launch_bounds__(256, 1) void k(const bf16x8* src, float* out, unsig
             bf16x8 xn[3];
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
-                if (MODE == 10) { MFV(acc[a], w[g], x[a]) } else if (MODE == 11) { MFVV(acc[a], w[g], x[a]) } else { MFA(acc[a], w[g], x[a]) }
+                if (MODE == 15 || MODE == 16 || MODE == 17) { MFAV(acc[a], w[g], x[a]) } else if (MODE == 10) { MFV(acc[a], w[g], x[a]) } else if (MODE == 11) { MFVV(acc[a], w[g], x[a]) } else { MFA(acc[a], w[g], x[a]) }
+                if (MODE == 16) { f0 = f0 + f2; f1 = f1 * f3; }
+                if (MODE == 17) { f0 = f0 + f2; f1 = f1 * f3; f2 = f2 + f3; f3 = f3 * f0; }
                 if (MODE == 1) { f0 = f0 + f2; }                                   // one independent-ish VALU (chain across MFMAs)
                 if (MODE == 2) { f0 = f0 + f2; f1 = f1 * f3; }                      // two VALU
                 if (MODE == 3) { f0 = f0 + f2; f1 = f1 * f3; f2 = f2 + f3; }        // three VALU
@@ -78,6 +81,9 @@ int main() {
         run<0>("bare (A operand in AGPRs)", d, o, t, blocks);
         run<10>("bare (A operand in VGPRs)", d, o, t, blocks);
         run<11>("bare (A, C/D in VGPRs)", d, o, t, blocks);
+        run<15>("bare (A in AGPRs, C/D in VGPRs)", d, o, t, blocks);
+        run<16>("  the same + 2 VALU per MFMA", d, o, t, blocks);
+        run<17>("  the same + 4 VALU per MFMA", d, o, t, blocks);
         run<1>("+1 v_add per MFMA", d, o, t, blocks);
         run<2>("+2 VALU per MFMA", d, o, t, blocks);
         run<3>("+3 VALU per MFMA", d, o, t, blocks);
