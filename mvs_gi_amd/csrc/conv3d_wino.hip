@@ -94,19 +94,15 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, uns
 }
 
 // The MFMAs are inline asm so that the weights can be pinned to the accumulator half of the register file ("a"); the output
-// accumulators and the transformed activations are ordinary registers.  hipcc pads no hazards around asm: every group of MFMAs
-// ends in WN_PAD before anything else may touch its accumulators.
+// accumulators and the transformed activations are ordinary registers.  hipcc pads no hazards around asm: the step ends in WN_PAD
+// before anything else may touch its accumulators, and the accumulators finished in a step get their last MFMAs in its first third.
 #define WN_MF(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(ACC) : "a"(WREG), "v"(XREG));
 #define WN_MF0(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "+v"(ACC) : "a"(WREG), "v"(XREG));
+// (accumulator slots 1 and 2 live in the accumulator file beside the weights -- 192 + 64 = all of it: with three slots in ordinary
+// registers next to the V pairs (64) and the raw patches (64) hipcc shuttles ~100 registers per step through v_accvgpr moves)
+#define WN_MFA(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "a"(WREG), "v"(XREG));
+#define WN_MFA0(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG));
 #define WN_PAD() asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-// the 24 MFMAs of one depth tap: term-major, so that the three products of an accumulator are 8 MFMAs apart
-#define WN_GROUP(S, KD, MF_FIRST)                                                                   \
-    _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_)                                                \
-        _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) { MF_FIRST(Y[S][b_][c_], wl[b_][KD][c_], vh[b_]) } \
-    _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_)                                                \
-        _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) { WN_MF(Y[S][b_][c_], wh[b_][KD][c_], vl[b_]) } \
-    _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_)                                                \
-        _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) { WN_MF(Y[S][b_][c_], wh[b_][KD][c_], vh[b_]) }
 
 namespace wn {
 // LDS image of one input plane of a unit: 4 rows x 34 columns, even and odd columns apart, 9 sixteen-byte slots per voxel (its 8 pieces
@@ -118,16 +114,21 @@ constexpr int ROW_SLOTS = 2 * HALF * PITCH;       // 306
 constexpr int PLANE_SLOTS = 4 * ROW_SLOTS;        // 1224
 constexpr int NDMA = 20, DPW = NDMA / 4;          // 1 KiB pieces per plane, per wave
 constexpr int PLANE_LDS = NDMA * 1024;            // 20,480
-constexpr int NBUF = 3;
+constexpr int DEPTH = 8;                          // planes per unit: the kernel body is one unit, unrolled
+constexpr int NBUF = 4;                           // the staging stream runs three planes ahead of the arithmetic
+static_assert(DEPTH % NBUF == 0 && DEPTH % 2 == 0 && (DEPTH - 1) % 3 == 1, "image / V pair / slot phases of the unrolled unit");
 constexpr int ZB = NBUF * PLANE_LDS;              // the exchange: 2 x [a 4][q 2][cout tile 2][64 lanes][16 B]
 // residual records of one output plane of a unit: 2 rows x 32 voxels at the same 9-slot pitch (the epilogue's 8-byte reads walk them
-// with stride 18 slots: two-way conflicts at worst), 576 slots in 9 one-KiB pieces; two images (one barrier per step)
-constexpr int RB = ZB + 2 * 16384, RDPW = 3, RES_LDS = 4 * RDPW * 1024;
-constexpr int LDS_BYTES = RB + 2 * RES_LDS;       // 118,784
+// with stride 18 slots: two-way conflicts at worst), 576 slots in 9 one-KiB pieces; three images (a unit's last plane is requested a
+// step early)
+constexpr int RB = ZB + 2 * 16384, RDPW = 3, RES_LDS = 4 * RDPW * 1024, NRES = 3;
+constexpr int EB = RB + NRES * RES_LDS;           // scale[32] | shift[32]
+constexpr int LDS_BYTES = EB + 256;               // 151,808
 static_assert(PLANE_SLOTS <= NDMA * 64, "DMA pieces cover the image");
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 }  // namespace wn
 
-template <int ABL>
+template <int ABL, bool RES>
 __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     using namespace wn;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -164,16 +165,16 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
         for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
             for (int c = 0; c < 2; ++c) asm volatile("" : "+a"(wh[b][kd][c]), "+a"(wl[b][kd][c]));
+    const f32x4 esc_[2] = {*reinterpret_cast<const f32x4*>(a.scale + kg * 4), *reinterpret_cast<const f32x4*>(a.scale + 16 + kg * 4)};
+    const f32x4 esh_[2] = {*reinterpret_cast<const f32x4*>(a.shift + kg * 4), *reinterpret_cast<const f32x4*>(a.shift + 16 + kg * 4)};
     __builtin_amdgcn_sched_barrier(0);
 
-    const f32x4 esc[2] = {*reinterpret_cast<const f32x4*>(a.scale + kg * 4), *reinterpret_cast<const f32x4*>(a.scale + 16 + kg * 4)};
-    const f32x4 esh[2] = {*reinterpret_cast<const f32x4*>(a.shift + kg * 4), *reinterpret_cast<const f32x4*>(a.shift + 16 + kg * 4)};
     const int lane_out = (2 * n) * 128 + (kg >> 1) * 16 + (kg & 1) * 8;       // this lane's 8-byte hi piece of an output voxel's slice 0
     // fragment reads: this lane's hi piece (slice kg >> 1, channel half kg & 1) of column 2 n in patch rows i0 / i1, image 0
     const int rd0 = ((i0 * 2 * HALF + n) * PITCH + (kg >> 1) * 4 + (kg & 1)) * 16;
     const int rd1 = ((i1 * 2 * HALF + n) * PITCH + (kg >> 1) * 4 + (kg & 1)) * 16;
-    // ---- DMA plan: piece m = wv + 4 k fills slots [64 m, 64 m + 64) of an image ----
-    unsigned voff[DPW];
+    // ---- DMA plans: piece m = wv + 4 k fills slots [64 m, 64 m + 64) of an image ----
+    unsigned voff[DPW], rvoff[RDPW];
 #pragma unroll
     for (int k = 0; k < DPW; ++k) {
         const int sl = (wv + 4 * k) * 64 + lane;
@@ -183,8 +184,6 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
         voff[k] = (sl < PLANE_SLOTS && piece < 8) ? (unsigned)((row * Wp + 2 * idx + par) * 128 + piece * 16)
                                                   : 0xffffff00u;          // pads: beyond num_records, zero-filled
     }
-
-    unsigned rvoff[RDPW];
 #pragma unroll
     for (int k = 0; k < RDPW; ++k) {
         const int sl = (wv + 4 * k) * 64 + lane;
@@ -195,42 +194,37 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     const int rrd = ((pa * 32 + 2 * n + q) * PITCH + (kg >> 1)) * 16 + (kg & 1) * 8;
 
     f32x4 Y[3][4][2];
-    u32x4 vh[4], vl[4];
-    u32x4 raw[2][4][2];            // [patch row i0 | i1][column][hi | lo]
+    u32x4 vh[2][4], vl[2][4];      // V of the plane being multiplied | of the next one (written while the first is read)
+    u32x4 raw[2][4][2];            // [patch row i0 | i1][column][hi | lo] of the plane being transformed
+    float T[2][4];                 // h-pass of one channel pair: [lo | hi half][column]
 
     const int G = gridDim.x;
     const int nmine = ((int)a.total_units - (int)blockIdx.x + G - 1) / G;     // units of this workgroup
-    const int nstream = nmine * (a.D + 1);                                     // its plane stream: per unit the real planes 0 .. D - 1 and the zero border D
 
-// descriptor whose base is the patch origin of unit U (padded rows 2 r .., columns 32 c ..)
-#define WN_DESC(U)                                                                                          \
+// descriptor whose base is the patch origin of unit U (padded rows 2 r .., columns 32 c ..); no records past the workgroup's last unit:
+// requests through it write zeros
+#define WN_DESC(U, LIVE)                                                                                    \
     ({                                                                                                      \
         const int c_ = (U) % a.groups_w, t_ = (U) / a.groups_w;                                             \
         const int r_ = t_ % a.tiles_h, b_ = t_ / a.tiles_h;                                                 \
-        const long long off_ = b_ * frame_bytes + ((long long)(2 * r_) * Wp + 32 * c_) * 128;               \
+        const long long off_ = (LIVE) ? b_ * frame_bytes + ((long long)(2 * r_) * Wp + 32 * c_) * 128 : 0;  \
         const long long left_ = total_bytes - off_;                                                         \
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.x) + off_, 0,                        \
-                                          left_ > 0x7fffff00ll ? 0x7fffff00 : (int)left_, 0x00020000);      \
+                                          (LIVE) ? (left_ > 0x7fffff00ll ? 0x7fffff00 : (int)left_) : 0, 0x00020000); \
     })
-// the staging stream runs two planes ahead of the arithmetic
-    int dk = 0, dp = 0, dg = 0, dbuf = 0;             // unit index, plane, stream position, image of the next plane to request
-    auto dsc = WN_DESC((int)blockIdx.x);
-#define WN_DMA()                                                                                            \
+// Staging: input plane (P + 3) of the plane stream -- of this unit, or of the next one from P = D - 3 on -- goes to image (P + 3) % 4
+// (D % 4 == 0: the images keep their phase over units); the residual records of plane P to image `ri` of a ring of three.
+#define WN_DMA_ISSUE(P3, K0, K1)                                                                            \
+    _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_)                                                  \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds((P3) < DEPTH ? dsc : dsc_next,                             \
+                                                 (__attribute__((address_space(3))) void*)(lds + ((P3) % NBUF) * PLANE_LDS + (wv + 4 * k_) * 1024), \
+                                                 16, voff[k_], (unsigned)(((P3) % DEPTH + 1) * plane_bytes), 0, 0);
+#define WN_RES_DMA(IMG, OPLANE)                                                                             \
     {                                                                                                       \
-        if (dg < nstream) {                                                                                 \
-            const unsigned so_ = (unsigned)((dp + 1) * plane_bytes);                                        \
-            unsigned char* dst_ = lds + dbuf * PLANE_LDS;                                                   \
-            dbuf = dbuf == NBUF - 1 ? 0 : dbuf + 1;                                                         \
-            _Pragma("unroll") for (int k_ = 0; k_ < DPW; ++k_)                                              \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(dsc, (__attribute__((address_space(3))) void*)(dst_ + (wv + 4 * k_) * 1024), \
-                                                         16, voff[k_], so_, 0, 0);                          \
-            ++dg;                                                                                           \
-            if (++dp > a.D) {                                                                               \
-                dp = 0;                                                                                     \
-                ++dk;                                                                                       \
-                if (dk < nmine) dsc = WN_DESC((int)blockIdx.x + dk * G);                                    \
-            }                                                                                               \
-        }                                                                                                   \
+        const unsigned so_ = (unsigned)(((OPLANE) + 1) * plane_bytes);                                      \
+        _Pragma("unroll") for (int k_ = 0; k_ < RDPW; ++k_)                                                 \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdsc, (__attribute__((address_space(3))) void*)(lds + RB + (IMG) * RES_LDS + (wv + 4 * k_) * 1024), \
+                                                     16, rvoff[k_], so_, 0, 0);                             \
     }
 #define WN_READ(BUF_)                                                                                       \
     {                                                                                                       \
@@ -243,24 +237,51 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
             raw[1][j_][1] = *reinterpret_cast<const u32x4*>(im_ + rd1 + o_ + 32);                           \
         }                                                                                                   \
     }
-// raw -> V (all four b of this wave's a), split, in the B-operand layout: lane (tile n, kg) holds channels 8 kg .. 8 kg + 7
-#define WN_TRANSFORM()                                                                                      \
-    _Pragma("unroll") for (int d_ = 0; d_ < 4; ++d_) {                                                      \
-        float tl_[4], th_[4];                                                                               \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                  \
-            tl_[j_] = mix_sum_lo(raw[0][j_][0][d_], raw[0][j_][1][d_]);                                     \
-            tl_[j_] = mix_fma_lo(raw[1][j_][0][d_], sgn, tl_[j_]);                                          \
-            tl_[j_] = mix_fma_lo(raw[1][j_][1][d_], sgn, tl_[j_]);                                          \
-            th_[j_] = mix_sum_hi(raw[0][j_][0][d_], raw[0][j_][1][d_]);                                     \
-            th_[j_] = mix_fma_hi(raw[1][j_][0][d_], sgn, th_[j_]);                                          \
-            th_[j_] = mix_fma_hi(raw[1][j_][1][d_], sgn, th_[j_]);                                          \
+// One piece of the transform raw -> V[VN] (all four b of this wave's a; split; B-operand layout: lane (tile n, kg) holds channels
+// 8 kg .. 8 kg + 7), sized to ride behind one MFMA: M = 0 .. 71 -> channel pair d = M / 18 and, within it, 8 pieces of the h-pass (one
+// (column, half) each: 3 dependent mixed-precision fmas), then per b one piece of the w-pass + range clamp (4 instructions) and one of
+// the split (4); piece 16 closes the last b, piece 17 carries the step's staging requests.
+#define WN_TPIECE(M, VN)                                                                                    \
+    {                                                                                                       \
+        constexpr int d_ = (M) / 18, r_ = (M) % 18;                                                         \
+        if constexpr (r_ < 8) {                                                                             \
+            constexpr int j_ = r_ >> 1;                                                                     \
+            /* ONE asm statement per chain: hipcc pads every VGPR an asm statement defines against a use by the very next instruction \
+               (it must assume a partial-register write), 4 cycles per pad, and only its own instructions count as distance */ \
+            if constexpr ((r_ & 1) == 0) {                                                                  \
+                asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"                    \
+                    "v_fma_mix_f32 %0, %3, %5, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"                     \
+                    "v_fma_mix_f32 %0, %4, %5, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]"                          \
+                    : "=&v"(T[0][j_]) : "v"(raw[0][j_][0][d_]), "v"(raw[0][j_][1][d_]), "v"(raw[1][j_][0][d_]), "v"(raw[1][j_][1][d_]), "s"(sgn)); \
+            } else {                                                                                        \
+                asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]\n\t"                    \
+                    "v_fma_mix_f32 %0, %3, %5, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"                     \
+                    "v_fma_mix_f32 %0, %4, %5, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]"                          \
+                    : "=&v"(T[1][j_]) : "v"(raw[0][j_][0][d_]), "v"(raw[0][j_][1][d_]), "v"(raw[1][j_][0][d_]), "v"(raw[1][j_][1][d_]), "s"(sgn)); \
+            }                                                                                               \
+        } else if constexpr (r_ < 16) {                                                                     \
+            constexpr int b_ = (r_ - 8) >> 1;                                                               \
+            constexpr int x_ = b_ == 0 ? 0 : (b_ == 2 ? 2 : 1), y_ = b_ == 0 ? 2 : (b_ == 1 ? 2 : (b_ == 2 ? 1 : 3)); \
+            if constexpr (((r_ - 8) & 1) == 0) {                                                            \
+                X0 = sf_clamp<true>(b_ == 1 ? T[0][x_] + T[0][y_] : T[0][x_] - T[0][y_]);                   \
+                X1 = sf_clamp<true>(b_ == 1 ? T[1][x_] + T[1][y_] : T[1][x_] - T[1][y_]);                   \
+                if constexpr (b_ > 0) vl[VN][b_ - 1][d_] = sf_cvt_pk<true>(L0, L1);     /* (the lo halves of the b before: not right behind the asm that made them) */ \
+            } else {                                                                                        \
+                const unsigned h_ = sf_cvt_pk<true>(X0, X1);                                                \
+                vh[VN][b_][d_] = h_;                                                                        \
+                asm("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"                   \
+                    "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"                        \
+                    : "=&v"(L0), "=&v"(L1) : "v"(h_), "v"(X0), "v"(X1));                                    \
+            }                                                                                               \
+        } else if constexpr (r_ == 16) {                                                                    \
+            vl[VN][3][d_] = sf_cvt_pk<true>(L0, L1);                                                        \
         }                                                                                                   \
-        unsigned h_, l_;                                                                                    \
-        split_pair(tl_[0] - tl_[2], th_[0] - th_[2], h_, l_); vh[0][d_] = h_; vl[0][d_] = l_;               \
-        split_pair(tl_[1] + tl_[2], th_[1] + th_[2], h_, l_); vh[1][d_] = h_; vl[1][d_] = l_;               \
-        split_pair(tl_[2] - tl_[1], th_[2] - th_[1], h_, l_); vh[2][d_] = h_; vl[2][d_] = l_;               \
-        split_pair(tl_[1] - tl_[3], th_[1] - th_[3], h_, l_); vh[3][d_] = h_; vl[3][d_] = l_;               \
     }
+#define WN_DPIECE(M, P)                                                                                     \
+    if constexpr ((M) == 17) { if constexpr (RES) { WN_RES_DMA(ri, P) } }                                   \
+    else if constexpr ((M) == 35) { WN_DMA_ISSUE((P) + 3, 0, 2) }                                           \
+    else if constexpr ((M) == 53) { WN_DMA_ISSUE((P) + 3, 2, 4) }                                           \
+    else if constexpr ((M) == 71) { WN_DMA_ISSUE((P) + 3, 4, 5) }
 #define WN_STAMP(K)                                                                                         \
     if constexpr (ABL & 16) {                                                                               \
         unsigned long long t_;                                                                              \
@@ -268,99 +289,146 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
         tsum[K] += t_ - tlast;                                                                              \
         tlast = t_;                                                                                         \
     }
-
-// One plane step.  P = real input plane 0 .. D (D = the zero border: it only finishes the last output plane).  Open output planes:
-// P + 1 in slot SI (first contribution: C = 0), P in slot SM, P - 1 in slot SF (last contribution; finished here).
-#define WN_STEP(P, SI, SM, SF)                                                                              \
-    {                                                                                                       \
-        const int p_ = (P);                                                                                 \
-        const int o_ = p_ - 1;                          /* the output plane finished in this step (-1: none) */ \
-        WN_STAMP(0)                                                                                         \
-        /* residual records of the plane finished in this step: staged like the input (every global read of the kernel is an LDS-DMA \
-           request waited for by hand: hipcc's vmcnt bookkeeping does not count them, its waits for ordinary loads would drain the stream) */ \
-        unsigned char* rim_ = lds + RB + (g & 1) * RES_LDS;                                                 \
-        if (a.res) {                                                                                        \
-            const unsigned so_ = (unsigned)((o_ + 1) * plane_bytes);                                        \
-            _Pragma("unroll") for (int k_ = 0; k_ < RDPW; ++k_)                                             \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rdsc, (__attribute__((address_space(3))) void*)(rim_ + (wv + 4 * k_) * 1024), \
-                                                         16, rvoff[k_], so_, 0, 0);                         \
+// the finished accumulators of slot SF leave through A^T: over b inside the wave, over a across the waves (LDS); then wave (pa, q)
+// finishes its output voxel of every tile
+#define WN_OUT_WRITE(SF, ZIMG)                                                                              \
+    _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) {                                                      \
+        f32x4 y0_ = Y[SF][0][c_], y1_ = Y[SF][1][c_], y2_ = Y[SF][2][c_], y3_ = Y[SF][3][c_];               \
+        if constexpr ((SF) >= 1) {      /* out of the accumulator file WHOLE (element-wise reads of an asm "+a" vector gave stale values, hipcc 7.2) */ \
+            asm volatile("" : "+v"(y0_), "+v"(y1_), "+v"(y2_), "+v"(y3_));                                  \
         }                                                                                                   \
-        const bool dma_ = dg < nstream;                                                                     \
-        if constexpr (!(ABL & 4)) { WN_DMA() }          /* the plane two steps ahead */                    \
+        const f32x4 z0_ = (y0_ + y1_) + y2_;                                                                \
+        const f32x4 z1_ = (y1_ - y2_) - y3_;                                                                \
+        *reinterpret_cast<f32x4*>(lds + ZB + (ZIMG) * 16384 + ((wv * 2 + 0) * 2 + c_) * 1024 + lane * 16) = z0_; \
+        *reinterpret_cast<f32x4*>(lds + ZB + (ZIMG) * 16384 + ((wv * 2 + 1) * 2 + c_) * 1024 + lane * 16) = z1_; \
+    }
+#define WN_EPI_READS(ZIMG)                                                                                  \
+    f32x4 zz_[2][3];                                                                                        \
+    u32x2 rh_[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}}, rl_[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};                 \
+    _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_)                                                        \
+        _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_)                                                    \
+            zz_[c_][k_] = *reinterpret_cast<const f32x4*>(lds + ZB + (ZIMG) * 16384 + (((pa + k_) * 2 + q) * 2 + c_) * 1024 + lane * 16); \
+    if constexpr (RES) {                                                                                    \
+        _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) {                                                  \
+            rh_[c_] = *reinterpret_cast<const u32x2*>(rim_ + rrd + c_ * 64);                                \
+            rl_[c_] = *reinterpret_cast<const u32x2*>(rim_ + rrd + c_ * 64 + 32);                           \
+        }                                                                                                   \
+    }
+#define WN_EPILOGUE(O)                                                                                      \
+    _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) {                                                      \
+        f32x4 t_ = zz_[c_][0] + osg * (zz_[c_][1] + zz_[c_][2]);                                            \
+        t_ = t_ * esc_[c_] + esh_[c_];                                                                      \
+        if constexpr (RES) {                                                                                \
+            t_[0] = mix_add_lo(rl_[c_][0], mix_add_lo(rh_[c_][0], t_[0]));                                  \
+            t_[1] = mix_add_hi(rl_[c_][0], mix_add_hi(rh_[c_][0], t_[1]));                                  \
+            t_[2] = mix_add_lo(rl_[c_][1], mix_add_lo(rh_[c_][1], t_[2]));                                  \
+            t_[3] = mix_add_hi(rl_[c_][1], mix_add_hi(rh_[c_][1], t_[3]));                                  \
+        }                                                                                                   \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) t_[e_] = __builtin_fmaxf(t_[e_], t_[e_] * a.neg_slope); \
+        unsigned h0_, l0_, h1_, l1_;                                                                        \
+        split_pair(t_[0], t_[1], h0_, l0_);                                                                 \
+        split_pair(t_[2], t_[3], h1_, l1_);                                                                 \
+        unsigned char* q_ = yb + (long long)((O) + 1) * plane_bytes + lane_out + c_ * 64;                   \
+        *reinterpret_cast<u32x2*>(q_) = u32x2{h0_, h1_};                                                    \
+        *reinterpret_cast<u32x2*>(q_ + 32) = u32x2{l0_, l1_};                                               \
+    }
+// one MFMA and the pieces that ride behind it (term-major inside a depth tap: the three products of an accumulator are 8 MFMAs apart;
+// the accumulators finished in this step first).  Depth taps that fall on the zero border have no MFMAs: kd = 2 of plane 0 (output
+// plane -1), kd = 0 of plane D - 1 (output plane D); an output plane's first contribution starts its accumulators (C = 0).
+#define WN_SLOT(M, P, SI, SM, SF, VB)                                                                       \
+    {                                                                                                       \
+        constexpr int g_ = (M) / 24, w_ = (M) % 24, tm_ = w_ / 8, b_ = (w_ % 8) / 2, c_ = w_ % 2;           \
+        constexpr int kd_ = 2 - g_, s_ = g_ == 0 ? (SF) : (g_ == 1 ? (SM) : (SI));                          \
+        constexpr bool live_ = !(g_ == 0 && (P) == 0) && !(g_ == 2 && (P) == DEPTH - 1);                    \
+        constexpr bool first_ = tm_ == 0 && (g_ == 2 || (g_ == 1 && (P) == 0));                             \
+        if constexpr (live_ && !(ABL & 1)) {                                                                \
+            if constexpr (s_ >= 1) {                                                                        \
+                if constexpr (first_) { WN_MFA0(Y[s_][b_][c_], wl[b_][kd_][c_], vh[VB][b_]) }               \
+                else if constexpr (tm_ == 0) { WN_MFA(Y[s_][b_][c_], wl[b_][kd_][c_], vh[VB][b_]) }         \
+                else if constexpr (tm_ == 1) { WN_MFA(Y[s_][b_][c_], wh[b_][kd_][c_], vl[VB][b_]) }         \
+                else { WN_MFA(Y[s_][b_][c_], wh[b_][kd_][c_], vh[VB][b_]) }                                 \
+            } else {                                                                                        \
+                if constexpr (first_) { WN_MF0(Y[s_][b_][c_], wl[b_][kd_][c_], vh[VB][b_]) }                \
+                else if constexpr (tm_ == 0) { WN_MF(Y[s_][b_][c_], wl[b_][kd_][c_], vh[VB][b_]) }          \
+                else if constexpr (tm_ == 1) { WN_MF(Y[s_][b_][c_], wh[b_][kd_][c_], vl[VB][b_]) }          \
+                else { WN_MF(Y[s_][b_][c_], wh[b_][kd_][c_], vh[VB][b_]) }                                  \
+            }                                                                                               \
+        }                                                                                                   \
+        if constexpr (!(ABL & 2)) { WN_TPIECE(M, (VB) ^ 1) }                                                \
+        if constexpr (!(ABL & 4)) { WN_DPIECE(M, P) }                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }
+#define WN_S8(M, P, SI, SM, SF, VB)                                                                         \
+    WN_SLOT(M, P, SI, SM, SF, VB) WN_SLOT(M + 1, P, SI, SM, SF, VB) WN_SLOT(M + 2, P, SI, SM, SF, VB) WN_SLOT(M + 3, P, SI, SM, SF, VB) \
+    WN_SLOT(M + 4, P, SI, SM, SF, VB) WN_SLOT(M + 5, P, SI, SM, SF, VB) WN_SLOT(M + 6, P, SI, SM, SF, VB) WN_SLOT(M + 7, P, SI, SM, SF, VB)
+
+// One plane step, P = 0 .. D - 1 (a compile-time constant: a unit is ONE basic block -- hipcc re-homes asm-tied accumulators at block
+// boundaries, behind the back of the hazards it cannot see).  V of plane P in vh / vl[VB]; raw holds the NEXT plane of the stream (the
+// next unit's first after P = D - 1), whose V goes to vh / vl[VB ^ 1] piece by piece behind this plane's MFMAs.  Open output planes:
+// P + 1 in slot SI, P in slot SM, P - 1 in slot SF (last contribution: leaves through the exchange at the end of the step).
+#define WN_STEP(P, SI, SM, SF, VB)                                                                          \
+    {                                                                                                       \
+        WN_STAMP(0)                                                                                         \
+        /* every global read of the kernel is an LDS-DMA request waited for by hand (hipcc's vmcnt bookkeeping does not count them: \
+           its own waits for ordinary loads would drain the stream).  Per step, in this order: the residual records of plane P (for the \
+           epilogue ONE step later -- the next step's, or the unit's closing one), then the input plane three steps ahead */ \
+        unsigned char* rim_ = lds + RB + rprev * RES_LDS;                                                   \
         asm volatile("s_nop 1");                                                                            \
-        WN_STAMP(1)                                                                                         \
-        if constexpr (!(ABL & 1)) {                                                                         \
-        WN_GROUP(SF, 2, WN_MF)                                                                              \
-        WN_GROUP(SM, 1, WN_MF)                                                                              \
-        WN_GROUP(SI, 0, WN_MF0)                                                                             \
+        {                                                                                                   \
+            float X0 = 0.f, X1 = 0.f, L0 = 0.f, L1 = 0.f;                                                   \
+            WN_S8(0, P, SI, SM, SF, VB) WN_S8(8, P, SI, SM, SF, VB) WN_S8(16, P, SI, SM, SF, VB)            \
+            WN_S8(24, P, SI, SM, SF, VB) WN_S8(32, P, SI, SM, SF, VB) WN_S8(40, P, SI, SM, SF, VB)          \
+            WN_S8(48, P, SI, SM, SF, VB) WN_S8(56, P, SI, SM, SF, VB) WN_S8(64, P, SI, SM, SF, VB)          \
         }                                                                                                   \
         WN_PAD()                                                                                            \
         WN_STAMP(2)                                                                                         \
-        /* A^T over b inside the wave, then across the waves through LDS */                                 \
-        unsigned char* zb_ = lds + ZB + (g & 1) * 16384;   /* alternating over ALL steps of the walk: one barrier per step is enough */ \
-        _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) {                                                  \
-            const f32x4 z0_ = (Y[SF][0][c_] + Y[SF][1][c_]) + Y[SF][2][c_];                                 \
-            const f32x4 z1_ = (Y[SF][1][c_] - Y[SF][2][c_]) - Y[SF][3][c_];                                 \
-            *reinterpret_cast<f32x4*>(zb_ + ((wv * 2 + 0) * 2 + c_) * 1024 + lane * 16) = z0_;              \
-            *reinterpret_cast<f32x4*>(zb_ + ((wv * 2 + 1) * 2 + c_) * 1024 + lane * 16) = z1_;              \
-        }                                                                                                   \
-        /* everything older than this step's staging requests has landed: the residual, and the image of the NEXT plane */ \
-        if (dma_) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");                               \
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
+        if constexpr ((P) > 0) { WN_OUT_WRITE(SF, ((P) - 1) & 1) }                                          \
+        /* everything older than this step's requests has landed: the residual asked for a step ago, the image of the plane after the next */ \
+        if constexpr (RES) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                      \
+        else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");                                    \
         WN_STAMP(3)                                                                                         \
         __builtin_amdgcn_s_barrier();                                                                       \
         WN_STAMP(4)                                                                                         \
-        f32x4 zz_[2][3];                                                                                    \
-        u32x2 rh_[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}}, rl_[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};             \
-        if (a.res) {                                                                                        \
-            _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) {                                              \
-                rh_[c_] = *reinterpret_cast<const u32x2*>(rim_ + rrd + c_ * 64);                            \
-                rl_[c_] = *reinterpret_cast<const u32x2*>(rim_ + rrd + c_ * 64 + 32);                       \
-            }                                                                                               \
+        if constexpr ((P) > 0) {                                                                            \
+            WN_EPI_READS(((P) - 1) & 1)                                                                     \
+            WN_EPILOGUE((P) - 1)                                                                            \
         }                                                                                                   \
-        _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_)                                                    \
-            _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_)                                                \
-                zz_[c_][k_] = *reinterpret_cast<const f32x4*>(zb_ + (((pa + k_) * 2 + q) * 2 + c_) * 1024 + lane * 16); \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
-        if (g + 1 < nstream) { WN_READ(nbuf) }          /* behind the exchange reads: the epilogue starts on those */ \
-        __builtin_amdgcn_sched_barrier(0);                                                                  \
-        _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) {                                                  \
-            f32x4 t_ = zz_[c_][0] + osg * (zz_[c_][1] + zz_[c_][2]);                                        \
-            t_ = t_ * esc[c_] + esh[c_];                                                                    \
-            if (a.res) {                                                                                    \
-                t_[0] = mix_add_lo(rl_[c_][0], mix_add_lo(rh_[c_][0], t_[0]));                              \
-                t_[1] = mix_add_hi(rl_[c_][0], mix_add_hi(rh_[c_][0], t_[1]));                              \
-                t_[2] = mix_add_lo(rl_[c_][1], mix_add_lo(rh_[c_][1], t_[2]));                              \
-                t_[3] = mix_add_hi(rl_[c_][1], mix_add_hi(rh_[c_][1], t_[3]));                              \
-            }                                                                                               \
-            _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) t_[e_] = __builtin_fmaxf(t_[e_], t_[e_] * a.neg_slope); \
-            unsigned h0_, l0_, h1_, l1_;                                                                    \
-            split_pair(t_[0], t_[1], h0_, l0_);                                                             \
-            split_pair(t_[2], t_[3], h1_, l1_);                                                             \
-            if (o_ >= 0) {                                                                                  \
-                unsigned char* q_ = yb + (long long)(o_ + 1) * plane_bytes + lane_out + c_ * 64;            \
-                *reinterpret_cast<u32x2*>(q_) = u32x2{h0_, h1_};                                            \
-                *reinterpret_cast<u32x2*>(q_ + 32) = u32x2{l0_, l1_};                                       \
-            }                                                                                               \
-        }                                                                                                   \
+        WN_READ(((P) + 2) % NBUF)                       /* the plane after the next: its latency under the next step's start */ \
         WN_STAMP(5)                                                                                         \
-        if constexpr (!(ABL & 2)) { WN_TRANSFORM() }                                                        \
-        WN_STAMP(6)                                                                                         \
-        ++g;                                                                                                \
-        nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;                                                             \
+        rprev = ri;                                                                                         \
+        ri = ri == NRES - 1 ? 0 : ri + 1;                                                                   \
     }
+// the unit's last output plane (its slot got the last contribution in step D - 1: plane D is the zero border)
+#define WN_FINISH(SF)                                                                                       \
+    {                                                                                                       \
+        unsigned char* rim_ = lds + RB + rprev * RES_LDS;                                                   \
+        WN_OUT_WRITE(SF, (DEPTH - 1) & 1)                                                                   \
+        /* its residual was requested in the step before, in front of that step's input plane (5 requests) and output stores (4) */ \
+        asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");                                         \
+        __builtin_amdgcn_s_barrier();                                                                       \
+        WN_EPI_READS((DEPTH - 1) & 1)                                                                       \
+        WN_EPILOGUE(DEPTH - 1)                                                                              \
+    }
+#define WN_T8(M) WN_TPIECE(M, 0) WN_TPIECE(M + 1, 0) WN_TPIECE(M + 2, 0) WN_TPIECE(M + 3, 0) WN_TPIECE(M + 4, 0) WN_TPIECE(M + 5, 0) WN_TPIECE(M + 6, 0) WN_TPIECE(M + 7, 0)
 
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     if constexpr (ABL & 16) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
-    int g = 0;                                         // stream position of the plane being multiplied
-    // the first two planes of the stream; V of the first
-    WN_DMA()
-    WN_DMA()
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int ri = 0, rprev = 0;                             // residual image to request into / requested a step ago
+    auto dsc = WN_DESC((int)blockIdx.x, true);
+    auto dsc_next = dsc;
+    // the first three planes of the stream; V of the first; raw of the second
+    WN_DMA_ISSUE(0, 0, DPW)
+    WN_DMA_ISSUE(1, 0, DPW)
+    WN_DMA_ISSUE(2, 0, DPW)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     WN_READ(0)
-    WN_TRANSFORM()
-    int nbuf = 1;                                      // image of stream position g + 1
+    {
+        float X0 = 0.f, X1 = 0.f, L0 = 0.f, L1 = 0.f;
+        WN_T8(0) WN_T8(8) WN_T8(16) WN_T8(24) WN_T8(32) WN_T8(40) WN_T8(48) WN_T8(56) WN_T8(64)
+    }
+    WN_READ(1)
     for (int k = 0; k < nmine; ++k) {
         const int u = (int)blockIdx.x + k * G;
         const int c = u % a.groups_w;
@@ -371,19 +439,20 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
         unsigned char* yb = a.y + b * frame_bytes + ((long long)(2 * r + pa + 1) * Wp + 32 * c + q + 1) * 128;
         const long long roff = b * frame_bytes + ((long long)(2 * r + 1) * Wp + 32 * c + 1) * 128;      // the unit's output rows in the residual tensor
         const long long rleft = total_bytes - roff;
-        const auto rdsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.res ? a.res : a.x) + roff, 0,
+        const auto rdsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(RES ? a.res : a.x) + roff, 0,
                                                             rleft > 0x7fffff00ll ? 0x7fffff00 : (int)rleft, 0x00020000);
-#pragma unroll
-        for (int s_ = 0; s_ < 3; ++s_)         // slot 0 (output plane 0) must start at zero; the others only must not be undefined
-#pragma unroll
-            for (int b_ = 0; b_ < 4; ++b_)
-#pragma unroll
-                for (int c_ = 0; c_ < 2; ++c_) Y[s_][b_][c_] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int p0 = 0; p0 <= a.D; p0 += 3) {
-            WN_STEP(p0, 1, 0, 2)
-            if (p0 + 1 <= a.D) WN_STEP(p0 + 1, 2, 1, 0)
-            if (p0 + 2 <= a.D) WN_STEP(p0 + 2, 0, 2, 1)
-        }
+        dsc_next = WN_DESC(u + G, k + 1 < nmine);
+        // slots follow the plane mod 3, the V pair the plane mod 2
+        WN_STEP(0, 1, 0, 2, 0)
+        WN_STEP(1, 2, 1, 0, 1)
+        WN_STEP(2, 0, 2, 1, 0)
+        WN_STEP(3, 1, 0, 2, 1)
+        WN_STEP(4, 2, 1, 0, 0)
+        WN_STEP(5, 0, 2, 1, 1)
+        WN_STEP(6, 1, 0, 2, 0)
+        WN_STEP(7, 2, 1, 0, 1)
+        WN_FINISH(1)
+        dsc = dsc_next;
     }
     if constexpr (ABL & 16) {
         if (blockIdx.x == 0 && lane == 0 && a.dbg)
@@ -391,14 +460,18 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     }
 }
 
-template <int ABL>
-int wino_launch(const WinoArgs& a, long long units, hipStream_t st) {
+template <int ABL, bool RES>
+int wino_launch2(const WinoArgs& a, long long units, hipStream_t st) {
     static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
-    if (mvsgi::persistent_geometry(conv3d_wino32_kernel<ABL>, 256, wn::LDS_BYTES, 1, geo_cache, "conv3d(winograd)", geo)) return 1;
+    if (mvsgi::persistent_geometry(conv3d_wino32_kernel<ABL, RES>, 256, wn::LDS_BYTES, 1, geo_cache, "conv3d(winograd)", geo)) return 1;
     const unsigned grid = (unsigned)(units < geo.cus ? units : geo.cus);
-    hipLaunchKernelGGL(conv3d_wino32_kernel<ABL>, dim3(grid), dim3(256), wn::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv3d_wino32_kernel<ABL, RES>), dim3(grid), dim3(256), wn::LDS_BYTES, st, a);
     return 0;
+}
+template <int ABL>
+int wino_launch(const WinoArgs& a, long long units, hipStream_t st) {
+    return a.res ? wino_launch2<ABL, true>(a, units, st) : wino_launch2<ABL, false>(a, units, st);
 }
 
 }  // namespace
@@ -411,7 +484,8 @@ int mvsgi_conv3d_wino32_f16(const void* x_split, const void* w_packed, const flo
                             void* y_split, int B, int D, int H, int W, float neg_slope, void* stream) {
     MVSGI_REQUIRE(x_split && w_packed && scale && shift && y_split, "mvsgi_conv3d_wino32_f16: null pointer");
     MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_conv3d_wino32_f16: bad dims");
-    MVSGI_REQUIRE(H % 2 == 0 && W % 32 == 0, "mvsgi_conv3d_wino32_f16: needs H %% 2 == 0 and W %% 32 == 0 (got %d, %d)", H, W);
+    MVSGI_REQUIRE(D == wn::DEPTH && H % 2 == 0 && W % 32 == 0,
+                  "mvsgi_conv3d_wino32_f16: needs D == %d, H %% 2 == 0 and W %% 32 == 0 (got %d, %d, %d)", wn::DEPTH, D, H, W);
     MVSGI_REQUIRE(neg_slope >= 0.f && neg_slope <= 1.f, "mvsgi_conv3d_wino32_f16: neg_slope outside [0, 1]");
     MVSGI_REQUIRE((long long)B * (D + 2) * (H + 2) * (W + 2) * 128 < (1ll << 40), "mvsgi_conv3d_wino32_f16: tensor too large");
     MVSGI_REQUIRE((long long)(D + 2) * (H + 2) * (W + 2) * 128 < (1ll << 31), "mvsgi_conv3d_wino32_f16: frame too large for 32-bit plane offsets");
@@ -450,11 +524,6 @@ int mvsgi_conv3d_wino32_f16(const void* x_split, const void* w_packed, const flo
             }
             break;
         }
-        case 1: rc = wino_launch<1>(a, units, st); break;
-        case 2: rc = wino_launch<2>(a, units, st); break;
-        case 4: rc = wino_launch<4>(a, units, st); break;
-        case 6: rc = wino_launch<6>(a, units, st); break;
-        case 7: rc = wino_launch<7>(a, units, st); break;
         default: rc = wino_launch<0>(a, units, st);
     }
     if (rc) return rc;

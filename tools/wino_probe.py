@@ -35,6 +35,9 @@ for name, ys in (("direct f16x3", yd), ("winograd f16x3", yw)):
     y = H.act_from_split(ys)
     err = float((y - y_ref).abs().max()) / ref_max
     print(f"{name}: max rel error vs exact fp32 {err:.3e}  finite {bool(torch.isfinite(y).all())}")
+    if err > 1e-4:
+        print("  per plane:", [f"{float((y[:, k] - y_ref[:, k]).abs().max()) / ref_max:.1e}" for k in range(d)])
+        print("  per frame:", [f"{float((y[k] - y_ref[k]).abs().max()) / ref_max:.1e}" for k in range(min(B, 8))])
     bad = ((y - y_ref).abs() > 1e-3 * ref_max).nonzero()
     if bad.shape[0]:
         print("  bad voxels", bad.shape[0], bad[:8].tolist())
