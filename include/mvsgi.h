@@ -403,12 +403,16 @@ int mvsgi_conv3d_up2_poly_fmt(const void* x_split, const void* plan_dev, const f
 
 /* ---- Winograd F(2x2, 3x3) x direct-D form of the 32 -> 32 convolutions (csrc/conv3d_wino.hip) -------------------------
  * BaseConvBlk3d.forward (dsta_mvs/model/common/common_modules.py:107-115) for Cin = Cout = 32, stride 1, on split-padded
- * activations in the fp16 split (MVSGI_SPLIT_F16), H even, W a multiple of 32: 2.25 x fewer matrix instructions than the direct
+ * activations in the fp16 split (MVSGI_SPLIT_F16), D = 8, H even, W a multiple of 32: 2.25 x fewer matrix instructions than the direct
  * form.  Weights: U = G g G^T per (cout, cin, kd), pre-scaled per cout by a power of two (its inverse folded into `scale`),
  * split, as [a 4][b 4][kd 3][cout tile 2][hi | lo][64 lanes][16 B]. */
 size_t mvsgi_conv3d_wino32_packed_weight_bytes(void);
+int mvsgi_conv3d_wino32_applies(int Cin, int Cout, int D, int H, int W, int stride, float neg_slope);
+/* w_oidhw [32][32][3][3][3] -> w_packed (mvsgi_conv3d_wino32_packed_weight_bytes()), unscale [32] (2^-k per cout: multiply the layer's scale by it) */
+int mvsgi_conv3d_wino32_pack_weights(const float* w_oidhw, void* w_packed, float* unscale, mvsgi_stream_t stream);
+/* y: split-padded fp16 [B][D+2][H+2][W+2][32] (y_is_f32 == 0) or plain fp32 [B][D][H][W][32]; res_split: split-padded fp16 or NULL */
 int mvsgi_conv3d_wino32_f16(const void* x_split, const void* w_packed, const float* scale, const float* shift, const void* res_split,
-                            void* y_split, int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream);
+                            void* y, int y_is_f32, int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -19,8 +19,10 @@
 #include "common.hpp"
 
 #include <cstring>
-#include <cstdlib>
+#ifdef MVSGI_WINO_STAMPS
 #include <cstdio>
+#include <cstdlib>
+#endif
 
 namespace {
 
@@ -128,7 +130,8 @@ static_assert(PLANE_SLOTS <= NDMA * 64, "DMA pieces cover the image");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 }  // namespace wn
 
-template <int ABL, bool RES>
+// OUT32: the output is a plain fp32 channels-last tensor [B][D][H][W][32] (the hand-over to a kernel that stages fp32)
+template <int ABL, bool RES, bool OUT32>
 __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     using namespace wn;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -170,6 +173,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 
     const int lane_out = (2 * n) * 128 + (kg >> 1) * 16 + (kg & 1) * 8;       // this lane's 8-byte hi piece of an output voxel's slice 0
+    const int lane_out32 = (2 * n) * 128 + kg * 16;                           // (fp32 output: its 16 bytes = couts 4 kg .. 4 kg + 3 of the voxel's first 16)
+    const long long oplane_bytes = (long long)a.H * a.W * 128;
     // fragment reads: this lane's hi piece (slice kg >> 1, channel half kg & 1) of column 2 n in patch rows i0 / i1, image 0
     const int rd0 = ((i0 * 2 * HALF + n) * PITCH + (kg >> 1) * 4 + (kg & 1)) * 16;
     const int rd1 = ((i1 * 2 * HALF + n) * PITCH + (kg >> 1) * 4 + (kg & 1)) * 16;
@@ -325,12 +330,16 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
             t_[3] = mix_add_hi(rl_[c_][1], mix_add_hi(rh_[c_][1], t_[3]));                                  \
         }                                                                                                   \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) t_[e_] = __builtin_fmaxf(t_[e_], t_[e_] * a.neg_slope); \
-        unsigned h0_, l0_, h1_, l1_;                                                                        \
-        split_pair(t_[0], t_[1], h0_, l0_);                                                                 \
-        split_pair(t_[2], t_[3], h1_, l1_);                                                                 \
-        unsigned char* q_ = yb + (long long)((O) + 1) * plane_bytes + lane_out + c_ * 64;                   \
-        *reinterpret_cast<u32x2*>(q_) = u32x2{h0_, h1_};                                                    \
-        *reinterpret_cast<u32x2*>(q_ + 32) = u32x2{l0_, l1_};                                               \
+        if constexpr (OUT32) {                                                                              \
+            *reinterpret_cast<f32x4*>(yb + (long long)(O) * oplane_bytes + lane_out32 + c_ * 64) = t_;      \
+        } else {                                                                                            \
+            unsigned h0_, l0_, h1_, l1_;                                                                    \
+            split_pair(t_[0], t_[1], h0_, l0_);                                                             \
+            split_pair(t_[2], t_[3], h1_, l1_);                                                             \
+            unsigned char* q_ = yb + (long long)((O) + 1) * plane_bytes + lane_out + c_ * 64;               \
+            *reinterpret_cast<u32x2*>(q_) = u32x2{h0_, h1_};                                                \
+            *reinterpret_cast<u32x2*>(q_ + 32) = u32x2{l0_, l1_};                                           \
+        }                                                                                                   \
     }
 // one MFMA and the pieces that ride behind it (term-major inside a depth tap: the three products of an accumulator are 8 MFMAs apart;
 // the accumulators finished in this step first).  Depth taps that fall on the zero border have no MFMAs: kd = 2 of plane 0 (output
@@ -404,8 +413,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     {                                                                                                       \
         unsigned char* rim_ = lds + RB + rprev * RES_LDS;                                                   \
         WN_OUT_WRITE(SF, (DEPTH - 1) & 1)                                                                   \
-        /* its residual was requested in the step before, in front of that step's input plane (5 requests) and output stores (4) */ \
-        asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");                                         \
+        /* its residual was requested in the step before, in front of that step's input plane (5 requests) and output stores (4, or 2 fp32) */ \
+        if constexpr (OUT32) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");                    \
+        else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");                                    \
         __builtin_amdgcn_s_barrier();                                                                       \
         WN_EPI_READS((DEPTH - 1) & 1)                                                                       \
         WN_EPILOGUE(DEPTH - 1)                                                                              \
@@ -436,7 +446,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
         const int r = t % a.tiles_h;
         const int b = t / a.tiles_h;
         // this wave's output voxel origin (padded row 2 r + pa + 1, column 32 c + q + 1)
-        unsigned char* yb = a.y + b * frame_bytes + ((long long)(2 * r + pa + 1) * Wp + 32 * c + q + 1) * 128;
+        unsigned char* yb = OUT32 ? a.y + b * (a.D * oplane_bytes) + ((long long)(2 * r + pa) * a.W + 32 * c + q) * 128
+                                  : a.y + b * frame_bytes + ((long long)(2 * r + pa + 1) * Wp + 32 * c + q + 1) * 128;
         const long long roff = b * frame_bytes + ((long long)(2 * r + 1) * Wp + 32 * c + 1) * 128;      // the unit's output rows in the residual tensor
         const long long rleft = total_bytes - roff;
         const auto rdsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(RES ? a.res : a.x) + roff, 0,
@@ -460,18 +471,65 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     }
 }
 
-template <int ABL, bool RES>
-int wino_launch2(const WinoArgs& a, long long units, hipStream_t st) {
+template <int ABL, bool RES, bool OUT32>
+int wino_launch3(const WinoArgs& a, long long units, hipStream_t st) {
     static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
-    if (mvsgi::persistent_geometry(conv3d_wino32_kernel<ABL, RES>, 256, wn::LDS_BYTES, 1, geo_cache, "conv3d(winograd)", geo)) return 1;
+    if (mvsgi::persistent_geometry(conv3d_wino32_kernel<ABL, RES, OUT32>, 256, wn::LDS_BYTES, 1, geo_cache, "conv3d(winograd)", geo)) return 1;
     const unsigned grid = (unsigned)(units < geo.cus ? units : geo.cus);
-    hipLaunchKernelGGL((conv3d_wino32_kernel<ABL, RES>), dim3(grid), dim3(256), wn::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv3d_wino32_kernel<ABL, RES, OUT32>), dim3(grid), dim3(256), wn::LDS_BYTES, st, a);
     return 0;
 }
 template <int ABL>
-int wino_launch(const WinoArgs& a, long long units, hipStream_t st) {
-    return a.res ? wino_launch2<ABL, true>(a, units, st) : wino_launch2<ABL, false>(a, units, st);
+int wino_launch(const WinoArgs& a, long long units, bool out32, hipStream_t st) {
+    if (out32) return a.res ? wino_launch3<ABL, true, true>(a, units, st) : wino_launch3<ABL, false, true>(a, units, st);
+    return a.res ? wino_launch3<ABL, true, false>(a, units, st) : wino_launch3<ABL, false, false>(a, units, st);
+}
+
+// [32][32][27] -> U = G g G^T per (cout, cin, kd), pre-scaled per cout by a power of two so that max |U| lies in (512, 1024], split, in
+// the MFMA's A-operand order [a][b][kd][cout tile][hi | lo][lane = (cin group) * 16 + cout][8 cins]; unscale[cout] = 2^-k.
+// One workgroup per cout: thread (ci = t & 31, group = t >> 5) computes 6 of the 48 (a, b, kd).
+__global__ __launch_bounds__(256) void wino_pack_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, float* __restrict__ unscale) {
+    __shared__ float red[256];
+    const int co = blockIdx.x, t = threadIdx.x, ci = t & 31, grp = t >> 5;
+    constexpr float Gm[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    const float* g = w + ((long long)co * 32 + ci) * 27;
+    float u[6], amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int e = grp * 6 + i, kd = e % 3, ab = e / 3, a_ = ab >> 2, b_ = ab & 3;
+        float acc = 0.f;
+        for (int kh = 0; kh < 3; ++kh)
+            for (int kw = 0; kw < 3; ++kw) acc += Gm[a_][kh] * Gm[b_][kw] * g[kd * 9 + kh * 3 + kw];
+        u[i] = acc;
+        amax = fmaxf(amax, fabsf(acc));
+    }
+    red[t] = amax;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if (t < sft) red[t] = fmaxf(red[t], red[t + sft]);
+        __syncthreads();
+    }
+    amax = red[0];
+    int k = 0;
+    if (amax > 0.f) {
+        int e;
+        const float m = frexpf(amax, &e);          // amax = m * 2^e, m in [0.5, 1)
+        k = m == 0.5f ? 11 - e : 10 - e;            // amax * 2^k in (512, 1024]
+        k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    }
+    const float up = ldexpf(1.f, k);
+    if (t == 0) unscale[co] = ldexpf(1.f, -k);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int e = grp * 6 + i, kd = e % 3, ab = e / 3;
+        unsigned short hi, lo;
+        sf_split_weight(u[i] * up, true, hi, lo);
+        const long long frag = (((long long)ab * 3 + kd) * 2 + (co >> 4)) * 2;
+        const int lane = (ci >> 3) * 16 + (co & 15);
+        wp[((frag + 0) * 64 + lane) * 8 + (ci & 7)] = hi;
+        wp[((frag + 1) * 64 + lane) * 8 + (ci & 7)] = lo;
+    }
 }
 
 }  // namespace
@@ -480,9 +538,21 @@ extern "C" {
 
 size_t mvsgi_conv3d_wino32_packed_weight_bytes(void) { return (size_t)4 * 4 * 3 * 2 * 2 * 64 * 16; }
 
+int mvsgi_conv3d_wino32_applies(int Cin, int Cout, int D, int H, int W, int stride, float neg_slope) {
+    return Cin == 32 && Cout == 32 && stride == 1 && D == wn::DEPTH && H > 0 && W > 0 && H % 2 == 0 && W % 32 == 0 && neg_slope >= 0.f && neg_slope <= 1.f &&
+           (long long)(D + 2) * (H + 2) * (W + 2) * 128 < (1ll << 31);
+}
+
+int mvsgi_conv3d_wino32_pack_weights(const float* w_oidhw, void* w_packed, float* unscale, void* stream) {
+    MVSGI_REQUIRE(w_oidhw && w_packed && unscale, "mvsgi_conv3d_wino32_pack_weights: null pointer");
+    hipLaunchKernelGGL(wino_pack_weights_kernel, dim3(32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w_oidhw,
+                       reinterpret_cast<unsigned short*>(w_packed), unscale);
+    return mvsgi::check_launch("mvsgi_conv3d_wino32_pack_weights");
+}
+
 int mvsgi_conv3d_wino32_f16(const void* x_split, const void* w_packed, const float* scale, const float* shift, const void* res_split,
-                            void* y_split, int B, int D, int H, int W, float neg_slope, void* stream) {
-    MVSGI_REQUIRE(x_split && w_packed && scale && shift && y_split, "mvsgi_conv3d_wino32_f16: null pointer");
+                            void* y, int y_is_f32, int B, int D, int H, int W, float neg_slope, void* stream) {
+    MVSGI_REQUIRE(x_split && w_packed && scale && shift && y, "mvsgi_conv3d_wino32_f16: null pointer");
     MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_conv3d_wino32_f16: bad dims");
     MVSGI_REQUIRE(D == wn::DEPTH && H % 2 == 0 && W % 32 == 0,
                   "mvsgi_conv3d_wino32_f16: needs D == %d, H %% 2 == 0 and W %% 32 == 0 (got %d, %d, %d)", wn::DEPTH, D, H, W);
@@ -492,7 +562,7 @@ int mvsgi_conv3d_wino32_f16(const void* x_split, const void* w_packed, const flo
     WinoArgs a;
     memset(&a, 0, sizeof(a));
     a.x = reinterpret_cast<const unsigned char*>(x_split);
-    a.y = reinterpret_cast<unsigned char*>(y_split);
+    a.y = reinterpret_cast<unsigned char*>(y);
     a.res = reinterpret_cast<const unsigned char*>(res_split);
     a.wp = reinterpret_cast<const u32x4*>(w_packed);
     a.scale = scale;
@@ -505,28 +575,24 @@ int mvsgi_conv3d_wino32_f16(const void* x_split, const void* w_packed, const flo
     MVSGI_REQUIRE(units < (1ll << 31), "mvsgi_conv3d_wino32_f16: too many units");
     a.total_units = (int)units;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const char* e_ = getenv("MVSGI_WINO_ABL");
-    const int abl = e_ ? atoi(e_) : 0;
-    int rc = 0;
-    switch (abl) {
-        case 16: {
-            static unsigned long long* dbg = nullptr;
-            if (!dbg) (void)hipMalloc(&dbg, 32 * 8);
-            a.dbg = dbg;
-            rc = wino_launch<16>(a, units, st);
-            (void)hipDeviceSynchronize();
-            unsigned long long h[32];
-            (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-            for (int w = 0; w < 4; ++w) {
-                fprintf(stderr, "wave %d:", w);
-                for (int k = 0; k < 7; ++k) fprintf(stderr, " %llu", h[w * 8 + k]);
-                fprintf(stderr, "\n");
-            }
-            break;
+#ifdef MVSGI_WINO_STAMPS      // diagnostic build: cycles per step section of workgroup 0 (tools/wino_probe.py)
+    if (getenv("MVSGI_WINO_STAMP")) {
+        static unsigned long long* dbg = nullptr;
+        if (!dbg) (void)hipMalloc(&dbg, 32 * 8);
+        a.dbg = dbg;
+        if (wino_launch<16>(a, units, y_is_f32 != 0, st)) return 1;
+        (void)hipDeviceSynchronize();
+        unsigned long long h[32];
+        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        for (int w = 0; w < 4; ++w) {
+            fprintf(stderr, "wave %d:", w);
+            for (int k = 0; k < 7; ++k) fprintf(stderr, " %llu", h[w * 8 + k]);
+            fprintf(stderr, "\n");
         }
-        default: rc = wino_launch<0>(a, units, st);
+        return mvsgi::check_launch("mvsgi_conv3d_wino32_f16");
     }
-    if (rc) return rc;
+#endif
+    if (wino_launch<0>(a, units, y_is_f32 != 0, st)) return 1;
     return mvsgi::check_launch("mvsgi_conv3d_wino32_f16");
 }
 

@@ -126,6 +126,19 @@ class ConvLaunch:
             self.f16["rs"] = (wp, (self.scale * unscale).contiguous())
         return self.f16["rs"]
 
+    def wino_ok(self, D: int, Hh: int, W: int) -> bool:
+        """The Winograd-form kernel (csrc/conv3d_wino.hip) serves this layer on a [D, Hh, W] volume (fp16 split only)."""
+        return H.conv3d_wino_applies(self.cin, self.cout, D, Hh, W, self.stride, self.neg_slope)
+
+    def _wino(self):
+        """(packed weights, per-channel scale) of the Winograd-form kernel."""
+        if self.f16 is None:
+            self.f16 = {}
+        if "wino" not in self.f16:
+            wp, unscale = H.pack_conv_weights_wino(self.w)
+            self.f16["wino"] = (wp, (self.scale * unscale).contiguous())
+        return self.f16["wino"]
+
     def _b3(self, fmt: str):
         """(packed weights, per-channel scale) of the streaming split kernel (generic layout) in the split `fmt`."""
         return (self._wp_b3(), self.scale) if fmt == "bf16" else self._f16(H.CONV_BF16X3)

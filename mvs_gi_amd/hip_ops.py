@@ -622,45 +622,51 @@ def conv3d_rs(x: SplitAct, w_packed_rs, scale, shift, res: Optional[SplitAct] = 
     return y
 
 
-_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+def conv3d_wino_applies(cin, cout, D, Hh, W, stride, neg_slope) -> bool:
+    """The Winograd-form 32 -> 32 kernel (csrc/conv3d_wino.hip) serves this layer on this geometry (fp16 split only)."""
+    return bool(_lib.load().mvsgi_conv3d_wino32_applies(int(cin), int(cout), int(D), int(Hh), int(W), int(stride), float(neg_slope)))
 
 
 def pack_conv_weights_wino(w_oidhw: torch.Tensor):
-    """[32, 32, 3, 3, 3] -> (packed weights of the Winograd F(2x2, 3x3) x direct-D kernel in the fp16 split, unscale [32]).
+    """[32, 32, 3, 3, 3] -> (packed weights of the Winograd F(2x2, 3x3) x direct-D kernel in the fp16 split, unscale [32]), or None.
     U[a, b, kd] = sum_kh,kw G[a, kh] G[b, kw] w[.., kd, kh, kw], pre-scaled per cout by a power of two so that max |U| lies in
-    (512, 1024] (the caller folds `unscale` into the epilogue's scale), split hi = fp16(U), lo = fp16(U - hi), and laid out as the
-    MFMA's A operand: [a][b][kd][cout tile][hi | lo][lane = (cin group kg) * 16 + cout][8 cins]."""
+    (512, 1024] (the caller folds `unscale` into the epilogue's scale), split hi = fp16(U), lo = fp16(U - hi)."""
+    lib = _lib.load()
     w = _dev(w_oidhw, "conv weight")
     if tuple(w.shape) != (32, 32, 3, 3, 3):
         return None
-    G = torch.tensor(_WINO_G, device=w.device, dtype=torch.float64)
-    U = torch.einsum("ah,bw,oidhw->abdoi", G, G, w.double())            # [a, b, kd, co, ci]
-    up, unscale = _pow2_unscale(U.abs().amax(dim=(0, 1, 2, 4)).float())
-    U = (U * up.double().view(1, 1, 1, -1, 1)).float()
-    hi = U.to(torch.float16)
-    lo = (U - hi.float()).to(torch.float16)
-    # fragment [a][b][kd][ct][hl][kg][co16][j]  <-  U[a, b, kd, ct * 16 + co16, kg * 8 + j]
-    f = torch.stack((hi, lo), dim=3)                                      # [a, b, kd, hl, co, ci]
-    f = f.view(4, 4, 3, 2, 2, 16, 4, 8).permute(0, 1, 2, 4, 3, 6, 5, 7).contiguous()     # [a, b, kd, ct, hl, kg, co16, j]
-    return f.view(torch.uint8).reshape(-1), unscale.contiguous()
+    wp = torch.empty(lib.mvsgi_conv3d_wino32_packed_weight_bytes(), device=w.device, dtype=torch.uint8)
+    unscale = torch.empty(32, device=w.device, dtype=torch.float32)
+    _lib.check(lib.mvsgi_conv3d_wino32_pack_weights(w.data_ptr(), wp.data_ptr(), unscale.data_ptr(), _stream_ptr(w)),
+               "mvsgi_conv3d_wino32_pack_weights")
+    return wp, unscale
 
 
-def conv3d_wino(x: SplitAct, w_packed, scale, shift, res: Optional[SplitAct] = None, neg_slope=0.01, out: Optional[SplitAct] = None) -> SplitAct:
-    """Winograd-form 32 -> 32 conv (stride 1) on split-padded activations in the fp16 split; H even, W % 32 == 0."""
+def conv3d_wino(x: SplitAct, w_packed, scale, shift, res: Optional[SplitAct] = None, neg_slope=0.01, out=None, out_f32: bool = False):
+    """Winograd-form 32 -> 32 conv (stride 1) on split-padded activations in the fp16 split; D == 8, H even, W % 32 == 0.
+    `out_f32`: the result is a plain fp32 [B, D, H, W, 32] tensor instead of a SplitAct."""
     lib = _lib.load()
     if x.fmt != "f16" or x.C != 32:
         raise AssertionError(f"conv3d_wino: needs a 32-channel input in the fp16 split (got {x.C}, {x.fmt})")
-    y = out if out is not None else SplitAct(x.B, x.D, x.H, x.W, 32, x.buf.device)
-    if y.shape != x.shape:
-        raise AssertionError(f"split output {y.shape} does not match {x.shape}")
+    if out_f32:
+        y = out if out is not None else torch.empty(x.shape, device=x.buf.device, dtype=torch.float32)
+        if tuple(y.shape) != x.shape or not y.is_contiguous() or y.dtype != torch.float32:
+            raise AssertionError(f"fp32 output {tuple(y.shape)} does not match {x.shape}")
+        yp = y.data_ptr()
+    else:
+        y = out if out is not None else SplitAct(x.B, x.D, x.H, x.W, 32, x.buf.device)
+        if y.shape != x.shape:
+            raise AssertionError(f"split output {y.shape} does not match {x.shape}")
+        yp = y.buf.data_ptr()
     if res is not None and (res.shape != x.shape or res.fmt != "f16"):
         raise AssertionError(f"residual {res.shape} ({res.fmt}) does not match the output")
     if w_packed.numel() != lib.mvsgi_conv3d_wino32_packed_weight_bytes():
         raise AssertionError("conv3d_wino: packed weights of the wrong size")
     _lib.check(lib.mvsgi_conv3d_wino32_f16(x.buf.data_ptr(), w_packed.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                           None if res is None else res.buf.data_ptr(), y.buf.data_ptr(), x.B, x.D, x.H, x.W,
+                                           None if res is None else res.buf.data_ptr(), yp, int(out_f32), x.B, x.D, x.H, x.W,
                                            float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_wino32_f16")
-    y.fmt = "f16"
+    if not out_f32:
+        y.fmt = "f16"
     return y
 
 

@@ -1587,6 +1587,46 @@ def test_split_padded_hand_over_between_builder_and_regulator(golden_dir):
         cr._USE_S2RS = old_use
 
 
+def test_full_size_winograd_level0_vs_direct_kernel_and_reference_golden(golden_dir):
+    """G16V at full size in the fp16 split: UNet level 0's six 32 -> 32 convs ([8, 40, 160]) on the Winograd-form kernel (the dispatcher's
+    choice) and on the direct register-stationary kernel (MVSGI_WINO=0) -- both reproduce the reference golden 3x inside the fp16
+    split's 1e-4, and differ from each other by less than either does from the golden."""
+    from mvs_gi_amd.dropin import cost_volume_regulator as cr
+    import parity_log
+    case = FULL_CASES["full_G16V"]
+    cfg, z = case["cfg"], _load(golden_dir, "full_G16V")
+    inp = synth.make_inputs(cfg, seed=case["seed"], batch=1, grid_kind=case["grid_kind"], grid_mask_dtype=case["grid_mask_dtype"])
+    assert synth.digest(inp) == str(z["inputs_sha256"]), "regenerated inputs differ from the golden run's (host libm)"
+    old, old_use, real = H.get_conv_mode(), cr._USE_WINO, H.conv3d_wino
+    calls = []
+
+    def spy(*a, **k):
+        calls.append(k.get("out_f32", False))
+        return real(*a, **k)
+    try:
+        H.set_conv_mode("f16x3")
+        H.conv3d_wino = spy
+        gain = case["gains"][-1]
+        w = synth.make_weights(cfg, seed=case["seed"], gain=gain)
+        feats = _g(inp["feats"]).expand(2, -1, -1, -1, -1).contiguous()
+        outs = {}
+        for use in (True, False):
+            cr._USE_WINO = use
+            calls.clear()
+            outs[use] = HotPath(cfg, w, inp, device=DEV)(feats)[0].cpu().numpy()
+            assert calls == ([False] * 5 + [True] if use else [])          # six launches, the last one hands fp32 to the next level
+        ref = z[f"inv_dist_g{gain:g}"]
+        for i in range(2):
+            err = _rel(outs[True][i:i + 1], ref)
+            parity_log.record("full_G16V(winograd level 0)", "f16x3", gain, err, _l1(outs[True][i:i + 1], ref), "golden")
+            assert err <= 1e-4 and _rel(outs[False][i:i + 1], ref) <= 1e-4
+        assert _rel(outs[True], outs[False]) <= 3e-5
+    finally:
+        H.conv3d_wino = real
+        H.set_conv_mode(old)
+        cr._USE_WINO = old_use
+
+
 @pytest.mark.parametrize("split", ["bf16x3", "f16x3"])
 def test_full_size_batch8_register_stationary_path_vs_reference_golden(golden_dir, split):
     """G16V at full size with 8 frames per launch: the batch at which bench.py's path (register-stationary level-0 convs)
@@ -2014,6 +2054,70 @@ def test_conv3d_rs_in_the_fp16_split_vs_oracle(shape, res, slope, out_f32):
     if not out_f32:
         for sl in (y.buf[:, 0], y.buf[:, -1], y.buf[:, :, 0], y.buf[:, :, -1], y.buf[:, :, :, 0], y.buf[:, :, :, -1]):
             assert int(sl.abs().max()) == 0
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 2, 32), (2, 8, 6, 64), (5, 8, 12, 32), (3, 8, 40, 160)])
+@pytest.mark.parametrize("res,slope,out_f32", [(True, 0.01, False), (False, 0.01, True), (True, 1.0, True), (False, 0.0, False)])
+def test_conv3d_winograd_in_the_fp16_split_vs_oracle(shape, res, slope, out_f32):
+    """The Winograd F(2x2, 3x3) x direct-D form of the 32 -> 32 layers (csrc/conv3d_wino.hip; BaseConvBlk3d.forward,
+    common_modules.py:107-115): transformed weights and activations in the fp16 split, 2.25 x fewer matrix instructions.  The same
+    5e-6 bar as the direct kernel in this split, against float64 on what it multiplied; units of several workgroups and of one
+    (the stream's tail), every epilogue variant; the border of a split-padded output stays zero."""
+    B, d, h, w = shape
+    rng = np.random.default_rng(sum(shape) + 18)
+    x, r = _g(rng.standard_normal((B, d, h, w, 32), dtype=np.float32)), _g(rng.standard_normal((B, d, h, w, 32), dtype=np.float32))
+    wt = (rng.standard_normal((32, 32, 3, 3, 3)) / np.sqrt(27 * 32)).astype(np.float32) * np.float32(0.02)
+    sc, sh = _bn(rng, 32)
+    assert H.conv3d_wino_applies(32, 32, d, h, w, 1, slope)
+    xs, rs = H.act_to_split(x, fmt="f16"), (H.act_to_split(r, fmt="f16") if res else None)
+    wp, un = H.pack_conv_weights_wino(_g(wt))
+    y = H.conv3d_wino(xs, wp, _g(sc) * un, _g(sh), res=rs, neg_slope=slope, out_f32=out_f32)
+    assert out_f32 or y.fmt == "f16"
+    got = (y if out_f32 else H.act_from_split(y)).cpu().numpy()
+    ref = _conv_ref64(H.act_from_split(xs), wt, sc, sh, slope, res=H.act_from_split(rs) if res else None)
+    assert _rel(got, ref) <= 5e-6
+    if not out_f32:
+        for sl in (y.buf[:, 0], y.buf[:, -1], y.buf[:, :, 0], y.buf[:, :, -1], y.buf[:, :, :, 0], y.buf[:, :, :, -1]):
+            assert int(sl.abs().max()) == 0
+        # the direct kernel in the same split on the same operands: the two forms agree far inside either one's error against the reference
+        wpd, und = H.pack_conv_weights_rs(_g(wt), "f16")
+        yd = H.act_from_split(H.conv3d_rs(xs, wpd, _g(sc) * und, _g(sh), res=rs, neg_slope=slope)).cpu().numpy()
+        assert _rel(got, yd) <= 5e-6
+
+
+def test_conv3d_winograd_weights_range_and_misuse():
+    """The packed weights are U = G g G^T, pre-scaled per cout by a power of two into (512, 1024] and split; saturating inputs stay
+    finite; geometries and formats the kernel does not serve are refused, not mis-served."""
+    rng = np.random.default_rng(181)
+    wt = (rng.standard_normal((32, 32, 3, 3, 3)) * np.exp(rng.uniform(-6, 6, (32, 1, 1, 1, 1)))).astype(np.float32)
+    wt[5] = 0.0                                                         # a dead channel keeps k = 0
+    wp, un = H.pack_conv_weights_wino(_g(wt))
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=np.float64)
+    U = np.einsum("ah,bw,oidhw->abdoi", G, G, wt.astype(np.float64))                 # [a, b, kd, co, ci]
+    amax = np.abs(U).max(axis=(0, 1, 2, 4))
+    unh = un.cpu().numpy().astype(np.float64)
+    live = amax > 0
+    assert (np.log2(unh) == np.round(np.log2(unh))).all() and unh[5] == 1.0
+    assert ((amax[live] / unh[live] > 512 * (1 - 1e-6)) & (amax[live] / unh[live] <= 1024 * (1 + 1e-6))).all()
+    f = wp.cpu().numpy().view(np.float16).reshape(4, 4, 3, 2, 2, 4, 16, 8).astype(np.float64)      # [a, b, kd, ct, hl, kg, co16, j]
+    back = (f[:, :, :, :, 0] + f[:, :, :, :, 1]).transpose(0, 1, 2, 3, 5, 4, 6).reshape(4, 4, 3, 32, 32)  # [a, b, kd, co, ci]
+    assert np.abs(back * unh[None, None, None, :, None] - U).max() <= 2.0 ** -20 * np.abs(U).max()
+    # inputs at the end of fp16's range: the transform's sums are clamped, nothing turns into inf / nan
+    x = torch.full((1, 8, 2, 32, 32), 65504.0, device=DEV)
+    xs = H.act_to_split(x, fmt="f16")
+    w1 = np.zeros((32, 32, 3, 3, 3), np.float32)
+    w1[:, :, 1, 1, 1] = 1.0 / 32
+    wp1, un1 = H.pack_conv_weights_wino(_g(w1))
+    y = H.act_from_split(H.conv3d_wino(xs, wp1, torch.ones(32, device=DEV) * un1, torch.zeros(32, device=DEV), neg_slope=0.01))
+    assert bool(torch.isfinite(y).all()) and float(y.max()) <= 65504.0
+    assert not H.conv3d_wino_applies(32, 32, 7, 4, 32, 1, 0.01) and not H.conv3d_wino_applies(32, 32, 8, 3, 32, 1, 0.01)
+    assert not H.conv3d_wino_applies(32, 32, 8, 4, 48, 1, 0.01) and not H.conv3d_wino_applies(16, 32, 8, 4, 32, 1, 0.01)
+    with pytest.raises(RuntimeError, match="needs D == 8"):
+        H.conv3d_wino(H.act_to_split(torch.zeros((1, 4, 4, 32, 32), device=DEV), fmt="f16"), wp1, un1, un1)
+    with pytest.raises(AssertionError, match="fp16 split"):
+        H.conv3d_wino(H.act_to_split(torch.zeros((1, 8, 4, 32, 32), device=DEV)), wp1, un1, un1)
+    with pytest.raises(AssertionError, match="wrong size"):
+        H.conv3d_wino(xs, wp1[:-16], un1, un1)
 
 
 @pytest.mark.parametrize("shape", [(1, 4, 4, 16), (2, 5, 7, 37), (3, 10, 30, 150)])

@@ -29,7 +29,9 @@ yd = H.SplitAct(B, d, h, w, 32, dev)
 yw = H.SplitAct(B, d, h, w, 32, dev)
 H.conv3d_rs(xs, wpr, sc * unr, sh, res=rs, out=yd)
 H.conv3d_wino(xs, wpw, sc * unw, sh, res=rs, out=yw)
+y32 = H.conv3d_wino(xs, wpw, sc * unw, sh, res=rs, out_f32=True)
 torch.cuda.synchronize()
+print("fp32-output variant vs split output: max abs diff", float((y32 - H.act_from_split(yw)).abs().max()))
 ref_max = float(y_ref.abs().max())
 for name, ys in (("direct f16x3", yd), ("winograd f16x3", yw)):
     y = H.act_from_split(ys)
