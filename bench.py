@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+OTHER_SPLIT = {"f16x3": "bf16x3", "bf16x3": "f16x3"}
 PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "f16x3": 2500.0}   # MI355X_MICROARCH.md: dense fp32-MFMA / bf16-MFMA (= fp16-MFMA) peaks
 DTYPE = {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA operands, f32 accumulate/activations)",
          "f16x3": "f16x3 (split-fp16 MFMA operands: 11 + 11 significant bits, f32 accumulate/activations)"}
@@ -52,9 +53,9 @@ def parse_args(argv=None):
                     help="independent parts of a step's batch, each on its own HIP stream inside the step's one hipGraph "
                          "(StreamedHotPath: one part's kernel tails are filled by the other's launches; MI355X, G16V: 2 x 64 frames "
                          "+1.8 % over 1 x 128 and +3.3 % over 1 x 64); 1 = the whole batch on one stream")
-    ap.add_argument("--mode", default="bf16x3", choices=["bf16x3", "f16x3", "f32"],
-                    help="conv arithmetic: split-bf16 MFMA (3 bf16 MFMAs per product, fp32 accumulate), the same in the fp16 split "
-                         "(11 + 11 bits per operand: ~10x closer to the reference, streaming kernels only) or exact fp32 MFMA")
+    ap.add_argument("--mode", default="f16x3", choices=["bf16x3", "f16x3", "f32"],
+                    help="conv arithmetic: split-fp16 MFMA (the library's default: 3 fp16 MFMAs per product, 11 + 11 bits per operand, "
+                         "fp32 accumulate; level-0 convs in Winograd form), the same in the bf16 split (8 + 8 bits, fp32's range) or exact fp32 MFMA")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extras / configs blocks (rig cache off, hipGraph, B=1 latency, images -> inverse "
                          "distance, host feed, other BASELINE configs); they never touch the headline's timed region")
@@ -153,6 +154,7 @@ class ConvProbe:
         self.orig = H.conv3d
         self.orig_up2 = H.conv3d_up2
         self.orig_rs = H.conv3d_rs
+        self.orig_wino = H.conv3d_wino
         self.orig_rs16 = H.conv3d_rs16
         self.orig_os = H.conv3d_out_split
         self.records = []
@@ -223,6 +225,19 @@ class ConvProbe:
             nv = x.B * x.D * x.H * x.W
             self.records.append(("conv3d_rs32_kernel<%d%s>" % (1 if out_f32 else 0, ", true" if x.fmt == "f16" else ", false"),
                                  2.0 * 27 * x.C * scale.numel() * nv, s, e, 4.0 * nv * (x.C + scale.numel() * (2 if res is not None else 1))))
+            return y
+
+        def probed_wino(x, w_packed, scale, shift, res=None, neg_slope=0.01, out=None, out_f32=False):
+            if not self.enabled:
+                return self.orig_wino(x, w_packed, scale, shift, res, neg_slope, out, out_f32)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = self.orig_wino(x, w_packed, scale, shift, res, neg_slope, out, out_f32)
+            e.record()
+            nv = x.B * x.D * x.H * x.W
+            # algorithmic FLOPs = the direct convolution's (the Winograd form issues 16 / 36 of its matrix instructions)
+            self.records.append(("conv3d_wino32_kernel<0, %s, %s>" % ("true" if res is not None else "false", "true" if out_f32 else "false"),
+                                 2.0 * 27 * 32 * 32 * nv, s, e, 4.0 * nv * 32 * (3 if res is not None else 2)))
             return y
 
         def probed_os(x, w_packed_b3, scale, shift, out, res=None, stride=1, neg_slope=0.01, fmt="bf16"):
@@ -323,6 +338,7 @@ class ConvProbe:
         H.conv3d_rs16 = probed_rs16
         H.conv3d_s2rs = probed_s2rs
         H.conv3d_rs = probed_rs
+        H.conv3d_wino = probed_wino
         H.conv3d_out_split = probed_os
 
         # ---- the HBM-bound launches of the path (K1 sweep, K4 soft-argmin, layout transposes) ----
@@ -386,6 +402,7 @@ class ConvProbe:
         self.H.conv3d = self.orig
         self.H.conv3d_up2 = self.orig_up2
         self.H.conv3d_rs = self.orig_rs
+        self.H.conv3d_wino = self.orig_wino
         self.H.conv3d_rs16 = self.orig_rs16
         self.H.conv3d_s2rs = self.orig_s2rs
         self.H.conv3d_out_split = self.orig_os
@@ -847,9 +864,9 @@ def main(argv=None):
         "path_tflops": round(value * path_gflop(cfg) / 1e3, 2),
         "roofline": {"bound": "mfma", "kernel": dname, "achieved": round(achieved, 2), "peak": peak,
                      "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                     "note": ("achieved = ALGORITHMIC conv FLOPs / kernel time; the split-bf16 kernel issues 3 bf16 "
-                              "MFMA FLOPs per algorithmic FLOP, so frac tops out at 1/3" if args.mode == "bf16x3"
-                              else "exact fp32 MFMA"),
+                     "note": ("achieved = ALGORITHMIC conv FLOPs / kernel time; a split kernel issues 3 16-bit "
+                              "MFMA FLOPs per algorithmic FLOP, so frac tops out at 1/3 (the Winograd-form level-0 kernel of the fp16 split: 3 x 16 / 36)"
+                              if args.mode in OTHER_SPLIT else "exact fp32 MFMA"),
                      "traffic": traffic, "traffic_source": traffic_src, "launches": dn,
                      "avg_launch_us": round(dms / dn * 1e3, 2), "gflop_per_launch": round(dflops / dn / 1e9, 3),
                      "conv_time_frac_of_step": round(conv_ms / (el_ev * 1e3), 3),
@@ -902,15 +919,15 @@ def main(argv=None):
                     m["frames_per_step"] = m.pop("graph_replay_frames_per_step")
                     m["path_tflops"] = round(m["frames_per_s"] * path_gflop(CONFIGS[tag]) / 1e3, 2)
                     m["submission"] = f"{S} parts of {b} frames on their own streams, one hipGraph replay per step"
-                if args.mode == "bf16x3":      # the fp16 split of the same step: the streaming kernels' other arithmetic (rate and error)
+                if args.mode in OTHER_SPLIT:      # the other 16-bit split of the same step (rate and error)
                     try:
-                        m16 = measure_path(CONFIGS[tag], b, "f16x3", max(3, args.extra_steps // 2), 2, dev, H, HotPath, synth, torch, np, rng,
+                        m16 = measure_path(CONFIGS[tag], b, OTHER_SPLIT[args.mode], max(3, args.extra_steps // 2), 2, dev, H, HotPath, synth, torch, np, rng,
                                            graph=use_graph, streams=S, ref_dump=config_dump_path(ref_dump, tag) if ref_dump else None)
-                        m["mode_f16x3"] = {"frames_per_s": m16.get("graph_replay_frames_per_s", m16["frames_per_s"]),
+                        m["mode_" + OTHER_SPLIT[args.mode]] = {"frames_per_s": m16.get("graph_replay_frames_per_s", m16["frames_per_s"]),
                                            "parity": m16.get("parity"), "dominant_kernel": m16["dominant_kernel"],
                                            "dominant_tflops": m16["dominant_tflops"]}
                     except Exception as e:
-                        m["mode_f16x3"] = {"error": f"{type(e).__name__}: {e}"}
+                        m["mode_" + OTHER_SPLIT[args.mode]] = {"error": f"{type(e).__name__}: {e}"}
                         torch.cuda.synchronize(dev)
                     finally:
                         H.set_conv_mode(args.mode)
@@ -1147,14 +1164,14 @@ def run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, 
         return m
     guarded("mode_f32", mode_f32)
 
-    def mode_f16x3():
-        # the fp16 split of the same path (hi = fp16(x), lo = fp16(x - hi): 11 + 11 bits per operand at the bf16 split's matrix rate):
-        # the deployer's answer for a checkpoint whose softmax is sharper than the bf16 split holds (Precision modes).
-        # Streaming kernels only -- the register-stationary level-0 / polyphase kernels of this regulator are bf16-split.
-        if args.mode == "f16x3":
-            return {"note": "the headline is the fp16-split mode"}
+    def mode_other_split():
+        # the other 16-bit split of the same path.  fp16 (hi = fp16(x), lo = fp16(x - hi): 11 + 11 bits per operand, saturating at
+        # +-65504) is the library's default; bf16 (8 + 8 bits, fp32's range) is the deployer's answer for activations beyond fp16's
+        # range (Precision modes) -- at the same matrix rate, without the Winograd form of the level-0 convs
+        if args.mode not in OTHER_SPLIT:
+            return {"note": "the headline is the exact-fp32 mode"}
         try:
-            m = measure_path(cfg, B, "f16x3", max(3, K // 2), 2, dev, H, HotPath, synth, torch, np, rng, graph=use_graph,
+            m = measure_path(cfg, B, OTHER_SPLIT[args.mode], max(3, K // 2), 2, dev, H, HotPath, synth, torch, np, rng, graph=use_graph,
                              streams=len(shp.parts), ref_dump=getattr(args, "ref_dump", None))
         finally:
             H.set_conv_mode(args.mode)
@@ -1163,7 +1180,7 @@ def run_extras(args, cfg, B, hp, feats, weights, dev, H, synth, torch, np, rng, 
             m["frames_per_s"] = m["graph_replay_frames_per_s"]
         m["vs_headline"] = round(m["frames_per_s"] / headline_fps, 4)
         return m
-    guarded("mode_f16x3", mode_f16x3)
+    guarded("mode_" + OTHER_SPLIT.get(args.mode, "f16x3"), mode_other_split)
 
     def precision_check():
         # the deployer's per-checkpoint measurement (HotPath.precision_check) on the benchmark's own weights and one synthetic frame:

@@ -18,13 +18,16 @@ SPLIT_F16 = 1          # `fmt` of the *_fmt entry points (include/mvsgi.h MVSGI_
 CONV_F16 = 0x100       # flag OR-ed into CONV_BF16X3 / _C16 / _V32: the same kernel in the fp16 split (include/mvsgi.h MVSGI_CONV_F16)
 
 # Arithmetic of the conv layers:
-#   "bf16x3" (default) = split-bf16 MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate; 8 + 8 significant bits per operand, fp32's range);
-#   "f16x3"            = the same three products in the fp16 split (11 + 11 bits per operand, operands clamped to +-65504): inverse
-#                        distance ~10x closer to the reference on a sharp softmax, on the streaming kernels (the register-stationary
-#                        kernels of the (16, 32) regulator are bf16-split only);
-#   "f32"              = exact fp32 MFMA (v_mfma_f32_16x16x4_f32; bit-for-bit an fp32 fmaf chain, ~4x slower).
+#   "f16x3" (default) = split-fp16 MFMA (x = hi + lo, hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16, fp32 accumulate; 11 + 11
+#                       significant bits per operand; operands saturate at +-65504 (never inf / nan); weights pre-scaled per output
+#                       channel by a power of two).  Inverse distance ~8x closer to the reference than the bf16 split, and since the
+#                       level-0 residual convs of the (16, 32) regulator run in Winograd form in this split (csrc/conv3d_wino.hip; exact
+#                       for |activation| <= 16376) also the fastest mode;
+#   "bf16x3"          = the same three products in the bf16 split (8 + 8 bits per operand, fp32's range): the answer for activations
+#                       beyond fp16's range (HotPath.precision_check tells the two apart);
+#   "f32"             = exact fp32 MFMA (v_mfma_f32_16x16x4_f32; bit-for-bit an fp32 fmaf chain, ~4x slower).
 CONV_MODES = ("f32", "bf16x3", "f16x3")
-_CONV_MODE = os.environ.get("MVSGI_CONV_MODE", "bf16x3")
+_CONV_MODE = os.environ.get("MVSGI_CONV_MODE", "f16x3")
 if _CONV_MODE not in CONV_MODES:
     raise ValueError(f"MVSGI_CONV_MODE={_CONV_MODE!r} not in {CONV_MODES}")
 
@@ -32,7 +35,8 @@ if _CONV_MODE not in CONV_MODES:
 def exp_env(name: str, default: str) -> str:
     """Experiment switches -- A/B knobs whose measurement is recorded in DESIGN.md / DESIGN_HISTORY.md as neutral or slower -- are
     read only when MVSGI_EXPERIMENTAL=1; the product configuration surface is MVSGI_CONV_MODE, MVSGI_RIG_CACHE, MVSGI_POLY,
-    MVSGI_S2RS, MVSGI_HEAD_SPLIT, MVSGI_FRONT_CHUNK (each covered by tests/test_gpu_parity.py::test_product_switches_off) and MVSGI_LIB."""
+    MVSGI_S2RS, MVSGI_HEAD_SPLIT, MVSGI_FRONT_CHUNK (each covered by tests/test_gpu_parity.py::test_product_switches_off), MVSGI_WINO
+    (test_full_size_winograd_level0_vs_direct_kernel_and_reference_golden) and MVSGI_LIB."""
     if os.environ.get("MVSGI_EXPERIMENTAL") == "1":
         return os.environ.get(name, default)
     if name in os.environ and name not in _EXP_WARNED:      # a probe / A-B script that forgot the gate would measure the default twice

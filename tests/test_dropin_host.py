@@ -137,9 +137,9 @@ def test_feature_extractor_state_dict_names():
         fe.eval()(torch.zeros(1, 3, 16, 32))
 
 
-def test_default_conv_mode_is_bf16x3():
+def test_default_conv_mode_is_the_fp16_split():
     """a maintainer who installs the drop-in without touching any knob gets the
-    split-bf16 path (the one bench.py reports); MVSGI_CONV_MODE=f32 selects the exact-fp32 kernels."""
+    split-fp16 path (the one bench.py reports); MVSGI_CONV_MODE=bf16x3 / f32 select the bf16 split / the exact-fp32 kernels."""
     import os
     import subprocess
     import sys
@@ -147,10 +147,11 @@ def test_default_conv_mode_is_bf16x3():
     env = {k: v for k, v in os.environ.items() if k != "MVSGI_CONV_MODE"}
     code = "from mvs_gi_amd import hip_ops as H; print(H.get_conv_mode())"
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
-    assert r.returncode == 0 and r.stdout.strip() == "bf16x3", r.stdout + r.stderr
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, MVSGI_CONV_MODE="f32"),
-                       cwd=root, timeout=300)
-    assert r.stdout.strip() == "f32"
+    assert r.returncode == 0 and r.stdout.strip() == "f16x3", r.stdout + r.stderr
+    for mode in ("f32", "bf16x3"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, MVSGI_CONV_MODE=mode),
+                           cwd=root, timeout=300)
+        assert r.stdout.strip() == mode
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, MVSGI_CONV_MODE="fp16"),
                        cwd=root, timeout=300)
     assert r.returncode != 0
