@@ -65,6 +65,27 @@ def _rs_chain(blk, x: Tensor):
     return L0, chain, (B, Do, Ho, Wo)
 
 
+_CUS = {}
+
+
+def _cu_count(device) -> int:
+    import torch
+    key = str(device)
+    if key not in _CUS:
+        _CUS[key] = torch.cuda.get_device_properties(device).multi_processor_count
+    return _CUS[key]
+
+
+def _wino_pays(B: int, Ho: int, Wo: int, device) -> bool:
+    """A Winograd unit (2 rows x 32 columns, all planes) occupies a CU for ~16 us: the form pays when the launch's units fill
+    their rounds of one unit per CU (measured on MI355X, [8, 40, 160]: 1 frame 0.95-0.99 x the direct kernel, 2 frames 1.26,
+    3 frames -- 300 units, the second round 17 % full -- 0.92-0.98, 4 frames 1.15, 16 and more 1.21-1.27)."""
+    units = B * (Ho // 2) * (Wo // 32)
+    cus = _cu_count(device)
+    rounds = -(-units // cus)
+    return units >= 0.7 * rounds * cus
+
+
 def _down_block_rs(blk, x: Tensor, L0, chain, dims) -> Tensor:
     """first conv (streaming kernel, output written split-padded) -> residual blocks on the register-stationary kernel, three
     rotating split-padded buffers owned by the module (zero borders, allocated once) -> last conv writes plain fp32."""
@@ -89,8 +110,9 @@ def _down_block_rs(blk, x: Tensor, L0, chain, dims) -> Tensor:
     for i, (L1, L2) in enumerate(chain):
         r, y = (cur + 1) % 3, (cur + 2) % 3
         # fp16 split on a [8, even, 32 k] volume: the Winograd form (2.25 x fewer matrix instructions, csrc/conv3d_wino.hip)
-        conv1 = H.conv3d_wino if fmt == "f16" and _USE_WINO and L1.wino_ok(Do, Ho, Wo) else None
-        conv2 = H.conv3d_wino if fmt == "f16" and _USE_WINO and L2.wino_ok(Do, Ho, Wo) else None
+        wino = fmt == "f16" and _USE_WINO and _wino_pays(B, Ho, Wo, x.device)
+        conv1 = H.conv3d_wino if wino and L1.wino_ok(Do, Ho, Wo) else None
+        conv2 = H.conv3d_wino if wino and L2.wino_ok(Do, Ho, Wo) else None
         (wp1, sc1) = L1._wino() if conv1 else L1._rs(fmt)
         (wp2, sc2) = L2._wino() if conv2 else L2._rs(fmt)
         (conv1 or H.conv3d_rs)(b[cur], wp1, sc1, L1.shift, neg_slope=L1.neg_slope, out=b[r])

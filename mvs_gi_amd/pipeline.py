@@ -98,13 +98,13 @@ class HotPath:
     @torch.no_grad()
     def precision_check(self, feats: torch.Tensor, bar: float = 5e-4) -> Dict[str, object]:
         """Which conv arithmetic does THIS checkpoint need?  Runs `feats` (one or a few real frames) through the path in the
-        bf16 split and in the fp16 split and returns their inverse-distance discrepancy, max |d| / max |inv_dist| -- the fp16
-        split's own error is 7-11x smaller (Precision modes), so the discrepancy IS the bf16 split's error to ~15 % --
-        and the cheapest mode that keeps it under `bar` (default: half the north star's 1e-3).  The error of either split grows
-        with the sharpness of the checkpoint's softmax over the candidates, which only the trained weights know: this is the
-        measurement a deployer makes once per checkpoint instead of guessing it.  When the two splits disagree by more than the
-        bar, the exact-fp32 mode arbitrates: the split closer to it wins if it is inside the bar (the fp16 split normally; the
-        bf16 split when activations leave fp16's range, +-65504, or live far below 1e-3), else "f32".
+        fp16 split (the library's default) and in the bf16 split and returns their inverse-distance discrepancy, max |d| / max |inv_dist|.
+        On in-range activations the fp16 split's own error is 7-11x smaller (Precision modes), so the discrepancy IS the
+        bf16 split's error to ~15 % -- small: the two agree and the default stands.  When they disagree by more than `bar` (default:
+        half the north star's 1e-3) the exact-fp32 mode arbitrates: the split closer to it wins if it is inside the bar -- the fp16
+        split on a sharp softmax (the error of either split grows with the sharpness of the checkpoint's softmax over the candidates,
+        which only the trained weights know), the bf16 split when activations leave fp16's range (+-65504; +-16376 at the
+        Winograd-form level-0 convs) or live far below 1e-3 -- else "f32".  The measurement a deployer makes once per checkpoint.
         -> {"bf16x3_vs_f16x3": e, "bar": bar, "recommended": mode [, "bf16x3_vs_f32": e, "f16x3_vs_f32": e, "note": ...]}"""
         from . import hip_ops as H
         old = H.get_conv_mode()
@@ -115,7 +115,7 @@ class HotPath:
                 outs[mode] = self(feats)[0].clone()
             den = float(outs["f16x3"].abs().max()) or 1.0
             e_b = float((outs["bf16x3"] - outs["f16x3"]).abs().max()) / den
-            res = {"bf16x3_vs_f16x3": e_b, "bar": bar, "recommended": "bf16x3"}
+            res = {"bf16x3_vs_f16x3": e_b, "bar": bar, "recommended": "f16x3"}
             if e_b > bar:
                 H.set_conv_mode("f32")
                 exact = self(feats)[0]
