@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Winograd-form 32->32 conv (mvsgi_conv3d_wino32_f16) against the register-stationary direct kernel in the fp16 split and the
-exact-fp32 kernel: parity and time."""
+exact-fp32 kernel: parity and time.  With MVSGI_LIB=<a -DMVSGI_WINO_STAMPS build> and MVSGI_WINO_STAMP=1 every launch prints the
+cycles workgroup 0's waves spent per step section (summed over the launch: before the span | - | span (MFMAs + transform + staging
+requests) | exchange write + wait | barrier | epilogue + next raw reads)."""
 import argparse, os, sys
 import numpy as np
 import torch
