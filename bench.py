@@ -459,7 +459,14 @@ def read_pmc_traffic(kernel_name: str):
         d = json.load(open(p))
         key = kernel_name.split(" [")[0]
         # (summaries written before the kernels carried their split as a template argument name them without the trailing ", false")
-        v = (d.get(key) or d.get(key.replace(", false>", ">")) or {}).get("hbm_bytes_per_launch")
+        def one(k):
+            return (d.get(k) or d.get(k.replace(", false>", ">")) or {}).get("hbm_bytes_per_launch")
+        v = one(key)
+        if v is None and " + " in key:      # a timed unit of several kernels (the polyphase layer: main + face + edge kernels): their sum
+            parts = [one(k.split(" (")[0].strip()) for k in key.split(" + ")]
+            parts = [one(next((n for n in d if n.startswith(k.split(" (")[0].strip())), "")) if p_ is None else p_
+                     for k, p_ in zip(key.split(" + "), parts)]
+            v = sum(parts) if all(p_ is not None for p_ in parts) else None
         return v, (f"profiles/pmc_traffic.json ({d.get('_source', 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE')})"
                    if v is not None else None)
     except Exception:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/profile_r05.sh <outdir>   -- round-5 evidence (the round-4 passes, plus the same G16V passes in the fp16 split: MODE=f16x3).  Every pass under its own timeout; stops at the first failure.
+# usage: tools/profile_r05.sh <outdir>   -- round-5 evidence (the round-4 passes in the library's default arithmetic -- the fp16 split since round 5 -- plus the same G16V passes in the bf16 split).  Every pass under its own timeout; stops at the first failure.
 #  1. the default bench command (2 parts of 64 frames on two streams, one hipGraph): the line, rocprofv3 kernel-trace stats
 #  2. the same kernels alone on the chip (--streams 1 --batch 64): kernel-trace stats (what the line's per-kernel attribution times), HBM
 #     traffic counters (separate passes), SQ counters of every step kernel
@@ -27,12 +27,12 @@ timeout -k 10 300 rocprofv3 --pmc $SQ1 --output-format csv -d $R/$OUT/sq1 -- $B1
 timeout -k 10 300 rocprofv3 --pmc $SQ2 --output-format csv -d $R/$OUT/sq2 -- $B1 --steps 2 --warmup 1 --settle-seconds 0 > $R/$OUT/sq2.log 2>&1 || exit 1
 python3 $R/tools/summarize_sq.py $R/$OUT/pmc_step_kernels.txt "B=64 step, one stream" "conv3d;sweep;softargmin;up2" $R/$OUT/sq1 $R/$OUT/sq2 > /dev/null || exit 1
 rm -rf $R/$OUT/sq1 $R/$OUT/sq2
-# the fp16 split of the same step (MVSGI_CONV_MODE=f16x3): line, kernel-trace stats alone on the chip, HBM traffic
-BF="$B --mode f16x3"
-timeout -k 10 280 python3 $R/bench.py --mode f16x3 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $R/$OUT/bench_G16V_f16x3.json 2> $R/$OUT/bench_G16V_f16x3.err || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_f16 -- $BF --streams 1 --batch 64 --steps 5 --warmup 2 > $R/$OUT/stats_f16.log 2>&1 || exit 1
-$S stats $R/$OUT/stats_f16 $R/$OUT/bench_streams1_b64_f16x3_kernel_stats.txt > /dev/null || exit 1
-rm -rf $R/$OUT/stats_f16
+# the bf16 split of the same step (MVSGI_CONV_MODE=bf16x3, the default of rounds 1-4): line, kernel-trace stats alone on the chip
+BF="$B --mode bf16x3"
+timeout -k 10 280 python3 $R/bench.py --mode bf16x3 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $R/$OUT/bench_G16V_bf16x3.json 2> $R/$OUT/bench_G16V_bf16x3.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_bf16 -- $BF --streams 1 --batch 64 --steps 5 --warmup 2 > $R/$OUT/stats_bf16.log 2>&1 || exit 1
+$S stats $R/$OUT/stats_bf16 $R/$OUT/bench_streams1_b64_bf16x3_kernel_stats.txt > /dev/null || exit 1
+rm -rf $R/$OUT/stats_bf16
 for T in G16VV E8 4cam-32; do
   PB=32; [ $T = E8 ] && PB=64; [ $T = 4cam-32 ] && PB=16
   C="$B --config $T --streams 1 --batch $PB"
