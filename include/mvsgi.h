@@ -403,7 +403,7 @@ int mvsgi_conv3d_up2_poly_fmt(const void* x_split, const void* plan_dev, const f
 
 /* ---- Winograd F(2x2, 3x3) x direct-D form of the 32 -> 32 convolutions (csrc/conv3d_wino.hip) -------------------------
  * BaseConvBlk3d.forward (dsta_mvs/model/common/common_modules.py:107-115) for Cin = Cout = 32, stride 1, on split-padded
- * activations in the fp16 split (MVSGI_SPLIT_F16), D = 8, H even, W a multiple of 32: 2.25 x fewer matrix instructions than the direct
+ * activations in the fp16 split (MVSGI_SPLIT_F16), D = 8 or 16, H even, W a multiple of 32: 2.25 x fewer matrix instructions than the direct
  * form.  Weights: U = G g G^T per (cout, cin, kd), pre-scaled per cout by a power of two (its inverse folded into `scale`),
  * split, as [a 4][b 4][kd 3][cout tile 2][hi | lo][64 lanes][16 B]. */
 size_t mvsgi_conv3d_wino32_packed_weight_bytes(void);

@@ -116,9 +116,9 @@ constexpr int ROW_SLOTS = 2 * HALF * PITCH;       // 306
 constexpr int PLANE_SLOTS = 4 * ROW_SLOTS;        // 1224
 constexpr int NDMA = 20, DPW = NDMA / 4;          // 1 KiB pieces per plane, per wave
 constexpr int PLANE_LDS = NDMA * 1024;            // 20,480
-constexpr int DEPTH = 8;                          // planes per unit: the kernel body is one unit, unrolled
+// (DEPTH, the planes per unit, is a template parameter of the kernel: its body is one unit, unrolled -- 8 or 16 planes)
 constexpr int NBUF = 4;                           // the staging stream runs three planes ahead of the arithmetic
-static_assert(DEPTH % NBUF == 0 && DEPTH % 2 == 0 && (DEPTH - 1) % 3 == 1, "image / V pair / slot phases of the unrolled unit");
+
 constexpr int ZB = NBUF * PLANE_LDS;              // the exchange: 2 x [a 4][q 2][cout tile 2][64 lanes][16 B]
 // residual records of one output plane of a unit: 2 rows x 32 voxels at the same 9-slot pitch (the epilogue's 8-byte reads walk them
 // with stride 18 slots: two-way conflicts at worst), 576 slots in 9 one-KiB pieces; three images (a unit's last plane is requested a
@@ -131,9 +131,10 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 }  // namespace wn
 
 // OUT32: the output is a plain fp32 channels-last tensor [B][D][H][W][32] (the hand-over to a kernel that stages fp32)
-template <int ABL, bool RES, bool OUT32>
+template <int ABL, bool RES, bool OUT32, int DEPTH>
 __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     using namespace wn;
+    static_assert(DEPTH % NBUF == 0 && DEPTH % 2 == 0, "image / V pair phases of the unrolled unit");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);                 // this wave's row of the transform space
@@ -204,7 +205,20 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     float T[2][4];                 // h-pass of one channel pair: [lo | hi half][column]
 
     const int G = gridDim.x;
-    const int nmine = ((int)a.total_units - (int)blockIdx.x + G - 1) / G;     // units of this workgroup
+    // The walk: workgroups are dealt to the 8 XCDs round-robin; XCD x owns a contiguous eighth of the unit space and its workgroups
+    // walk it side by side (ids ubase + k * ustep), so that the units sharing patch rows -- tile rows r and r + 1, groups_w ids apart --
+    // are read through ONE L2 at about the same time (the plain walk blockIdx + k * G fetched every shared row from HBM twice:
+    // 1313 MB per launch against 840 MB of tensors)
+    const int T_ = a.total_units;
+    int ubase = (int)blockIdx.x, ustep = G, nmine = (T_ - (int)blockIdx.x + G - 1) / G;
+    if ((G & 7) == 0 && T_ >= G) {
+        const int x = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3, q8 = T_ >> 3, r8 = T_ & 7;
+        const int lo = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8, cnt = q8 + (x < r8 ? 1 : 0);
+        ustep = G >> 3;
+        ubase = lo + i;
+        nmine = i < cnt ? (lo + cnt - ubase + ustep - 1) / ustep : 0;
+    }
+    if (nmine == 0) return;         // (the whole workgroup, before anything was requested)
 
 // descriptor whose base is the patch origin of unit U (padded rows 2 r .., columns 32 c ..); no records past the workgroup's last unit:
 // requests through it write zeros
@@ -425,7 +439,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     if constexpr (ABL & 16) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
     int ri = 0, rprev = 0;                             // residual image to request into / requested a step ago
-    auto dsc = WN_DESC((int)blockIdx.x, true);
+    auto dsc = WN_DESC(ubase, true);
     auto dsc_next = dsc;
     // the first three planes of the stream; V of the first; raw of the second
     WN_DMA_ISSUE(0, 0, DPW)
@@ -440,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     }
     WN_READ(1)
     for (int k = 0; k < nmine; ++k) {
-        const int u = (int)blockIdx.x + k * G;
+        const int u = ubase + k * ustep;
         const int c = u % a.groups_w;
         const int t = u / a.groups_w;
         const int r = t % a.tiles_h;
@@ -452,17 +466,14 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
         const long long rleft = total_bytes - roff;
         const auto rdsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(RES ? a.res : a.x) + roff, 0,
                                                             rleft > 0x7fffff00ll ? 0x7fffff00 : (int)rleft, 0x00020000);
-        dsc_next = WN_DESC(u + G, k + 1 < nmine);
+        dsc_next = WN_DESC(u + ustep, k + 1 < nmine);
         // slots follow the plane mod 3, the V pair the plane mod 2
-        WN_STEP(0, 1, 0, 2, 0)
-        WN_STEP(1, 2, 1, 0, 1)
-        WN_STEP(2, 0, 2, 1, 0)
-        WN_STEP(3, 1, 0, 2, 1)
-        WN_STEP(4, 2, 1, 0, 0)
-        WN_STEP(5, 0, 2, 1, 1)
-        WN_STEP(6, 1, 0, 2, 0)
-        WN_STEP(7, 2, 1, 0, 1)
-        WN_FINISH(1)
+#define WN_STEPP(P) WN_STEP(P, ((P) + 1) % 3, (P) % 3, ((P) + 2) % 3, (P) & 1)
+        WN_STEPP(0) WN_STEPP(1) WN_STEPP(2) WN_STEPP(3) WN_STEPP(4) WN_STEPP(5) WN_STEPP(6) WN_STEPP(7)
+        if constexpr (DEPTH == 16) {
+            WN_STEPP(8) WN_STEPP(9) WN_STEPP(10) WN_STEPP(11) WN_STEPP(12) WN_STEPP(13) WN_STEPP(14) WN_STEPP(15)
+        }
+        WN_FINISH((DEPTH - 1) % 3)
         dsc = dsc_next;
     }
     if constexpr (ABL & 16) {
@@ -471,19 +482,23 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     }
 }
 
-template <int ABL, bool RES, bool OUT32>
-int wino_launch3(const WinoArgs& a, long long units, hipStream_t st) {
+template <int ABL, bool RES, bool OUT32, int DEPTH>
+int wino_launch4(const WinoArgs& a, long long units, hipStream_t st) {
     static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
-    if (mvsgi::persistent_geometry(conv3d_wino32_kernel<ABL, RES, OUT32>, 256, wn::LDS_BYTES, 1, geo_cache, "conv3d(winograd)", geo)) return 1;
+    if (mvsgi::persistent_geometry(conv3d_wino32_kernel<ABL, RES, OUT32, DEPTH>, 256, wn::LDS_BYTES, 1, geo_cache, "conv3d(winograd)", geo)) return 1;
     const unsigned grid = (unsigned)(units < geo.cus ? units : geo.cus);
-    hipLaunchKernelGGL((conv3d_wino32_kernel<ABL, RES, OUT32>), dim3(grid), dim3(256), wn::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv3d_wino32_kernel<ABL, RES, OUT32, DEPTH>), dim3(grid), dim3(256), wn::LDS_BYTES, st, a);
     return 0;
+}
+template <int ABL, int DEPTH>
+int wino_launch2(const WinoArgs& a, long long units, bool out32, hipStream_t st) {
+    if (out32) return a.res ? wino_launch4<ABL, true, true, DEPTH>(a, units, st) : wino_launch4<ABL, false, true, DEPTH>(a, units, st);
+    return a.res ? wino_launch4<ABL, true, false, DEPTH>(a, units, st) : wino_launch4<ABL, false, false, DEPTH>(a, units, st);
 }
 template <int ABL>
 int wino_launch(const WinoArgs& a, long long units, bool out32, hipStream_t st) {
-    if (out32) return a.res ? wino_launch3<ABL, true, true>(a, units, st) : wino_launch3<ABL, false, true>(a, units, st);
-    return a.res ? wino_launch3<ABL, true, false>(a, units, st) : wino_launch3<ABL, false, false>(a, units, st);
+    return a.D == 16 ? wino_launch2<ABL, 16>(a, units, out32, st) : wino_launch2<ABL, 8>(a, units, out32, st);
 }
 
 // [32][32][27] -> U = G g G^T per (cout, cin, kd), pre-scaled per cout by a power of two so that max |U| lies in (512, 1024], split, in
@@ -539,7 +554,7 @@ extern "C" {
 size_t mvsgi_conv3d_wino32_packed_weight_bytes(void) { return (size_t)4 * 4 * 3 * 2 * 2 * 64 * 16; }
 
 int mvsgi_conv3d_wino32_applies(int Cin, int Cout, int D, int H, int W, int stride, float neg_slope) {
-    return Cin == 32 && Cout == 32 && stride == 1 && D == wn::DEPTH && H > 0 && W > 0 && H % 2 == 0 && W % 32 == 0 && neg_slope >= 0.f && neg_slope <= 1.f &&
+    return Cin == 32 && Cout == 32 && stride == 1 && (D == 8 || D == 16) && H > 0 && W > 0 && H % 2 == 0 && W % 32 == 0 && neg_slope >= 0.f && neg_slope <= 1.f &&
            (long long)(D + 2) * (H + 2) * (W + 2) * 128 < (1ll << 31);
 }
 
@@ -554,8 +569,8 @@ int mvsgi_conv3d_wino32_f16(const void* x_split, const void* w_packed, const flo
                             void* y, int y_is_f32, int B, int D, int H, int W, float neg_slope, void* stream) {
     MVSGI_REQUIRE(x_split && w_packed && scale && shift && y, "mvsgi_conv3d_wino32_f16: null pointer");
     MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_conv3d_wino32_f16: bad dims");
-    MVSGI_REQUIRE(D == wn::DEPTH && H % 2 == 0 && W % 32 == 0,
-                  "mvsgi_conv3d_wino32_f16: needs D == %d, H %% 2 == 0 and W %% 32 == 0 (got %d, %d, %d)", wn::DEPTH, D, H, W);
+    MVSGI_REQUIRE((D == 8 || D == 16) && H % 2 == 0 && W % 32 == 0,
+                  "mvsgi_conv3d_wino32_f16: needs D == 8 or 16, H %% 2 == 0 and W %% 32 == 0 (got %d, %d, %d)", D, H, W);
     MVSGI_REQUIRE(neg_slope >= 0.f && neg_slope <= 1.f, "mvsgi_conv3d_wino32_f16: neg_slope outside [0, 1]");
     MVSGI_REQUIRE((long long)B * (D + 2) * (H + 2) * (W + 2) * 128 < (1ll << 40), "mvsgi_conv3d_wino32_f16: tensor too large");
     MVSGI_REQUIRE((long long)(D + 2) * (H + 2) * (W + 2) * 128 < (1ll << 31), "mvsgi_conv3d_wino32_f16: frame too large for 32-bit plane offsets");

@@ -647,7 +647,7 @@ def pack_conv_weights_wino(w_oidhw: torch.Tensor):
 
 
 def conv3d_wino(x: SplitAct, w_packed, scale, shift, res: Optional[SplitAct] = None, neg_slope=0.01, out=None, out_f32: bool = False):
-    """Winograd-form 32 -> 32 conv (stride 1) on split-padded activations in the fp16 split; D == 8, H even, W % 32 == 0.
+    """Winograd-form 32 -> 32 conv (stride 1) on split-padded activations in the fp16 split; D == 8 or 16, H even, W % 32 == 0.
     `out_f32`: the result is a plain fp32 [B, D, H, W, 32] tensor instead of a SplitAct."""
     lib = _lib.load()
     if x.fmt != "f16" or x.C != 32:

@@ -2056,13 +2056,14 @@ def test_conv3d_rs_in_the_fp16_split_vs_oracle(shape, res, slope, out_f32):
             assert int(sl.abs().max()) == 0
 
 
-@pytest.mark.parametrize("shape", [(1, 8, 2, 32), (2, 8, 6, 64), (5, 8, 12, 32), (3, 8, 40, 160)])
+@pytest.mark.parametrize("shape", [(1, 8, 2, 32), (2, 8, 6, 64), (5, 8, 12, 32), (3, 8, 40, 160), (2, 16, 4, 32), (1, 16, 40, 160)])
 @pytest.mark.parametrize("res,slope,out_f32", [(True, 0.01, False), (False, 0.01, True), (True, 1.0, True), (False, 0.0, False)])
 def test_conv3d_winograd_in_the_fp16_split_vs_oracle(shape, res, slope, out_f32):
     """The Winograd F(2x2, 3x3) x direct-D form of the 32 -> 32 layers (csrc/conv3d_wino.hip; BaseConvBlk3d.forward,
     common_modules.py:107-115): transformed weights and activations in the fp16 split, 2.25 x fewer matrix instructions.  The same
-    5e-6 bar as the direct kernel in this split, against float64 on what it multiplied; units of several workgroups and of one
-    (the stream's tail), every epilogue variant; the border of a split-padded output stays zero."""
+    5e-6 bar as the direct kernel in this split, against float64 on what it multiplied; volumes of 8 and of 16 planes (the unit is
+    unrolled over either), units of several workgroups and of one (the stream's tail), every epilogue variant; the border of a
+    split-padded output stays zero."""
     B, d, h, w = shape
     rng = np.random.default_rng(sum(shape) + 18)
     x, r = _g(rng.standard_normal((B, d, h, w, 32), dtype=np.float32)), _g(rng.standard_normal((B, d, h, w, 32), dtype=np.float32))
@@ -2111,6 +2112,7 @@ def test_conv3d_winograd_weights_range_and_misuse():
     y = H.act_from_split(H.conv3d_wino(xs, wp1, torch.ones(32, device=DEV) * un1, torch.zeros(32, device=DEV), neg_slope=0.01))
     assert bool(torch.isfinite(y).all()) and float(y.max()) <= 65504.0
     assert not H.conv3d_wino_applies(32, 32, 7, 4, 32, 1, 0.01) and not H.conv3d_wino_applies(32, 32, 8, 3, 32, 1, 0.01)
+    assert H.conv3d_wino_applies(32, 32, 16, 4, 32, 1, 0.01) and not H.conv3d_wino_applies(32, 32, 12, 4, 32, 1, 0.01)
     assert not H.conv3d_wino_applies(32, 32, 8, 4, 48, 1, 0.01) and not H.conv3d_wino_applies(16, 32, 8, 4, 32, 1, 0.01)
     with pytest.raises(RuntimeError, match="needs D == 8"):
         H.conv3d_wino(H.act_to_split(torch.zeros((1, 4, 4, 32, 32), device=DEV), fmt="f16"), wp1, un1, un1)
