@@ -236,7 +236,7 @@ class ConvProbe:
             e.record()
             nv = x.B * x.D * x.H * x.W
             # algorithmic FLOPs = the direct convolution's (the Winograd form issues 16 / 36 of its matrix instructions)
-            self.records.append(("conv3d_wino32_kernel<0, %s, %s>" % ("true" if res is not None else "false", "true" if out_f32 else "false"),
+            self.records.append(("conv3d_wino32_kernel<0, %s, %s, %d>" % ("true" if res is not None else "false", "true" if out_f32 else "false", x.D),
                                  2.0 * 27 * 32 * 32 * nv, s, e, 4.0 * nv * 32 * (3 if res is not None else 2)))
             return y
 
