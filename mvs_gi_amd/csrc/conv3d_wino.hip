@@ -43,7 +43,7 @@ struct WinoArgs {
     int B, D, H, W;
     float neg_slope;
     int tiles_h, groups_w, total_units;
-    unsigned long long* dbg;   // diagnostic (MVSGI_WINO_ABL bit 16): per wave of workgroup 0, cycles per step section
+    unsigned long long* dbg;   // -DMVSGI_WINO_STAMPS builds (ABL = 16): per wave of workgroup 0, cycles per step section
 };
 
 // fp32 <- f16 half of a dword through the mixed-precision fma (one instruction where widen + add are two or three)
@@ -131,6 +131,7 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 }  // namespace wn
 
 // OUT32: the output is a plain fp32 channels-last tensor [B][D][H][W][32] (the hand-over to a kernel that stages fp32)
+// ABL: 0, or 16 = the section stamps of a -DMVSGI_WINO_STAMPS build
 template <int ABL, bool RES, bool OUT32, int DEPTH>
 __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     using namespace wn;
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
         constexpr int kd_ = 2 - g_, s_ = g_ == 0 ? (SF) : (g_ == 1 ? (SM) : (SI));                          \
         constexpr bool live_ = !(g_ == 0 && (P) == 0) && !(g_ == 2 && (P) == DEPTH - 1);                    \
         constexpr bool first_ = tm_ == 0 && (g_ == 2 || (g_ == 1 && (P) == 0));                             \
-        if constexpr (live_ && !(ABL & 1)) {                                                                \
+        if constexpr (live_) {                                                                              \
             if constexpr (s_ >= 1) {                                                                        \
                 if constexpr (first_) { WN_MFA0(Y[s_][b_][c_], wl[b_][kd_][c_], vh[VB][b_]) }               \
                 else if constexpr (tm_ == 0) { WN_MFA(Y[s_][b_][c_], wl[b_][kd_][c_], vh[VB][b_]) }         \
@@ -377,8 +378,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
                 else { WN_MF(Y[s_][b_][c_], wh[b_][kd_][c_], vh[VB][b_]) }                                  \
             }                                                                                               \
         }                                                                                                   \
-        if constexpr (!(ABL & 2)) { WN_TPIECE(M, (VB) ^ 1) }                                                \
-        if constexpr (!(ABL & 4)) { WN_DPIECE(M, P) }                                                       \
+        WN_TPIECE(M, (VB) ^ 1)                                                                              \
+        WN_DPIECE(M, P)                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
     }
 #define WN_S8(M, P, SI, SM, SF, VB)                                                                         \
