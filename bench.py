@@ -236,7 +236,8 @@ class ConvProbe:
             e.record()
             nv = x.B * x.D * x.H * x.W
             # algorithmic FLOPs = the direct convolution's (the Winograd form issues 16 / 36 of its matrix instructions)
-            self.records.append(("conv3d_wino32_kernel<0, %s, %s, %d>" % ("true" if res is not None else "false", "true" if out_f32 else "false", x.D),
+            self.records.append(("conv3d_wino32_kernel<0, %s, %s, %d, %s>" % ("true" if res is not None else "false", "true" if out_f32 else "false", x.D,
+                                                                              "true" if x.fmt == "f32p" else "false"),
                                  2.0 * 27 * 32 * 32 * nv, s, e, 4.0 * nv * 32 * (3 if res is not None else 2)))
             return y
 
@@ -267,15 +268,15 @@ class ConvProbe:
 
         self.orig_s2rs = H.conv3d_s2rs
 
-        def probed_s2rs(x, w_packed, shift, out, neg_slope=0.01, unscale=1.0):
+        def probed_s2rs(x, w_packed, shift, out, neg_slope=0.01, unscale=1.0, out_f32p=False):
             if not self.enabled:
-                return self.orig_s2rs(x, w_packed, shift, out, neg_slope, unscale)
+                return self.orig_s2rs(x, w_packed, shift, out, neg_slope, unscale, out_f32p)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            y = self.orig_s2rs(x, w_packed, shift, out, neg_slope, unscale)
+            y = self.orig_s2rs(x, w_packed, shift, out, neg_slope, unscale, out_f32p)
             e.record()
             nvo = out.B * out.D * out.H * out.W
-            self.records.append(("conv3d_s2rs_kernel<4, 2%s>" % (", true" if x.fmt == "f16" else ", false"), 2.0 * 27 * 16 * 32 * nvo, s, e, 4.0 * (16 * x.B * x.D * x.H * x.W + 32 * nvo)))
+            self.records.append(("conv3d_s2rs_kernel<4, 2%s>" % ((", true, true" if out_f32p else ", true, false") if x.fmt == "f16" else ", false, false"), 2.0 * 27 * 16 * 32 * nvo, s, e, 4.0 * (16 * x.B * x.D * x.H * x.W + 32 * nvo)))
             return y
 
         orig_poly, orig_up2s = H.conv3d_up2_poly, H.conv3d_up2_out_split

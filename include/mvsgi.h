@@ -397,6 +397,9 @@ int mvsgi_conv3d_rs16_split_fmt(const void* x_split, const void* w_packed_rs, co
 int mvsgi_conv3d_s2rs_pack_weights_fmt(const float* w_oidhw, const float* scale, void* w_packed, int fmt, mvsgi_stream_t stream);
 int mvsgi_conv3d_s2rs_fmt(const void* x_split, const void* w_packed, const float* shift, void* y_split, int B, int D, int H, int W,
                           float neg_slope, float unscale, int fmt, mvsgi_stream_t stream);
+/* y_f32p != 0 (MVSGI_SPLIT_F16 only): y is written "fp32-padded" (the padded geometry, plain fp32 records): see mvsgi_conv3d_wino32_f16 */
+int mvsgi_conv3d_s2rs_out_fmt(const void* x_split, const void* w_packed, const float* shift, void* y_split, int B, int D, int H, int W,
+                              float neg_slope, float unscale, int fmt, int y_f32p, mvsgi_stream_t stream);
 int mvsgi_conv3d_up2_poly_plan_fmt(const float* w_oidhw_host, void* plan_host, int D, int H, int W, int fmt);
 int mvsgi_conv3d_up2_poly_fmt(const void* x_split, const void* plan_dev, const float* scale, const float* shift, void* y,
                               int y_is_split, int B, int D, int H, int W, float neg_slope, int fmt, mvsgi_stream_t stream);
@@ -410,9 +413,11 @@ size_t mvsgi_conv3d_wino32_packed_weight_bytes(void);
 int mvsgi_conv3d_wino32_applies(int Cin, int Cout, int D, int H, int W, int stride, float neg_slope);
 /* w_oidhw [32][32][3][3][3] -> w_packed (mvsgi_conv3d_wino32_packed_weight_bytes()), unscale [32] (2^-k per cout: multiply the layer's scale by it) */
 int mvsgi_conv3d_wino32_pack_weights(const float* w_oidhw, void* w_packed, float* unscale, mvsgi_stream_t stream);
-/* y: split-padded fp16 [B][D+2][H+2][W+2][32] (y_is_f32 == 0) or plain fp32 [B][D][H][W][32]; res_split: split-padded fp16 or NULL */
+/* y: split-padded fp16 [B][D+2][H+2][W+2][32] (y_is_f32 == 0) or plain fp32 [B][D][H][W][32]; res_split: split-padded fp16 or NULL.
+ * act_f32p != 0: x, res and a padded y are "fp32-padded" instead -- the same padded geometry with plain fp32 records (32 floats per
+ * voxel, zero border): the hand-over between Winograd layers, which split their operands behind the transform anyway. */
 int mvsgi_conv3d_wino32_f16(const void* x_split, const void* w_packed, const float* scale, const float* shift, const void* res_split,
-                            void* y, int y_is_f32, int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream);
+                            void* y, int y_is_f32, int act_f32p, int B, int D, int H, int W, float neg_slope, mvsgi_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -104,11 +104,12 @@ SIGNATURES = {
     "mvsgi_conv3d_rs16_split_fmt": (c_int, [_P] * 5 + [c_int] * 5 + [c_float, c_int, _P]),
     "mvsgi_conv3d_s2rs_pack_weights_fmt": (c_int, [_P, _P, _P, c_int, _P]),
     "mvsgi_conv3d_s2rs_fmt": (c_int, [_P] * 4 + [c_int] * 4 + [c_float, c_float, c_int, _P]),
+    "mvsgi_conv3d_s2rs_out_fmt": (c_int, [_P] * 4 + [c_int] * 4 + [c_float, c_float, c_int, c_int, _P]),
     "mvsgi_conv3d_up2_poly_plan_fmt": (c_int, [_P, _P] + [c_int] * 4),
     "mvsgi_conv3d_wino32_packed_weight_bytes": (c_size_t, []),
     "mvsgi_conv3d_wino32_applies": (c_int, [c_int] * 6 + [c_float]),
     "mvsgi_conv3d_wino32_pack_weights": (c_int, [_P] * 4),
-    "mvsgi_conv3d_wino32_f16": (c_int, [_P] * 6 + [c_int] * 5 + [c_float, _P]),
+    "mvsgi_conv3d_wino32_f16": (c_int, [_P] * 6 + [c_int] * 6 + [c_float, _P]),
     "mvsgi_conv3d_up2_poly_fmt": (c_int, [_P] * 5 + [c_int] * 5 + [c_float, c_int, _P]),
     "mvsgi_ncv_to_nvc_f32": (c_int, [_P, _P, c_int, c_int, c_longlong, _P]),
     "mvsgi_nvc_to_ncv_f32": (c_int, [_P, _P, c_int, c_int, c_longlong, _P]),

@@ -134,7 +134,9 @@ __device__ __forceinline__ int s2_xcd_remap(int bid, int n) {
 // two workgroups per CU -- the next window is requested when the workgroup is done with the current one, and the partner workgroup's
 // request is in flight meanwhile (~1.6 windows in flight per CU instead of 1).  Measured the same within 2 % (565 vs 577 us per 64
 // frames): the kernel is not short of requests in flight; NBUF = 2 is the default, MVSGI_S2RS_NBUF=1 selects the other.
-template <int TH, int NBUF, bool F16 = false>
+// O32P: the output is "fp32-padded" -- the split-padded geometry with plain fp32 records -- for a Winograd-form level 0 behind it
+// (csrc/conv3d_wino.hip: its layers split their operands behind the transform, a pre-split input buys them nothing)
+template <int TH, int NBUF, bool F16 = false, bool O32P = false>
 __global__ __launch_bounds__(256, (TH == 4 && NBUF == 2) ? 1 : 2) void conv3d_s2rs_kernel(S2Args a) {
     using namespace s2;
     using G = Geo<TH>;
@@ -187,7 +189,8 @@ __global__ __launch_bounds__(256, (TH == 4 && NBUF == 2) ? 1 : 2) void conv3d_s2
         voff[m] = v < NPX ? (unsigned)(((pl * Hp + row) * Wp + c) * 64 + region * 32 + chunk * 16) : 0xffffff00u;
     }
     // ---- output: this lane's 16 bytes of voxel (row t0 + i, ow = col) of slice ct: lanes kg and kg ^ 1 trade halves ----
-    unsigned vst = (unsigned)((t0 * Wop + col) * 128 + ct * 64 + (kg & 1) * 32 + (kg >> 1) * 16);
+    unsigned vst = O32P ? (unsigned)((t0 * Wop + col) * 128 + ct * 64 + kg * 16)
+                        : (unsigned)((t0 * Wop + col) * 128 + ct * 64 + (kg & 1) * 32 + (kg >> 1) * 16);
 
     // brick order (b, oh, od, ow), ow fastest: the bricks stacked along D share one of their three input planes and follow each
     // other within one XCD round
@@ -271,7 +274,9 @@ __global__ __launch_bounds__(256, (TH == 4 && NBUF == 2) ? 1 : 2) void conv3d_s2
                 f32x4 v = acc[i] + (acc1[i] + acc2[i]);          // the small terms first
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = lrelu(F16 ? v[e] * a.unscale : v[e], a.neg_slope);
-                const u32x4 o = s2_pack_split<F16>(v);
+                u32x4 o;
+                if constexpr (O32P) o = __builtin_bit_cast(u32x4, v);
+                else o = s2_pack_split<F16>(v);
                 if (okc && oh0 + t0 + i < a.Ho) s2_store16(o, dsc_, vst, i * Wop * 128);
             }
         }
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256, (TH == 4 && NBUF == 2) ? 1 : 2) void conv3d_s2
 #undef S2_STAGE
 }
 
-template <int TH, int NBUF, bool F16 = false>
+template <int TH, int NBUF, bool F16 = false, bool O32P = false>
 int s2_launch(S2Args a, hipStream_t st) {
     constexpr int lds_bytes = NBUF * s2::Geo<TH>::IMG;
     constexpr int wgs = (TH == 4 && NBUF == 2) ? 1 : 2;
@@ -293,10 +298,10 @@ int s2_launch(S2Args a, hipStream_t st) {
     a.total_units = (int)nb;
     static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
-    if (mvsgi::persistent_geometry(conv3d_s2rs_kernel<TH, NBUF, F16>, 256, lds_bytes, wgs, geo_cache, "mvsgi_conv3d_s2rs", geo)) return 1;
+    if (mvsgi::persistent_geometry(conv3d_s2rs_kernel<TH, NBUF, F16, O32P>, 256, lds_bytes, wgs, geo_cache, "mvsgi_conv3d_s2rs", geo)) return 1;
     long long resident = ((long long)geo.cus * geo.wgs_per_cu) / 8 * 8;
     if (resident < 8) resident = 8;
-    hipLaunchKernelGGL((conv3d_s2rs_kernel<TH, NBUF, F16>), dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), lds_bytes, st, a);
+    hipLaunchKernelGGL((conv3d_s2rs_kernel<TH, NBUF, F16, O32P>), dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), lds_bytes, st, a);
     return mvsgi::check_launch("mvsgi_conv3d_s2rs");
 }
 
@@ -320,9 +325,11 @@ extern "C" int mvsgi_conv3d_s2rs_pack_weights(const float* w_oidhw, const float*
 // zero-bordered, only y's interior is written.  w_packed from mvsgi_conv3d_s2rs_pack_weights (scale folded in).
 // _fmt: fmt = MVSGI_SPLIT_F16 runs the layer in the fp16 split; `scale` (at packing) and `shift` then carry a power of two 1 / unscale
 // chosen by the caller (the epilogue has no per-channel multiplier to hide it in), and the accumulators are multiplied by `unscale`
-extern "C" int mvsgi_conv3d_s2rs_fmt(const void* x_split, const void* w_packed, const float* shift, void* y_split, int B, int D, int H,
-                                     int W, float neg_slope, float unscale, int fmt, mvsgi_stream_t stream) {
+// _out_fmt: y_f32p != 0 (fp16 split only) writes y "fp32-padded": the same padded geometry, plain fp32 records
+extern "C" int mvsgi_conv3d_s2rs_out_fmt(const void* x_split, const void* w_packed, const float* shift, void* y_split, int B, int D, int H,
+                                         int W, float neg_slope, float unscale, int fmt, int y_f32p, mvsgi_stream_t stream) {
     MVSGI_REQUIRE(x_split && w_packed && shift && y_split, "mvsgi_conv3d_s2rs: null pointer");
+    MVSGI_REQUIRE(!y_f32p || fmt == MVSGI_SPLIT_F16, "mvsgi_conv3d_s2rs: the fp32-padded output exists in the fp16 split only");
     MVSGI_REQUIRE(fmt == 0 || fmt == MVSGI_SPLIT_F16, "mvsgi_conv3d_s2rs: fmt %d not in {0, MVSGI_SPLIT_F16}", fmt);
     MVSGI_REQUIRE(fmt != 0 || unscale == 1.f, "mvsgi_conv3d_s2rs: unscale is a parameter of the fp16 split");
     MVSGI_REQUIRE(unscale > 0.f, "mvsgi_conv3d_s2rs: unscale must be positive");
@@ -340,6 +347,7 @@ extern "C" int mvsgi_conv3d_s2rs_fmt(const void* x_split, const void* w_packed, 
     a.neg_slope = neg_slope;
     a.unscale = unscale;
     hipStream_t st = mvsgi::as_stream(stream);
+    if (fmt && y_f32p) return s2_launch<4, 2, true, true>(a, st);
     if (fmt) return s2_launch<4, 2, true>(a, st);
 #ifdef MVSGI_EXPERIMENTAL      // measured equal or slower (DESIGN_HISTORY.md): 2-row bricks with two workgroups per CU, single-window workgroups
     const char* th_e = mvsgi::exp_env("MVSGI_S2RS_TH");          // brick height: 4 output rows (one workgroup per CU) or 2 (two)
@@ -348,6 +356,10 @@ extern "C" int mvsgi_conv3d_s2rs_fmt(const void* x_split, const void* w_packed, 
     if (nb_e && atoi(nb_e) == 1) return s2_launch<4, 1>(a, st);
 #endif
     return s2_launch<4, 2>(a, st);
+}
+extern "C" int mvsgi_conv3d_s2rs_fmt(const void* x_split, const void* w_packed, const float* shift, void* y_split, int B, int D, int H,
+                                     int W, float neg_slope, float unscale, int fmt, mvsgi_stream_t stream) {
+    return mvsgi_conv3d_s2rs_out_fmt(x_split, w_packed, shift, y_split, B, D, H, W, neg_slope, unscale, fmt, 0, stream);
 }
 extern "C" int mvsgi_conv3d_s2rs(const void* x_split, const void* w_packed, const float* shift, void* y_split, int B, int D, int H,
                                  int W, float neg_slope, mvsgi_stream_t stream) {

@@ -132,7 +132,10 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // OUT32: the output is a plain fp32 channels-last tensor [B][D][H][W][32] (the hand-over to a kernel that stages fp32)
 // ABL: 0, or 16 = the section stamps of a -DMVSGI_WINO_STAMPS build
-template <int ABL, bool RES, bool OUT32, int DEPTH>
+// A32: activations (input, residual, padded output) are "fp32-padded" -- the split-padded geometry with plain fp32 records
+//      [B][D+2][H+2][W+2][32 floats], zero border -- instead of fp16 pairs: the hand-over BETWEEN Winograd layers (their operands are
+//      split after the transform anyway: no join in front of it, no split behind the epilogue: ~90 of ~420 vector instructions a step)
+template <int ABL, bool RES, bool OUT32, int DEPTH, bool A32>
 __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     using namespace wn;
     static_assert(DEPTH % NBUF == 0 && DEPTH % 2 == 0, "image / V pair phases of the unrolled unit");
@@ -178,8 +181,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     const int lane_out32 = (2 * n) * 128 + kg * 16;                           // (fp32 output: its 16 bytes = couts 4 kg .. 4 kg + 3 of the voxel's first 16)
     const long long oplane_bytes = (long long)a.H * a.W * 128;
     // fragment reads: this lane's hi piece (slice kg >> 1, channel half kg & 1) of column 2 n in patch rows i0 / i1, image 0
-    const int rd0 = ((i0 * 2 * HALF + n) * PITCH + (kg >> 1) * 4 + (kg & 1)) * 16;
-    const int rd1 = ((i1 * 2 * HALF + n) * PITCH + (kg >> 1) * 4 + (kg & 1)) * 16;
+    // (fp32 records: channels 8 kg .. 8 kg + 7 are pieces 2 kg, 2 kg + 1)
+    const int rd0 = ((i0 * 2 * HALF + n) * PITCH + (A32 ? 2 * kg : (kg >> 1) * 4 + (kg & 1))) * 16;
+    const int rd1 = ((i1 * 2 * HALF + n) * PITCH + (A32 ? 2 * kg : (kg >> 1) * 4 + (kg & 1))) * 16;
+    constexpr int RD2 = A32 ? 16 : 32;                // from a lane's first piece to its second
     // ---- DMA plans: piece m = wv + 4 k fills slots [64 m, 64 m + 64) of an image ----
     unsigned voff[DPW], rvoff[RDPW];
 #pragma unroll
@@ -198,7 +203,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
         rvoff[k] = (vox < 64 && piece < 8) ? (unsigned)(((vox >> 5) * Wp + (vox & 31)) * 128 + piece * 16) : 0xffffff00u;
     }
     // the epilogue's residual reads: voxel (row pa, column 2 n + q), this lane's 8 bytes of slice 0's hi piece
-    const int rrd = ((pa * 32 + 2 * n + q) * PITCH + (kg >> 1)) * 16 + (kg & 1) * 8;
+    const int rrd = A32 ? ((pa * 32 + 2 * n + q) * PITCH + kg) * 16                       // (fp32 records: 16 bytes = couts 4 kg .. 4 kg + 3 of a cout tile)
+                        : ((pa * 32 + 2 * n + q) * PITCH + (kg >> 1)) * 16 + (kg & 1) * 8;
 
     f32x4 Y[3][4][2];
     u32x4 vh[2][4], vl[2][4];      // V of the plane being multiplied | of the next one (written while the first is read)
@@ -252,9 +258,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                  \
             const int o_ = (((j_ & 1) * HALF + (j_ >> 1)) * PITCH) * 16;                                    \
             raw[0][j_][0] = *reinterpret_cast<const u32x4*>(im_ + rd0 + o_);                                \
-            raw[0][j_][1] = *reinterpret_cast<const u32x4*>(im_ + rd0 + o_ + 32);                           \
+            raw[0][j_][1] = *reinterpret_cast<const u32x4*>(im_ + rd0 + o_ + RD2);                          \
             raw[1][j_][0] = *reinterpret_cast<const u32x4*>(im_ + rd1 + o_);                                \
-            raw[1][j_][1] = *reinterpret_cast<const u32x4*>(im_ + rd1 + o_ + 32);                           \
+            raw[1][j_][1] = *reinterpret_cast<const u32x4*>(im_ + rd1 + o_ + RD2);                          \
         }                                                                                                   \
     }
 // One piece of the transform raw -> V[VN] (all four b of this wave's a; split; B-operand layout: lane (tile n, kg) holds channels
@@ -268,7 +274,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
             constexpr int j_ = r_ >> 1;                                                                     \
             /* ONE asm statement per chain: hipcc pads every VGPR an asm statement defines against a use by the very next instruction \
                (it must assume a partial-register write), 4 cycles per pad, and only its own instructions count as distance */ \
-            if constexpr ((r_ & 1) == 0) {                                                                  \
+            if constexpr (A32) {    /* channel 2 d_ + (r_ & 1) of the lane's eight: one fma */            \
+                constexpr int e_ = (d_ & 1) * 2 + (r_ & 1);                                                 \
+                T[r_ & 1][j_] = __builtin_fmaf(__builtin_bit_cast(float, raw[1][j_][d_ >> 1][e_] | 0u), sgn, \
+                                               __builtin_bit_cast(float, raw[0][j_][d_ >> 1][e_] | 0u));    \
+            } else if constexpr ((r_ & 1) == 0) {                                                           \
                 asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"                    \
                     "v_fma_mix_f32 %0, %3, %5, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"                     \
                     "v_fma_mix_f32 %0, %4, %5, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]"                          \
@@ -328,17 +338,24 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_)                                                        \
         _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_)                                                    \
             zz_[c_][k_] = *reinterpret_cast<const f32x4*>(lds + ZB + (ZIMG) * 16384 + (((pa + k_) * 2 + q) * 2 + c_) * 1024 + lane * 16); \
+    f32x4 rf_[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};                                 \
     if constexpr (RES) {                                                                                    \
         _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) {                                                  \
-            rh_[c_] = *reinterpret_cast<const u32x2*>(rim_ + rrd + c_ * 64);                                \
-            rl_[c_] = *reinterpret_cast<const u32x2*>(rim_ + rrd + c_ * 64 + 32);                           \
+            if constexpr (A32) {                                                                            \
+                rf_[c_] = *reinterpret_cast<const f32x4*>(rim_ + rrd + c_ * 64);                            \
+            } else {                                                                                        \
+                rh_[c_] = *reinterpret_cast<const u32x2*>(rim_ + rrd + c_ * 64);                            \
+                rl_[c_] = *reinterpret_cast<const u32x2*>(rim_ + rrd + c_ * 64 + 32);                       \
+            }                                                                                               \
         }                                                                                                   \
     }
 #define WN_EPILOGUE(O)                                                                                      \
     _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) {                                                      \
         f32x4 t_ = zz_[c_][0] + osg * (zz_[c_][1] + zz_[c_][2]);                                            \
         t_ = t_ * esc_[c_] + esh_[c_];                                                                      \
-        if constexpr (RES) {                                                                                \
+        if constexpr (RES && A32) {                                                                         \
+            t_ = t_ + rf_[c_];                                                                              \
+        } else if constexpr (RES) {                                                                         \
             t_[0] = mix_add_lo(rl_[c_][0], mix_add_lo(rh_[c_][0], t_[0]));                                  \
             t_[1] = mix_add_hi(rl_[c_][0], mix_add_hi(rh_[c_][0], t_[1]));                                  \
             t_[2] = mix_add_lo(rl_[c_][1], mix_add_lo(rh_[c_][1], t_[2]));                                  \
@@ -347,6 +364,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) t_[e_] = __builtin_fmaxf(t_[e_], t_[e_] * a.neg_slope); \
         if constexpr (OUT32) {                                                                              \
             *reinterpret_cast<f32x4*>(yb + (long long)(O) * oplane_bytes + lane_out32 + c_ * 64) = t_;      \
+        } else if constexpr (A32) {                                                                         \
+            *reinterpret_cast<f32x4*>(yb + (long long)((O) + 1) * plane_bytes + lane_out32 + c_ * 64) = t_; \
         } else {                                                                                            \
             unsigned h0_, l0_, h1_, l1_;                                                                    \
             split_pair(t_[0], t_[1], h0_, l0_);                                                             \
@@ -429,7 +448,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
         unsigned char* rim_ = lds + RB + rprev * RES_LDS;                                                   \
         WN_OUT_WRITE(SF, (DEPTH - 1) & 1)                                                                   \
         /* its residual was requested in the step before, in front of that step's input plane (5 requests) and output stores (4, or 2 fp32) */ \
-        if constexpr (OUT32) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");                    \
+        if constexpr (OUT32 || A32) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");             \
         else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");                                    \
         __builtin_amdgcn_s_barrier();                                                                       \
         WN_EPI_READS((DEPTH - 1) & 1)                                                                       \
@@ -483,23 +502,24 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     }
 }
 
-template <int ABL, bool RES, bool OUT32, int DEPTH>
-int wino_launch4(const WinoArgs& a, long long units, hipStream_t st) {
+template <int ABL, bool RES, bool OUT32, int DEPTH, bool A32>
+int wino_launch5(const WinoArgs& a, long long units, hipStream_t st) {
     static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
-    if (mvsgi::persistent_geometry(conv3d_wino32_kernel<ABL, RES, OUT32, DEPTH>, 256, wn::LDS_BYTES, 1, geo_cache, "conv3d(winograd)", geo)) return 1;
+    if (mvsgi::persistent_geometry(conv3d_wino32_kernel<ABL, RES, OUT32, DEPTH, A32>, 256, wn::LDS_BYTES, 1, geo_cache, "conv3d(winograd)", geo)) return 1;
     const unsigned grid = (unsigned)(units < geo.cus ? units : geo.cus);
-    hipLaunchKernelGGL((conv3d_wino32_kernel<ABL, RES, OUT32, DEPTH>), dim3(grid), dim3(256), wn::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv3d_wino32_kernel<ABL, RES, OUT32, DEPTH, A32>), dim3(grid), dim3(256), wn::LDS_BYTES, st, a);
     return 0;
 }
-template <int ABL, int DEPTH>
-int wino_launch2(const WinoArgs& a, long long units, bool out32, hipStream_t st) {
-    if (out32) return a.res ? wino_launch4<ABL, true, true, DEPTH>(a, units, st) : wino_launch4<ABL, false, true, DEPTH>(a, units, st);
-    return a.res ? wino_launch4<ABL, true, false, DEPTH>(a, units, st) : wino_launch4<ABL, false, false, DEPTH>(a, units, st);
+template <int ABL, int DEPTH, bool A32>
+int wino_launch3(const WinoArgs& a, long long units, bool out32, hipStream_t st) {
+    if (out32) return a.res ? wino_launch5<ABL, true, true, DEPTH, A32>(a, units, st) : wino_launch5<ABL, false, true, DEPTH, A32>(a, units, st);
+    return a.res ? wino_launch5<ABL, true, false, DEPTH, A32>(a, units, st) : wino_launch5<ABL, false, false, DEPTH, A32>(a, units, st);
 }
 template <int ABL>
-int wino_launch(const WinoArgs& a, long long units, bool out32, hipStream_t st) {
-    return a.D == 16 ? wino_launch2<ABL, 16>(a, units, out32, st) : wino_launch2<ABL, 8>(a, units, out32, st);
+int wino_launch(const WinoArgs& a, long long units, bool out32, bool act32, hipStream_t st) {
+    if (act32) return a.D == 16 ? wino_launch3<ABL, 16, true>(a, units, out32, st) : wino_launch3<ABL, 8, true>(a, units, out32, st);
+    return a.D == 16 ? wino_launch3<ABL, 16, false>(a, units, out32, st) : wino_launch3<ABL, 8, false>(a, units, out32, st);
 }
 
 // [32][32][27] -> U = G g G^T per (cout, cin, kd), pre-scaled per cout by a power of two so that max |U| lies in (512, 1024], split, in
@@ -567,7 +587,7 @@ int mvsgi_conv3d_wino32_pack_weights(const float* w_oidhw, void* w_packed, float
 }
 
 int mvsgi_conv3d_wino32_f16(const void* x_split, const void* w_packed, const float* scale, const float* shift, const void* res_split,
-                            void* y, int y_is_f32, int B, int D, int H, int W, float neg_slope, void* stream) {
+                            void* y, int y_is_f32, int act_f32p, int B, int D, int H, int W, float neg_slope, void* stream) {
     MVSGI_REQUIRE(x_split && w_packed && scale && shift && y, "mvsgi_conv3d_wino32_f16: null pointer");
     MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_conv3d_wino32_f16: bad dims");
     MVSGI_REQUIRE((D == 8 || D == 16) && H % 2 == 0 && W % 32 == 0,
@@ -596,7 +616,7 @@ int mvsgi_conv3d_wino32_f16(const void* x_split, const void* w_packed, const flo
         static unsigned long long* dbg = nullptr;
         if (!dbg) (void)hipMalloc(&dbg, 32 * 8);
         a.dbg = dbg;
-        if (wino_launch<16>(a, units, y_is_f32 != 0, st)) return 1;
+        if (wino_launch<16>(a, units, y_is_f32 != 0, act_f32p != 0, st)) return 1;
         (void)hipDeviceSynchronize();
         unsigned long long h[32];
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
@@ -608,7 +628,7 @@ int mvsgi_conv3d_wino32_f16(const void* x_split, const void* w_packed, const flo
         return mvsgi::check_launch("mvsgi_conv3d_wino32_f16");
     }
 #endif
-    if (wino_launch<0>(a, units, y_is_f32 != 0, st)) return 1;
+    if (wino_launch<0>(a, units, y_is_f32 != 0, act_f32p != 0, st)) return 1;
     return mvsgi::check_launch("mvsgi_conv3d_wino32_f16");
 }
 

@@ -38,6 +38,7 @@ class UNetDownBlk(nn.Module):
 # 128-voxel bricks per launch (one workgroup per CU, each with a prologue and two drain phases: small launches lose)
 _USE_RS = H.exp_env("MVSGI_RS", "1") != "0"
 _USE_WINO = os.environ.get("MVSGI_WINO", "1") != "0"        # MVSGI_WINO=0: the level-0 residual convs stay on the direct kernel in the fp16 split too
+_WINO_A32 = H.exp_env("MVSGI_WINO_A32", "1") != "0"          # (experiment switch: 0 = split-padded fp16 pairs between the Winograd layers)
 _RS_MIN_UNITS = int(H.exp_env("MVSGI_RS_MIN_UNITS", "0"))      # measured faster down to one frame (B=1: 16.9 vs 24.2 us, 23.5 vs 32.2 us)
 
 
@@ -98,28 +99,29 @@ def _down_block_rs(blk, x: Tensor, L0, chain, dims) -> Tensor:
         sets[key] = [H.SplitAct(B, Do, Ho, Wo, 32, x.device) for _ in range(3)]
     b = sets[key]
     fmt = H.mode_fmt()              # the split of this chain's activations and weights (the library's mode)
+    # fp16 split on a [8 | 16, even, 32 k] volume: the Winograd form (2.25 x fewer matrix instructions, csrc/conv3d_wino.hip) when its
+    # units fill the chip; behind the split-padded hand-over its layers pass fp32-padded activations to each other
+    wino = fmt == "f16" and _USE_WINO and _wino_pays(B, Ho, Wo, x.device) and \
+        all(L1.wino_ok(Do, Ho, Wo) and L2.wino_ok(Do, Ho, Wo) for L1, L2 in chain)
     if isinstance(x, H.SplitAct):      # the builder handed post_vol's output over split-padded: staged by LDS-DMA (csrc/conv3d_s2rs.hip)
         if x.fmt != fmt:
             raise RuntimeError(f"split-padded cost volume holds {x.fmt} pieces, the library's mode writes {fmt}")
         wp0, sh0, un0 = L0._s2(fmt)
-        H.conv3d_s2rs(x, wp0, sh0, out=b[0], neg_slope=L0.neg_slope, unscale=un0)
+        H.conv3d_s2rs(x, wp0, sh0, out=b[0], neg_slope=L0.neg_slope, unscale=un0, out_f32p=wino and _WINO_A32)
     else:
         wp0, sc0 = L0._b3(fmt)
         H.conv3d_out_split(x, wp0, sc0, L0.shift, out=b[0], stride=L0.stride, neg_slope=L0.neg_slope, fmt=fmt)
+    conv = H.conv3d_wino if wino else H.conv3d_rs
     cur, out = 0, None
     for i, (L1, L2) in enumerate(chain):
         r, y = (cur + 1) % 3, (cur + 2) % 3
-        # fp16 split on a [8, even, 32 k] volume: the Winograd form (2.25 x fewer matrix instructions, csrc/conv3d_wino.hip)
-        wino = fmt == "f16" and _USE_WINO and _wino_pays(B, Ho, Wo, x.device)
-        conv1 = H.conv3d_wino if wino and L1.wino_ok(Do, Ho, Wo) else None
-        conv2 = H.conv3d_wino if wino and L2.wino_ok(Do, Ho, Wo) else None
-        (wp1, sc1) = L1._wino() if conv1 else L1._rs(fmt)
-        (wp2, sc2) = L2._wino() if conv2 else L2._rs(fmt)
-        (conv1 or H.conv3d_rs)(b[cur], wp1, sc1, L1.shift, neg_slope=L1.neg_slope, out=b[r])
+        (wp1, sc1) = L1._wino() if wino else L1._rs(fmt)
+        (wp2, sc2) = L2._wino() if wino else L2._rs(fmt)
+        conv(b[cur], wp1, sc1, L1.shift, neg_slope=L1.neg_slope, out=b[r])
         if i == len(chain) - 1:
-            out = (conv2 or H.conv3d_rs)(b[r], wp2, sc2, L2.shift, res=b[cur], neg_slope=L2.neg_slope, out_f32=True)
+            out = conv(b[r], wp2, sc2, L2.shift, res=b[cur], neg_slope=L2.neg_slope, out_f32=True)
         else:
-            (conv2 or H.conv3d_rs)(b[r], wp2, sc2, L2.shift, res=b[cur], neg_slope=L2.neg_slope, out=b[y])
+            conv(b[r], wp2, sc2, L2.shift, res=b[cur], neg_slope=L2.neg_slope, out=b[y])
             cur = y
     return out
 

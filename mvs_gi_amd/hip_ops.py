@@ -646,12 +646,31 @@ def pack_conv_weights_wino(w_oidhw: torch.Tensor):
     return wp, unscale
 
 
-def conv3d_wino(x: SplitAct, w_packed, scale, shift, res: Optional[SplitAct] = None, neg_slope=0.01, out=None, out_f32: bool = False):
-    """Winograd-form 32 -> 32 conv (stride 1) on split-padded activations in the fp16 split; D == 8 or 16, H even, W % 32 == 0.
-    `out_f32`: the result is a plain fp32 [B, D, H, W, 32] tensor instead of a SplitAct."""
+def act_to_f32p(x_ndhwc: torch.Tensor, out: Optional[SplitAct] = None) -> SplitAct:
+    """fp32 NDHWC -> "fp32-padded": the split-padded geometry with plain fp32 records (tests / tools; torch copies)."""
+    x = _dev(x_ndhwc, "x")
+    B, D, Hh, W, C = x.shape
+    y = out if out is not None else SplitAct(B, D, Hh, W, C, x.device)
+    y.buf.view(torch.float32)[:, 1:-1, 1:-1, 1:-1, :] = x
+    y.fmt = "f32p"
+    return y
+
+
+def act_from_f32p(x: SplitAct) -> torch.Tensor:
+    if x.fmt != "f32p":
+        raise AssertionError(f"buffer holds {x.fmt} records")
+    return x.buf.view(torch.float32)[:, 1:-1, 1:-1, 1:-1, :].contiguous()
+
+
+def conv3d_wino(x: SplitAct, w_packed, scale, shift, res: Optional[SplitAct] = None, neg_slope=0.01, out=None, out_f32: bool = False,
+                ):
+    """Winograd-form 32 -> 32 conv (stride 1) on padded activations, arithmetic in the fp16 split; D == 8 or 16, H even, W % 32 == 0.
+    x (and res) are split-padded fp16 pairs (fmt 'f16') or fp32-padded ('f32p': plain fp32 records in the same padded geometry --
+    the cheaper hand-over between Winograd layers); the output takes x's format.  `out_f32`: the result is a plain fp32
+    [B, D, H, W, 32] tensor instead of a SplitAct."""
     lib = _lib.load()
-    if x.fmt != "f16" or x.C != 32:
-        raise AssertionError(f"conv3d_wino: needs a 32-channel input in the fp16 split (got {x.C}, {x.fmt})")
+    if x.fmt not in ("f16", "f32p") or x.C != 32:
+        raise AssertionError(f"conv3d_wino: needs a 32-channel input in the fp16 split or fp32-padded (got {x.C}, {x.fmt})")
     if out_f32:
         y = out if out is not None else torch.empty(x.shape, device=x.buf.device, dtype=torch.float32)
         if tuple(y.shape) != x.shape or not y.is_contiguous() or y.dtype != torch.float32:
@@ -662,15 +681,15 @@ def conv3d_wino(x: SplitAct, w_packed, scale, shift, res: Optional[SplitAct] = N
         if y.shape != x.shape:
             raise AssertionError(f"split output {y.shape} does not match {x.shape}")
         yp = y.buf.data_ptr()
-    if res is not None and (res.shape != x.shape or res.fmt != "f16"):
-        raise AssertionError(f"residual {res.shape} ({res.fmt}) does not match the output")
+    if res is not None and (res.shape != x.shape or res.fmt != x.fmt):
+        raise AssertionError(f"residual {res.shape} ({res.fmt}) does not match the input ({x.fmt})")
     if w_packed.numel() != lib.mvsgi_conv3d_wino32_packed_weight_bytes():
         raise AssertionError("conv3d_wino: packed weights of the wrong size")
     _lib.check(lib.mvsgi_conv3d_wino32_f16(x.buf.data_ptr(), w_packed.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                           None if res is None else res.buf.data_ptr(), yp, int(out_f32), x.B, x.D, x.H, x.W,
-                                           float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_wino32_f16")
+                                           None if res is None else res.buf.data_ptr(), yp, int(out_f32), int(x.fmt == "f32p"),
+                                           x.B, x.D, x.H, x.W, float(neg_slope), _stream_ptr(x.buf)), "mvsgi_conv3d_wino32_f16")
     if not out_f32:
-        y.fmt = "f16"
+        y.fmt = x.fmt
     return y
 
 
@@ -739,15 +758,17 @@ def pack_conv_weights_s2rs(w_oidhw: torch.Tensor, scale: torch.Tensor, fmt: str 
     return (wp, up, un) if fmt == "f16" else wp
 
 
-def conv3d_s2rs(x: "SplitAct", w_packed, shift, out: "SplitAct", neg_slope=0.01, unscale: float = 1.0) -> "SplitAct":
-    """16 -> 32 channel 3x3x3 stride-2 conv + scale / shift + LeakyReLU, split-padded in and out (LDS-DMA staging)."""
+def conv3d_s2rs(x: "SplitAct", w_packed, shift, out: "SplitAct", neg_slope=0.01, unscale: float = 1.0, out_f32p: bool = False) -> "SplitAct":
+    """16 -> 32 channel 3x3x3 stride-2 conv + scale / shift + LeakyReLU, split-padded in and out (LDS-DMA staging).
+    `out_f32p` (fp16 split): the output is fp32-padded (plain fp32 records, fmt 'f32p') for a Winograd-form level 0 behind it."""
     lib = _lib.load()
     Do, Ho, Wo = (x.D - 1) // 2 + 1, (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
     if x.C != 16 or out.shape != (x.B, Do, Ho, Wo, 32) or shift.numel() != 32:
         raise AssertionError(f"conv3d_s2rs: input {x.shape} -> output {out.shape}, expected {(x.B, Do, Ho, Wo, 32)}")
-    _lib.check(lib.mvsgi_conv3d_s2rs_fmt(x.buf.data_ptr(), w_packed.data_ptr(), shift.data_ptr(), out.buf.data_ptr(), x.B, x.D, x.H, x.W,
-                                         float(neg_slope), float(unscale), _fmt_code(x.fmt), _stream_ptr(x.buf)), "mvsgi_conv3d_s2rs")
-    out.fmt = x.fmt
+    _lib.check(lib.mvsgi_conv3d_s2rs_out_fmt(x.buf.data_ptr(), w_packed.data_ptr(), shift.data_ptr(), out.buf.data_ptr(), x.B, x.D, x.H, x.W,
+                                             float(neg_slope), float(unscale), _fmt_code(x.fmt), int(out_f32p), _stream_ptr(x.buf)),
+               "mvsgi_conv3d_s2rs")
+    out.fmt = "f32p" if out_f32p else x.fmt
     return out
 
 

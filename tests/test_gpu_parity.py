@@ -1645,7 +1645,8 @@ def test_full_size_batch8_register_stationary_path_vs_reference_golden(golden_di
         inv = hp(_g(inp["feats"]).expand(8, -1, -1, -1, -1).contiguous())[0]
         assert "_mvsgi_rs_bufs" in hp.cv_regulator.down_blks[0].__dict__
         fmt = "f16" if split == "f16x3" else "bf16"      # every split-padded buffer of the path carries the mode's split
-        assert all(b.fmt == fmt for bufs in hp.cv_regulator.down_blks[0].__dict__["_mvsgi_rs_bufs"].values() for b in bufs)
+        lvl0 = "f32p" if split == "f16x3" else fmt        # (the Winograd-form level 0 of the fp16 split passes fp32-padded records between its layers)
+        assert all(b.fmt == lvl0 for bufs in hp.cv_regulator.down_blks[0].__dict__["_mvsgi_rs_bufs"].values() for b in bufs)
         assert all(b.fmt == fmt for b in hp.cv_regulator.__dict__["_mvsgi_poly_bufs"].values())
         # the sweep -> post_vol front end in chunks of frames (bench.py's B=64 runs chunks of 16): same bits
         from mvs_gi_amd.dropin import cost_volume_builder as cvb_mod

@@ -35,8 +35,12 @@ y32 = H.conv3d_wino(xs, wpw, sc * unw, sh, res=rs, out_f32=True)
 torch.cuda.synchronize()
 print("fp32-output variant vs split output: max abs diff", float((y32 - H.act_from_split(yw)).abs().max()))
 ref_max = float(y_ref.abs().max())
-for name, ys in (("direct f16x3", yd), ("winograd f16x3", yw)):
-    y = H.act_from_split(ys)
+xp, rp = H.act_to_f32p(x), (H.act_to_f32p(r) if a.res else None)
+yp = H.SplitAct(B, d, h, w, 32, dev)
+H.conv3d_wino(xp, wpw, sc * unw, sh, res=rp, out=yp)
+torch.cuda.synchronize()
+for name, ys in (("direct f16x3", yd), ("winograd f16x3", yw), ("winograd f16x3, fp32-padded activations", yp)):
+    y = H.act_from_f32p(ys) if ys.fmt == "f32p" else H.act_from_split(ys)
     err = float((y - y_ref).abs().max()) / ref_max
     print(f"{name}: max rel error vs exact fp32 {err:.3e}  finite {bool(torch.isfinite(y).all())}")
     if err > 1e-4:
@@ -66,4 +70,5 @@ gf = 2 * 27 * 32 * 32 * B * d * h * w / 1e9
 for rep in range(3):
     t_d = timeit(lambda: H.conv3d_rs(xs, wpr, sc * unr, sh, res=rs, out=yd), a.iters)
     t_w = timeit(lambda: H.conv3d_wino(xs, wpw, sc * unw, sh, res=rs, out=yw), a.iters)
-    print(f"direct {t_d:8.1f} us ({gf / t_d * 1e3:6.1f} TF)   winograd {t_w:8.1f} us ({gf / t_w * 1e3:6.1f} TF direct-equivalent)   x{t_d / t_w:.2f}")
+    t_p = timeit(lambda: H.conv3d_wino(xp, wpw, sc * unw, sh, res=rp, out=yp), a.iters)
+    print(f"direct {t_d:8.1f} us ({gf / t_d * 1e3:6.1f} TF)   winograd {t_w:8.1f} us ({gf / t_w * 1e3:6.1f} TF direct-equivalent)   x{t_d / t_w:.2f}   fp32-padded {t_p:8.1f} us x{t_d / t_p:.2f}")
