@@ -2059,28 +2059,34 @@ def test_conv3d_rs_in_the_fp16_split_vs_oracle(shape, res, slope, out_f32):
 
 @pytest.mark.parametrize("shape", [(1, 8, 2, 32), (2, 8, 6, 64), (5, 8, 12, 32), (3, 8, 40, 160), (2, 16, 4, 32), (1, 16, 40, 160)])
 @pytest.mark.parametrize("res,slope,out_f32", [(True, 0.01, False), (False, 0.01, True), (True, 1.0, True), (False, 0.0, False)])
-def test_conv3d_winograd_in_the_fp16_split_vs_oracle(shape, res, slope, out_f32):
+@pytest.mark.parametrize("act32", [False, True])
+def test_conv3d_winograd_in_the_fp16_split_vs_oracle(shape, res, slope, out_f32, act32):
     """The Winograd F(2x2, 3x3) x direct-D form of the 32 -> 32 layers (csrc/conv3d_wino.hip; BaseConvBlk3d.forward,
     common_modules.py:107-115): transformed weights and activations in the fp16 split, 2.25 x fewer matrix instructions.  The same
     5e-6 bar as the direct kernel in this split, against float64 on what it multiplied; volumes of 8 and of 16 planes (the unit is
-    unrolled over either), units of several workgroups and of one (the stream's tail), every epilogue variant; the border of a
-    split-padded output stays zero."""
+    unrolled over either), units of several workgroups and of one (the stream's tail), every epilogue variant, activations as
+    split-padded fp16 pairs or fp32-padded (`act32`: the hand-over between Winograd layers); the border of a padded output stays zero."""
     B, d, h, w = shape
     rng = np.random.default_rng(sum(shape) + 18)
     x, r = _g(rng.standard_normal((B, d, h, w, 32), dtype=np.float32)), _g(rng.standard_normal((B, d, h, w, 32), dtype=np.float32))
     wt = (rng.standard_normal((32, 32, 3, 3, 3)) / np.sqrt(27 * 32)).astype(np.float32) * np.float32(0.02)
     sc, sh = _bn(rng, 32)
     assert H.conv3d_wino_applies(32, 32, d, h, w, 1, slope)
-    xs, rs = H.act_to_split(x, fmt="f16"), (H.act_to_split(r, fmt="f16") if res else None)
+    to_act, from_act, fmt = (H.act_to_f32p, H.act_from_f32p, "f32p") if act32 else (lambda t: H.act_to_split(t, fmt="f16"), H.act_from_split, "f16")
+    xs, rs = to_act(x), (to_act(r) if res else None)
     wp, un = H.pack_conv_weights_wino(_g(wt))
     y = H.conv3d_wino(xs, wp, _g(sc) * un, _g(sh), res=rs, neg_slope=slope, out_f32=out_f32)
-    assert out_f32 or y.fmt == "f16"
-    got = (y if out_f32 else H.act_from_split(y)).cpu().numpy()
-    ref = _conv_ref64(H.act_from_split(xs), wt, sc, sh, slope, res=H.act_from_split(rs) if res else None)
+    assert out_f32 or y.fmt == fmt
+    got = (y if out_f32 else from_act(y)).cpu().numpy()
+    ref = _conv_ref64(from_act(xs), wt, sc, sh, slope, res=from_act(rs) if res else None)
     assert _rel(got, ref) <= 5e-6
     if not out_f32:
         for sl in (y.buf[:, 0], y.buf[:, -1], y.buf[:, :, 0], y.buf[:, :, -1], y.buf[:, :, :, 0], y.buf[:, :, :, -1]):
             assert int(sl.abs().max()) == 0
+    if act32:
+        with pytest.raises(AssertionError, match="does not match the input"):      # a residual in the other activation format
+            H.conv3d_wino(xs, wp, _g(sc) * un, _g(sh), res=H.act_to_split(r, fmt="f16"))
+        return
         # the direct kernel in the same split on the same operands: the two forms agree far inside either one's error against the reference
         wpd, und = H.pack_conv_weights_rs(_g(wt), "f16")
         yd = H.act_from_split(H.conv3d_rs(xs, wpd, _g(sc) * und, _g(sh), res=rs, neg_slope=slope)).cpu().numpy()
@@ -2146,6 +2152,11 @@ def test_front_end_kernels_in_the_fp16_split_vs_oracle(shape):
     z = H.conv3d_s2rs(ys, wp2, _g(sh2) * up, H.SplitAct(B, do, ho, wo, 32, x.device), neg_slope=0.01, unscale=un2)
     assert z.fmt == "f16"
     assert _rel(H.act_from_split(z).cpu().numpy(), _conv_ref64(H.act_from_split(ys), w32, sc2, sh2, 0.01, stride=2)) <= 5e-6
+    # the fp32-padded output (for a Winograd-form level 0 behind it): the same values before the split, the border untouched
+    z32 = H.conv3d_s2rs(ys, wp2, _g(sh2) * up, H.SplitAct(B, do, ho, wo, 32, x.device), neg_slope=0.01, unscale=un2, out_f32p=True)
+    assert z32.fmt == "f32p" and torch.equal(H.act_to_split(H.act_from_f32p(z32), fmt="f16").buf, z.buf)
+    for sl in (z32.buf[:, 0], z32.buf[:, -1], z32.buf[:, :, 0], z32.buf[:, :, -1], z32.buf[:, :, :, 0], z32.buf[:, :, :, -1]):
+        assert int(sl.abs().max()) == 0
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 1, 1), (2, 2, 4, 16), (3, 5, 9, 33), (2, 8, 40, 160)])
