@@ -10,12 +10,15 @@
 //
 // Shape of the kernel.  A workgroup is 4 waves, one per SIMD; wave `a` owns row a of the 4 x 4 transform space: its 4 (b) x 3 (kd) x
 // 2 (cout tiles) x (hi, lo) weight fragments = 192 registers stay in the accumulator half of the register file for the whole launch.
-// A unit is 16 tiles in a row (2 output rows x 32 columns) marched through all D planes: per plane a lane (tile n, channel group kg)
-// reads the two patch rows its wave's `a` needs (B^T has two non-zeros per row), transforms 8 channels in registers straight into
-// the MFMA's B-operand layout (no LDS round trip for V), and issues 72 MFMAs: plane p adds U_kd V_p to the open output planes
+// A unit is 16 tiles in a row (2 output rows x 32 columns) marched through all D (8 or 16) planes: per plane a lane (tile n, channel
+// group kg) reads the two patch rows its wave's `a` needs (B^T has two non-zeros per row) from the plane's LDS image (every global read
+// is an LDS-DMA request, three planes ahead), transforms 8 channels in registers straight into the MFMA's B-operand layout (no LDS
+// round trip for V) piece by piece behind the MFMAs, and issues 72 MFMAs: plane p adds U_kd V_p to the open output planes
 // p + 1 - kd.  A finished output plane leaves through A^T: the (b) half inside the wave, the (a) half across the waves through a
 // 16 KiB LDS exchange, after which wave (pa, q) owns output voxel (2 r + pa, 2 n + q) of every tile: scale / shift, residual,
-// LeakyReLU, split, store.  Tensors are split-padded (conv3d_rs.hip): the zero border is the convolution's padding.
+// LeakyReLU, (split,) store.  Tensors are padded (conv3d_rs.hip's geometry: the zero border is the convolution's padding) and hold
+// either fp16 pairs (split-padded) or plain fp32 records ("fp32-padded": what the layers of a chain hand to each other).
+// DESIGN.md section 2, K2w, has the measurements and what it took to make hipcc emit it.
 #include "common.hpp"
 
 #include <cstring>
@@ -34,9 +37,9 @@ typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 #include "split_fmt.hpp"
 
 struct WinoArgs {
-    const unsigned char* x;    // split-padded fp16 [B][D+2][H+2][W+2][32]
-    unsigned char* y;          // the same geometry
-    const unsigned char* res;  // split-padded residual or nullptr
+    const unsigned char* x;    // padded [B][D+2][H+2][W+2][32 x 4 bytes]: fp16 pairs (split-padded) or plain fp32 (A32)
+    unsigned char* y;          // the same geometry and format, or a plain fp32 [B][D][H][W][32] tensor (OUT32)
+    const unsigned char* res;  // residual in x's format or nullptr
     const u32x4* wp;           // [a 4][b 4][kd 3][cout tile 2][hi | lo][64 lanes] 16-byte fragments
     const float* scale;        // (carries the inverse of the weights' pre-scaling)
     const float* shift;
