@@ -246,3 +246,21 @@ def test_power_of_two_prescale_of_the_fp16_split():
         assert not H.split_mode() and H.mode_fmt() == "bf16"
     finally:
         H.set_conv_mode(old)
+
+
+def test_winograd_dispatch_rule_follows_the_rounds_of_units():
+    """dropin/cost_volume_regulator.py::_wino_pays: a Winograd unit (2 rows x 32 columns, all planes) holds a CU for the whole
+    launch, so the form is dispatched when the launch's units fill at least 70 % of their rounds of one unit per CU -- on a
+    256-CU part and a [8, 40, 160] level 0 (100 units per frame): not at 1 or 3 frames, from 2 frames on otherwise."""
+    from mvs_gi_amd.dropin import cost_volume_regulator as cr
+    old = dict(cr._CUS)
+    try:
+        cr._CUS["fake"] = 256
+        got = {b: cr._wino_pays(b, 40, 160, "fake") for b in (1, 2, 3, 4, 5, 6, 8, 16, 64)}
+        assert got == {1: False, 2: True, 3: False, 4: True, 5: True, 6: True, 8: True, 16: True, 64: True}
+        cr._CUS["small"] = 64                       # a smaller part: one frame already fills it
+        assert cr._wino_pays(1, 40, 160, "small")
+    finally:
+        cr._CUS.clear()
+        cr._CUS.update(old)
+

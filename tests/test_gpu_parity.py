@@ -2127,6 +2127,12 @@ def test_conv3d_winograd_weights_range_and_misuse():
         H.conv3d_wino(H.act_to_split(torch.zeros((1, 8, 4, 32, 32), device=DEV)), wp1, un1, un1)
     with pytest.raises(AssertionError, match="wrong size"):
         H.conv3d_wino(xs, wp1[:-16], un1, un1)
+    # the stride-2 kernel's fp32-padded output exists in the fp16 split only
+    x16 = torch.zeros((1, 4, 4, 32, 16), device=DEV)
+    w16 = _g(np.zeros((32, 16, 3, 3, 3), np.float32))
+    wpb = H.pack_conv_weights_s2rs(w16, torch.ones(32, device=DEV))
+    with pytest.raises(RuntimeError, match="fp16 split only"):
+        H.conv3d_s2rs(H.act_to_split(x16), wpb, torch.zeros(32, device=DEV), H.SplitAct(1, 2, 2, 16, 32, DEV), out_f32p=True)
 
 
 @pytest.mark.parametrize("shape", [(1, 4, 4, 16), (2, 5, 7, 37), (3, 10, 30, 150)])
