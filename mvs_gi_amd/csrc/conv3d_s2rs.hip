@@ -274,6 +274,10 @@ __global__ __launch_bounds__(256, (TH == 4 && NBUF == 2) ? 1 : 2) void conv3d_s2
                 f32x4 v = acc[i] + (acc1[i] + acc2[i]);          // the small terms first
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = lrelu(F16 ? v[e] * a.unscale : v[e], a.neg_slope);
+                if constexpr (O32P) {       // the fp32-padded format's range: +-16376 (a Winograd layer sums four of these in front of its fp16 split)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -16376.f, 16376.f);
+                }
                 u32x4 o;
                 if constexpr (O32P) o = __builtin_bit_cast(u32x4, v);
                 else o = s2_pack_split<F16>(v);

@@ -109,6 +109,11 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, uns
 #define WN_MFA0(ACC, WREG, XREG) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG));
 #define WN_PAD() asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
 
+#ifndef WN_VCLAMP_A32
+#define WN_VCLAMP_A32 0     // (A/B builds: 1 = clamp the transform's sums on fp32-padded input too)
+#endif
+constexpr float kWinoActMax = 16376.f;     // fp32-padded activations are written clamped to this: the transform's sums of four stay inside fp16's range
+
 namespace wn {
 // LDS image of one input plane of a unit: 4 rows x 34 columns, even and odd columns apart, 9 sixteen-byte slots per voxel (its 8 pieces
 // [slice][hi | lo][channels 0-7 | 8-15] as they lie in the tensor + 1 pad): the 16 lanes of a ds_read_b128 group -- one piece of the
@@ -296,8 +301,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
             constexpr int b_ = (r_ - 8) >> 1;                                                               \
             constexpr int x_ = b_ == 0 ? 0 : (b_ == 2 ? 2 : 1), y_ = b_ == 0 ? 2 : (b_ == 1 ? 2 : (b_ == 2 ? 1 : 3)); \
             if constexpr (((r_ - 8) & 1) == 0) {                                                            \
-                X0 = sf_clamp<true>(b_ == 1 ? T[0][x_] + T[0][y_] : T[0][x_] - T[0][y_]);                   \
-                X1 = sf_clamp<true>(b_ == 1 ? T[1][x_] + T[1][y_] : T[1][x_] - T[1][y_]);                   \
+                X0 = b_ == 1 ? T[0][x_] + T[0][y_] : T[0][x_] - T[0][y_];                                   \
+                X1 = b_ == 1 ? T[1][x_] + T[1][y_] : T[1][x_] - T[1][y_];                                   \
+                if constexpr (!A32 || WN_VCLAMP_A32) {      /* (fp32-padded records arrive clamped to +-16376: their sums of four cannot leave fp16's range) */ \
+                    X0 = sf_clamp<true>(X0);                                                                \
+                    X1 = sf_clamp<true>(X1);                                                                \
+                }                                                                                           \
                 if constexpr (b_ > 0) vl[VN][b_ - 1][d_] = sf_cvt_pk<true>(L0, L1);     /* (the lo halves of the b before: not right behind the asm that made them) */ \
             } else {                                                                                        \
                 const unsigned h_ = sf_cvt_pk<true>(X0, X1);                                                \
@@ -364,7 +373,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
             t_[2] = mix_add_lo(rl_[c_][1], mix_add_lo(rh_[c_][1], t_[2]));                                  \
             t_[3] = mix_add_hi(rl_[c_][1], mix_add_hi(rh_[c_][1], t_[3]));                                  \
         }                                                                                                   \
-        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) t_[e_] = __builtin_fmaxf(t_[e_], t_[e_] * a.neg_slope); \
+        if constexpr (A32 && !OUT32) {      /* LeakyReLU + the fp32-padded format's range (the upper end rides in the med3) */ \
+            _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                                \
+                t_[e_] = __builtin_fmaxf(__builtin_amdgcn_fmed3f(t_[e_], t_[e_] * a.neg_slope, kWinoActMax), -kWinoActMax); \
+        } else {                                                                                            \
+            _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) t_[e_] = __builtin_fmaxf(t_[e_], t_[e_] * a.neg_slope); \
+        }                                                                                                   \
         if constexpr (OUT32) {                                                                              \
             *reinterpret_cast<f32x4*>(yb + (long long)(O) * oplane_bytes + lane_out32 + c_ * 64) = t_;      \
         } else if constexpr (A32) {                                                                         \

@@ -646,12 +646,15 @@ def pack_conv_weights_wino(w_oidhw: torch.Tensor):
     return wp, unscale
 
 
+F32P_MAX = 16376.0       # range of fp32-padded activations: a Winograd layer sums four of them in front of its fp16 split (65504 / 4)
+
+
 def act_to_f32p(x_ndhwc: torch.Tensor, out: Optional[SplitAct] = None) -> SplitAct:
     """fp32 NDHWC -> "fp32-padded": the split-padded geometry with plain fp32 records (tests / tools; torch copies)."""
     x = _dev(x_ndhwc, "x")
     B, D, Hh, W, C = x.shape
     y = out if out is not None else SplitAct(B, D, Hh, W, C, x.device)
-    y.buf.view(torch.float32)[:, 1:-1, 1:-1, 1:-1, :] = x
+    y.buf.view(torch.float32)[:, 1:-1, 1:-1, 1:-1, :] = x.clamp(-F32P_MAX, F32P_MAX)      # the format's range (its writers clamp to it)
     y.fmt = "f32p"
     return y
 

@@ -2127,6 +2127,14 @@ def test_conv3d_winograd_weights_range_and_misuse():
         H.conv3d_wino(H.act_to_split(torch.zeros((1, 8, 4, 32, 32), device=DEV)), wp1, un1, un1)
     with pytest.raises(AssertionError, match="wrong size"):
         H.conv3d_wino(xs, wp1[:-16], un1, un1)
+    # fp32-padded activations are written clamped to +-16376 (the transform then needs no clamp of its own): by the converter, by the
+    # stride-2 kernel, by the Winograd kernel's padded output
+    big = torch.full((1, 8, 2, 32, 32), 3.0e4, device=DEV)
+    xp = H.act_to_f32p(big)
+    assert float(H.act_from_f32p(xp).max()) == H.F32P_MAX
+    yp = H.conv3d_wino(xp, wp1, torch.ones(32, device=DEV) * un1 * 8.0, torch.zeros(32, device=DEV), neg_slope=0.01)
+    back = H.act_from_f32p(yp)
+    assert yp.fmt == "f32p" and bool(torch.isfinite(back).all()) and float(back.max()) == H.F32P_MAX
     # the stride-2 kernel's fp32-padded output exists in the fp16 split only
     x16 = torch.zeros((1, 4, 4, 32, 16), device=DEV)
     w16 = _g(np.zeros((32, 16, 3, 3, 3), np.float32))
