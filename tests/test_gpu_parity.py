@@ -1597,7 +1597,7 @@ def test_full_size_winograd_level0_vs_direct_kernel_and_reference_golden(golden_
     cfg, z = case["cfg"], _load(golden_dir, "full_G16V")
     inp = synth.make_inputs(cfg, seed=case["seed"], batch=1, grid_kind=case["grid_kind"], grid_mask_dtype=case["grid_mask_dtype"])
     assert synth.digest(inp) == str(z["inputs_sha256"]), "regenerated inputs differ from the golden run's (host libm)"
-    old, old_use, real = H.get_conv_mode(), cr._USE_WINO, H.conv3d_wino
+    old, old_use, old_a32, real = H.get_conv_mode(), cr._USE_WINO, cr._WINO_A32, H.conv3d_wino
     calls = []
 
     def spy(*a, **k):
@@ -1610,21 +1610,24 @@ def test_full_size_winograd_level0_vs_direct_kernel_and_reference_golden(golden_
         w = synth.make_weights(cfg, seed=case["seed"], gain=gain)
         feats = _g(inp["feats"]).expand(2, -1, -1, -1, -1).contiguous()
         outs = {}
-        for use in (True, False):
-            cr._USE_WINO = use
+        for use in (True, "pairs", False):          # fp32-padded activations between the layers (the default) | fp16 pairs | the direct kernel
+            cr._USE_WINO, cr._WINO_A32 = bool(use), use is True
             calls.clear()
-            outs[use] = HotPath(cfg, w, inp, device=DEV)(feats)[0].cpu().numpy()
+            hp = HotPath(cfg, w, inp, device=DEV)
+            outs[use] = hp(feats)[0].cpu().numpy()
             assert calls == ([False] * 5 + [True] if use else [])          # six launches, the last one hands fp32 to the next level
+            fmts = {b.fmt for bufs in hp.cv_regulator.down_blks[0].__dict__["_mvsgi_rs_bufs"].values() for b in bufs}
+            assert fmts == ({"f32p"} if use is True else {"f16"})
         ref = z[f"inv_dist_g{gain:g}"]
         for i in range(2):
             err = _rel(outs[True][i:i + 1], ref)
             parity_log.record("full_G16V(winograd level 0)", "f16x3", gain, err, _l1(outs[True][i:i + 1], ref), "golden")
-            assert err <= 1e-4 and _rel(outs[False][i:i + 1], ref) <= 1e-4
-        assert _rel(outs[True], outs[False]) <= 3e-5
+            assert err <= 1e-4 and _rel(outs[False][i:i + 1], ref) <= 1e-4 and _rel(outs["pairs"][i:i + 1], ref) <= 1e-4
+        assert _rel(outs[True], outs[False]) <= 3e-5 and _rel(outs["pairs"], outs[False]) <= 3e-5
     finally:
         H.conv3d_wino = real
         H.set_conv_mode(old)
-        cr._USE_WINO = old_use
+        cr._USE_WINO, cr._WINO_A32 = old_use, old_a32
 
 
 @pytest.mark.parametrize("split", ["bf16x3", "f16x3"])
