@@ -22,7 +22,8 @@
  *     mvsgi_last_error() returns a thread-local description of the last failure
  *     (the Python layer raises RuntimeError with it, mirroring the reference's
  *     assert/exception behaviour, e.g. backports.py:32).
- *   - no global mutable state: every call is re-entrant per stream, one process per GPU.
+ *   - no global mutable state but the range report's sticky words (mvsgi_saturation_flags):
+ *     every call is re-entrant per stream, one process per GPU.
  */
 #ifndef MVSGI_H
 #define MVSGI_H
@@ -34,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MVSGI_ABI_VERSION 1
+#define MVSGI_ABI_VERSION 2   /* 2: mvsgi_saturation_flags; the symbol set of round 5 (Winograd level, *_fmt entry points) */
 
 typedef void* mvsgi_stream_t;
 
@@ -67,6 +68,21 @@ typedef void* mvsgi_stream_t;
 
 int         mvsgi_abi_version(void);
 const char* mvsgi_last_error(void);
+
+/* ---- range report of the fp16 split ------------------------------------------------------
+ * The reference computes in fp32 with no clamp (dsta_mvs/model/common/common_modules.py:105-115,
+ * distance_regressor/distance_regressor.py:51-79); the "f16x3" arithmetic (MVSGI_CONV_F16 / MVSGI_SPLIT_F16) saturates
+ * what it writes or stages in fp16 pieces at +-65504, and the Winograd level's fp32-padded records at +-16376.  Every
+ * kernel that clamps reports a clamp that ENGAGED (a value at or beyond the bound) into sticky per-process words of pinned
+ * host memory; this call reads them (no stream operation, no copy: ask after synchronising the streams whose launches
+ * the question is about) and optionally clears them.  Results computed while a bit was raised are NOT the reference's:
+ * re-run in the bf16 split (fmt 0 / no MVSGI_CONV_F16: fp32's range) or in the exact fp32 mode.
+ *   flags  out, may be NULL: OR of the MVSGI_SAT_* bits raised since the last clear
+ */
+#define MVSGI_SAT_SWEEP 1u     /* the sweep's split-padded cost volume (the one un-normalised tensor of the path) reached +-65504 */
+#define MVSGI_SAT_SPLIT 2u     /* an activation written or staged in fp16 pieces by a conv layer reached +-65504                */
+#define MVSGI_SAT_WINO  4u     /* an activation of the Winograd level reached +-16376, or a transformed sum of four +-65504      */
+int mvsgi_saturation_flags(int clear, unsigned* flags);
 
 /* ---- K1: fused spherical sweep -------------------------------------------------------
  * Replaces SphericalSweepStdMasked.sweep (cost_volume_builder/spherical_sweep_avg.py:38-136)

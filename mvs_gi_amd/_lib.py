@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVSGI_LIB", os.path.join(_HERE, "libmvsgi_hip.so"))   # MVSGI_LIB: diagnostic builds
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class MvsgiLibraryMissing(RuntimeError):
@@ -25,6 +25,7 @@ _P = c_void_p
 SIGNATURES = {
     "mvsgi_abi_version": (c_int, []),
     "mvsgi_last_error": (c_char_p, []),
+    "mvsgi_saturation_flags": (c_int, [c_int, _P]),
     "mvsgi_sweep_std_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 10 + [_P]),
     "mvsgi_sweep_cat_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P]),
     "mvsgi_sweep_std_nhwc_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 10 + [_P]),
@@ -131,13 +132,27 @@ def load() -> ctypes.CDLL:
     # this library fails with "no ROCm-capable device is detected"
     import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
+    # the version first: a stale library (an old diagnostic build named by MVSGI_LIB, say) must fail with the rebuild hint, not
+    # with an AttributeError on the first symbol it lacks
+    try:
+        lib.mvsgi_abi_version.restype = c_int
+        lib.mvsgi_abi_version.argtypes = []
+        got = lib.mvsgi_abi_version()
+    except AttributeError as e:
+        raise MvsgiLibraryMissing(f"{LIB_PATH}: not a libmvsgi_hip ({e}); rebuild it (__graft_entry__.build())") from None
+    if got != ABI_VERSION:
+        raise MvsgiLibraryMissing(f"{LIB_PATH}: ABI version {got}, expected {ABI_VERSION}; rebuild it (__graft_entry__.build())")
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise MvsgiLibraryMissing(f"{LIB_PATH}: symbol {name} missing although the ABI version matches; rebuild it "
+                                      "(__graft_entry__.build())") from None
         fn.restype = res
         fn.argtypes = args
-    got = lib.mvsgi_abi_version()
-    if got != ABI_VERSION:
-        raise MvsgiLibraryMissing(f"{LIB_PATH}: ABI version {got}, expected {ABI_VERSION}; rebuild it")
+    # allocates the range report's pinned words now, so that no allocation falls into a stream capture (include/mvsgi.h).  Without a
+    # usable device (the CPU-only symbol test) this fails and is asked again by the first launch, which then fails loudly.
+    lib.mvsgi_saturation_flags(0, None)
     _lib = lib
     return lib
 

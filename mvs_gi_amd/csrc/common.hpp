@@ -35,6 +35,13 @@ inline int check_launch(const char* what) {
         if (!(cond)) return ::mvsgi::fail(__VA_ARGS__); \
     } while (0)
 
+// the range report's words (csrc/api.cpp; kinds in csrc/split_fmt.hpp): every launcher of a kernel that can clamp passes them on
+constexpr int kSatWords = 8;
+unsigned* sat_words();
+#define MVSGI_SAT_WORDS(VAR)                                                            \
+    unsigned* VAR = ::mvsgi::sat_words();                                               \
+    MVSGI_REQUIRE(VAR != nullptr, "cannot allocate the range report's pinned host words")
+
 inline hipStream_t as_stream(mvsgi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }

@@ -35,6 +35,8 @@
 #define MVSGI_ABL 0   // diagnostic builds: 1 no weight loads, 2 no LDS fragment reads, 4 no split, 8 no staging, 16 no MFMA
 #endif
 
+#include "split_fmt.hpp"      // the range report of the fp16 split (sf_sat_acc / sf_sat_report)
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -104,6 +106,16 @@ __device__ __forceinline__ void split_f16x4(const f32x4 x, u32x2& hi, u32x2& lo)
 template <bool F16>
 __device__ __forceinline__ void split_x4(const f32x4 x, u32x2& hi, u32x2& lo) {
     if constexpr (F16) split_f16x4(x, hi, lo); else split_bf16x4(x, hi, lo);
+}
+// the same, keeping the lane's running maximum |clamped value| for the range report of the fp16 split (csrc/split_fmt.hpp)
+template <bool F16>
+__device__ __forceinline__ void split_x4(const f32x4 x, u32x2& hi, u32x2& lo, float& satm) {
+    if constexpr (F16) {
+        const f32x4 c = {__builtin_amdgcn_fmed3f(x[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(x[1], -65504.f, 65504.f),
+                         __builtin_amdgcn_fmed3f(x[2], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(x[3], -65504.f, 65504.f)};
+        satm = sf_sat_acc(sf_sat_acc(satm, c[0], c[1]), c[2], c[3]);
+        split_f16x4(c, hi, lo);          // (its own clamp of the clamped values folds away)
+    } else split_bf16x4(x, hi, lo);
 }
 // one matrix instruction of the split product: operands travel as 16-byte fragments whatever their element type
 template <bool F16>
@@ -298,6 +310,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
     constexpr int WBYTES = WLDS ? NW * kPairs * 2048 : 0;      // the unit's weight slice in LDS, behind its activation image
     constexpr int BUFW = BUF + WBYTES;             // one buffer of the double-buffered LDS (image + weights)
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    float satm = 0.f;          // fp16 split: running maximum |value staged or written in fp16 pieces| (range report)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform
@@ -436,7 +449,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
                         _Pragma("unroll") for (int kw = 0; kw < 2; ++kw) {                              \
                             const bool ok = ((IM[IT] >> kd) & (IM[IT] >> (2 + kh)) & (IM[IT] >> (4 + kw)) & 1u) != 0; \
                             u32x2 hi, lo;                                                               \
-                            split_x4<F16>(xo[kh][kw], hi, lo);                                           \
+                            split_x4<F16>(xo[kh][kw], hi, lo, satm);                                           \
                             if (!ok) hi = lo = u32x2{0u, 0u};                                           \
                             const int vo_ = ((2 * cd + kd) * ITH + 2 * ch + kh) * ROWP + (2 * cw + kw) * kVSB; \
                             *reinterpret_cast<u32x2*>((DST) + vo_ + q * 8) = hi;                        \
@@ -463,7 +476,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
                             _Pragma("unroll") for (int kw = 0; kw < 2; ++kw) {                          \
                                 const bool ok = ((IM[IT] >> kd) & (IM[IT] >> (2 + kh)) & (IM[IT] >> (4 + kw)) & 1u) != 0; \
                                 u32x2 hi, lo;                                                           \
-                                split_x4<F16>(xo[kd][kh][kw], hi, lo);                                   \
+                                split_x4<F16>(xo[kd][kh][kw], hi, lo, satm);                                   \
                                 if (!ok) hi = lo = u32x2{0u, 0u};                                       \
                                 const int vo_ = ((2 * cd + kd) * ITH + 2 * ch + kh) * ROWP + (2 * cw + kw) * kVSB; \
                                 *reinterpret_cast<u32x2*>((DST) + vo_ + q * 8) = hi;                    \
@@ -609,7 +622,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
                     hi = u32x2{__builtin_bit_cast(unsigned, PRE[IT][0] + 0.f), __builtin_bit_cast(unsigned, PRE[IT][1] + 0.f)}; \
                     lo = u32x2{__builtin_bit_cast(unsigned, PRE[IT][2] + 0.f), __builtin_bit_cast(unsigned, PRE[IT][3] + 0.f)}; \
                 } else {                                                                                \
-                    split_x4<F16>(PRE[IT], hi, lo);                                                      \
+                    split_x4<F16>(PRE[IT], hi, lo, satm);                                                      \
                 }                                                                                       \
                 const int vo_ = V32 ? (v / ITW) * ROWP + (v % ITW) * kVSB : v * kVSB;                   \
                 *reinterpret_cast<u32x2*>((DST) + vo_ + q * 8) = hi;                                    \
@@ -1134,7 +1147,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
                         if (a.y_split) {
                             // split-padded output: slice (ct0 + j) of the voxel record, this lane's 4 couts = 8 B of hi and 8 B of lo
                             u32x2 hi, lo;
-                            split_x4<F16>(r, hi, lo);
+                            split_x4<F16>(r, hi, lo, satm);
                             if (eoff[i] >= 0 && ct0 + j < CT) {
                                 unsigned char* q = a.y_split + (long long)b_ * ((long long)(a.Do + 2 * ypd) * (a.Ho + 2 * ypp) * (a.Wo + 2 * ypp) * a.Cout * 4) +
                                                    soff[i] + (ct0 + j) * 64;
@@ -1166,6 +1179,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
     }
 #undef MVSGI_DECODE
 #undef STAMP
+    if constexpr (F16) sf_sat_report(a.sat, kSatSplit, satm, 65504.f);
 }
 
 // the two arithmetics of the body as two kernels (the names the profiler and mvsgi_conv3d_variant_f32 report)
@@ -1206,6 +1220,8 @@ int launch_bf16x3(ConvArgs a, hipStream_t st) {
     MVSGI_REQUIRE(!a.y_split || (!V32 && (long long)(a.Do + 2) * (a.Ho + 4) * (a.Wo + 4) * a.Cout * 4 < (1ll << 31)),
                   "conv3d: split-padded output not available for this kernel / size");
     a.total_units = (int)nb;
+    MVSGI_SAT_WORDS(sat_words_);
+    a.sat = sat_words_;
 #ifdef MVSGI_STAMPS
     {   // stamps of the PREVIOUS launch are printed when MVSGI_STAMP=2
         static unsigned long long* dbgbuf = nullptr;

@@ -59,10 +59,11 @@ typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 // ---------------------------------------------------------------------------------------------
 template <bool F16>
 __global__ void f32_to_split_kernel(const float* __restrict__ x, unsigned char* __restrict__ y, int B, int C, int D, int H,
-                                    int W) {
+                                    int W, unsigned* __restrict__ sat) {
     const long long n = (long long)B * D * H * W * (C / 8);
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n) return;
+    long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = idx < n;
+    if (!live) idx = n - 1;          // whole waves reach the range report (the store below is masked)
     const int g = (int)(idx % (C / 8));          // 8-channel group
     long long v = idx / (C / 8);
     const int w = (int)(v % W);
@@ -74,12 +75,16 @@ __global__ void f32_to_split_kernel(const float* __restrict__ x, unsigned char* 
     const float* src = x + ((((long long)b * D + d) * H + h) * W + w) * C + g * 8;
     const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
     u32x2 h0, l0, h1, l1;
-    sf_split4<F16>(a0, h0, l0);
-    sf_split4<F16>(a1, h1, l1);
+    float satm = 0.f;
+    sf_split4<F16>(a0, h0, l0, satm);
+    sf_split4<F16>(a1, h1, l1, satm);
     unsigned char* dst = y + ((((long long)b * (D + 2) + d + 1) * (H + 2) + h + 1) * (W + 2) + w + 1) * (C * 4) +
                          (g >> 1) * 64 + (g & 1) * 16;
-    *reinterpret_cast<u32x4*>(dst) = u32x4{h0[0], h0[1], h1[0], h1[1]};
-    *reinterpret_cast<u32x4*>(dst + 32) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+    if (live) {
+        *reinterpret_cast<u32x4*>(dst) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+        *reinterpret_cast<u32x4*>(dst + 32) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+    }
+    if constexpr (F16) sf_sat_report(sat, kSatSplit, satm, kF16Max);
 }
 
 template <bool F16>
@@ -122,6 +127,7 @@ struct RsArgs {
     // walkers per (XCD, role)
     long long wp_set;
     int walkers;
+    unsigned* sat;             // the range report's words (csrc/api.cpp): written when a clamp of the fp16 split engaged
 };
 
 __device__ __forceinline__ int rs_xcd_remap(int bid, int n) {
@@ -394,14 +400,15 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 #define RS_MF0(ACC, WREG, XREG)                                                                                        \
     if constexpr (F16) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }   \
     else { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }
-// the split's conversions inside the generated schedules (tools/gen_rs*_schedule.py); RS_LRELU_MAX is LeakyReLU's max and, in the
-// fp16 split on a split output, also the upper end of the range clamp (one v_med3_f32 instead of the v_max_f32)
+// the split's conversions inside the generated schedules (tools/gen_rs*_schedule.py); RS_LRELU_MAX is LeakyReLU's max, RS_CLAMP the
+// fp16 split's range clamp on a split output: one v_med3_f32 BEHIND the activation (round 5 folded the upper end into the
+// activation's max as med3(t, t * slope, 65504), which passes t unclamped when t * slope > 65504: every t > 65504 at slope 1)
 #define RS_W_LO(U) sf_widen_lo<F16>(U)
 #define RS_W_HI(U) sf_widen_hi<F16>(U)
 #define RS_CVT_PK(A, B) sf_cvt_pk<F16>(A, B)
 #define RS_F_F16(...) if constexpr (F16) { __VA_ARGS__ }
-#define RS_CLAMP_LO(T) __builtin_fmaxf(T, -kF16Max)
-#define RS_LRELU_MAX(T, U) ((F16 && !OUTF32) ? __builtin_amdgcn_fmed3f(T, U, kF16Max) : __builtin_fmaxf(T, U))
+#define RS_CLAMP(T) __builtin_amdgcn_fmed3f(T, -kF16Max, kF16Max)
+#define RS_LRELU_MAX(T, U) __builtin_fmaxf(T, U)
 
 // diagnostic builds only: MVSGI_RS_ABL bit 1 drops the fragment reads, 2 the epilogue, 4 the LDS-DMA (results are wrong)
 #ifndef MVSGI_RS_ABL
@@ -475,6 +482,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     u32x2 sa0, sb0, sa1, sb1, sa2, sb2, sa3, sb3, hb0, hb1, hb2, hb3, lb0, lb1, lb2, lb3;
     f32x2v hf0, hf1, hf2, hf3;
     float rh0, rl0, u0, rh1, rl1, u1, rh2, rl2, u2, rh3, rl3, u3;
+    float satm = 0.f;          // fp16 split, split output: running maximum |value written| (range report)
 #define t1 t1_
     // phases: ph = 0 .. n + 1.  Phase ph = [pair 13 of brick ph - 1, accumulators handed over] [pairs 0 .. 12 of brick ph]
     // with, between the MFMAs: the staging of brick ph + 1, the epilogue of brick ph - 2, the residual request of brick
@@ -513,6 +521,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
         // all but the 4 youngest vector-memory operations (the residual requests): the next image has landed
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         STAMP()
+        // (phases 0 and 1 ran the epilogue of bricks that do not exist -- on whatever the exchange scratch held; their stores are
+        // masked, their "values" must not reach the range report either: a select, not a branch)
+        if constexpr (F16 && !OUTF32) satm = ph < 2 ? 0.f : satm;
         __builtin_amdgcn_s_barrier();
     }
     for (; ph < n + 2; ++ph) {
@@ -521,8 +532,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
         STAMP()
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         STAMP()
+        if constexpr (F16 && !OUTF32) satm = ph < 2 ? 0.f : satm;
         __builtin_amdgcn_s_barrier();
     }
+    if constexpr (F16 && !OUTF32) sf_sat_report(a.sat, kSatSplit, satm, kF16Max);
 #undef RS_VOY
 #undef RS_VOC
 #undef RS_F_UP2
@@ -538,7 +551,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 #undef RS_W_HI
 #undef RS_CVT_PK
 #undef RS_F_F16
-#undef RS_CLAMP_LO
+#undef RS_CLAMP
 #undef RS_LRELU_MAX
 #undef RS_DMA
 #undef RS_DESC
@@ -561,6 +574,7 @@ struct Rs16Args {
     int B, D, H, W;
     float neg_slope;
     int tiles_d, tiles_h, tiles_w, total_units;
+    unsigned* sat;             // the range report's words (csrc/api.cpp)
 };
 
 namespace rs16 {
@@ -731,14 +745,15 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
 #define RS_MF0(ACC, WREG, XREG)                                                                                        \
     if constexpr (F16) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }   \
     else { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }
-// the split's conversions inside the generated schedules (tools/gen_rs*_schedule.py); RS_LRELU_MAX is LeakyReLU's max and, in the
-// fp16 split on a split output, also the upper end of the range clamp (one v_med3_f32 instead of the v_max_f32)
+// the split's conversions inside the generated schedules (tools/gen_rs*_schedule.py); RS_LRELU_MAX is LeakyReLU's max, RS_CLAMP the
+// fp16 split's range clamp on a split output: one v_med3_f32 BEHIND the activation (round 5 folded the upper end into the
+// activation's max as med3(t, t * slope, 65504), which passes t unclamped when t * slope > 65504: every t > 65504 at slope 1)
 #define RS_W_LO(U) sf_widen_lo<F16>(U)
 #define RS_W_HI(U) sf_widen_hi<F16>(U)
 #define RS_CVT_PK(A, B) sf_cvt_pk<F16>(A, B)
 #define RS_F_F16(...) if constexpr (F16) { __VA_ARGS__ }
-#define RS_CLAMP_LO(T) __builtin_fmaxf(T, -kF16Max)
-#define RS_LRELU_MAX(T, U) ((F16 && OSPLIT) ? __builtin_amdgcn_fmed3f(T, U, kF16Max) : __builtin_fmaxf(T, U))
+#define RS_CLAMP(T) __builtin_amdgcn_fmed3f(T, -kF16Max, kF16Max)
+#define RS_LRELU_MAX(T, U) __builtin_fmaxf(T, U)
 #define RS_PIN_V(V) asm volatile("" : "+v"(V));
 #define RS_F_STORE16(V, D, O) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, V), D, O, 0, MVSGI_RS16_NT);
 #define RS16_F_SPL(...) if constexpr (OSPLIT) { __VA_ARGS__ }
@@ -760,6 +775,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
     f32x4 acc[4], fin[4];
     bf16x8 xh[3][2], xl[3][2];
     float u0, u1, u2, u3;
+    float satm = 0.f;          // fp16 split, split output: running maximum |value written| (range report)
 #pragma unroll
     for (int o = 0; o < 4; ++o) acc[o] = fin[o] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -787,6 +803,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
 #include "conv3d_rs16_phase_drain.inc"
         }
     }
+    if constexpr (F16 && OSPLIT) sf_sat_report(a.sat, kSatSplit, satm, kF16Max);
 #undef RS16_STEP
 #undef RS16_DESC
 #undef RS16_DESC_OUT
@@ -798,7 +815,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
 #undef RS_W_HI
 #undef RS_CVT_PK
 #undef RS_F_F16
-#undef RS_CLAMP_LO
+#undef RS_CLAMP
 #undef RS_LRELU_MAX
 #undef RS_PIN_V
 #undef RS_F_STORE16
@@ -819,12 +836,13 @@ extern "C" int mvsgi_act_f32_to_split_fmt(const float* x, void* y, int B, int C,
     MVSGI_REQUIRE(fmt == 0 || fmt == MVSGI_SPLIT_F16, "mvsgi_act_f32_to_split: fmt %d not in {0, MVSGI_SPLIT_F16}", fmt);
     const long long n = (long long)B * D * H * W * (C / 8);
     MVSGI_REQUIRE(mvsgi::cdiv(n, 256) < (1ll << 31), "mvsgi_act_f32_to_split: tensor too large");
+    MVSGI_SAT_WORDS(sat);
     if (fmt)
         hipLaunchKernelGGL(f32_to_split_kernel<true>, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, mvsgi::as_stream(stream), x,
-                           static_cast<unsigned char*>(y), B, C, D, H, W);
+                           static_cast<unsigned char*>(y), B, C, D, H, W, sat);
     else
         hipLaunchKernelGGL(f32_to_split_kernel<false>, dim3((unsigned)mvsgi::cdiv(n, 256)), dim3(256), 0, mvsgi::as_stream(stream), x,
-                           static_cast<unsigned char*>(y), B, C, D, H, W);
+                           static_cast<unsigned char*>(y), B, C, D, H, W, sat);
     return mvsgi::check_launch("mvsgi_act_f32_to_split");
 }
 extern "C" int mvsgi_act_f32_to_split(const float* x, void* y, int B, int C, int D, int H, int W, mvsgi_stream_t stream) {
@@ -896,6 +914,8 @@ extern "C" int mvsgi_conv3d_rs_split_fmt(const void* x, const void* w_packed_rs,
     const long long nb = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
     MVSGI_REQUIRE(nb < (1ll << 31), "mvsgi_conv3d_rs_split: too many units");
     a.total_units = (int)nb;
+    MVSGI_SAT_WORDS(sat_words_);
+    a.sat = sat_words_;
 #ifdef MVSGI_RS_STAMPS
     {   // MVSGI_STAMP=1: record; =2: print the stamps of the previous launch
         static unsigned long long* dbgbuf = nullptr;
@@ -972,6 +992,8 @@ int rs32_up2_launch(const void* x_split, const void* w_sets, const float* scale3
     const long long per_role = (long long)B * a.tiles_h * a.tiles_w;
     MVSGI_REQUIRE(per_role < (1ll << 31), "mvsgi_conv3d_up2_poly_f32: too many units");
     a.total_units = (int)per_role;
+    MVSGI_SAT_WORDS(sat_words_);
+    a.sat = sat_words_;
     a.wp_set = (long long)(kRs32PackedBytes / 16);
     MVSGI_REQUIRE((long long)(2 * D + 2) * (2 * H + 2) * (2 * W + 2) * 64 < (1ll << 31), "mvsgi_conv3d_up2_poly: output frame too large for 32-bit offsets");
     static PersistentGeom geo_cache[4][kMaxDevices] = {};
@@ -1017,6 +1039,8 @@ int rs16_run(const void* x, const void* w_packed_rs, const float* scale, const f
     const long long nb = (long long)B * a.tiles_d * a.tiles_h * a.tiles_w;
     MVSGI_REQUIRE(nb < (1ll << 31), "mvsgi_conv3d_rs16_split: too many units");
     a.total_units = (int)nb;
+    MVSGI_SAT_WORDS(sat_words_);
+    a.sat = sat_words_;
     static mvsgi::PersistentGeom geo_cache[4][mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
     void (*kern)(Rs16Args) = fmt ? (y_is_split ? conv3d_rs16_kernel<true, true> : conv3d_rs16_kernel<false, true>)

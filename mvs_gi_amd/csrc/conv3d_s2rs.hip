@@ -60,10 +60,10 @@ __device__ __forceinline__ void s2_store16(const u32x4 v, const __amdgpu_buffer_
     __builtin_amdgcn_raw_buffer_store_b128(v, dsc, voff, soff, MVSGI_S2RS_ST_AUX);
 }
 template <bool F16>
-__device__ __forceinline__ u32x4 s2_pack_split(const f32x4 v) {
+__device__ __forceinline__ u32x4 s2_pack_split(const f32x4 v, float& satm) {
     // hi | lo of four channels; lanes kg and kg ^ 1 trade halves: kg even ends up with hi / lo of channels 8 (kg >> 1) .. + 7
     u32x2 hi, lo;
-    sf_split4<F16>(v, hi, lo);
+    sf_split4<F16>(v, hi, lo, satm);
     const u32x2 sa = __builtin_amdgcn_permlane16_swap(hi[0], lo[0], false, false);
     const u32x2 sb = __builtin_amdgcn_permlane16_swap(hi[1], lo[1], false, false);
     return u32x4{sa[0], sb[0], sa[1], sb[1]};
@@ -123,6 +123,7 @@ struct S2Args {
     float neg_slope;
     float unscale;             // fp16 split: the packed weights and `shift` carry a power of two 1 / unscale (so that the weights' lo parts
                                // are normal fp16 numbers); the accumulators are multiplied by it in front of the activation
+    unsigned* sat;             // the range report's words (csrc/api.cpp)
 };
 
 __device__ __forceinline__ int s2_xcd_remap(int bid, int n) {
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(256, (TH == 4 && NBUF == 2) ? 1 : 2) void conv3d_s2
     int b_, od, oh0, ow0;
     S2_DECODE(id0, b_, od, oh0, ow0)
     S2_STAGE(0, b_, od, oh0, ow0)
+    float satm = 0.f;          // fp16 split: running maximum |value written| (range report)
     for (int u = 0; u < nmine; ++u) {
         int nb, nod, noh, now;
         S2_DECODE(id0 + (u + 1 < nmine ? u + 1 : u) * idstep, nb, nod, noh, now)
@@ -277,15 +279,17 @@ __global__ __launch_bounds__(256, (TH == 4 && NBUF == 2) ? 1 : 2) void conv3d_s2
                 if constexpr (O32P) {       // the fp32-padded format's range: +-16376 (a Winograd layer sums four of these in front of its fp16 split)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], -16376.f, 16376.f);
+                    satm = sf_sat_acc(sf_sat_acc(satm, v[0], v[1]), v[2], v[3]);
                 }
                 u32x4 o;
                 if constexpr (O32P) o = __builtin_bit_cast(u32x4, v);
-                else o = s2_pack_split<F16>(v);
+                else o = s2_pack_split<F16>(v, satm);
                 if (okc && oh0 + t0 + i < a.Ho) s2_store16(o, dsc_, vst, i * Wop * 128);
             }
         }
         b_ = nb; od = nod; oh0 = noh; ow0 = now;
     }
+    if constexpr (F16) sf_sat_report(a.sat, O32P ? kSatWino : kSatSplit, satm, O32P ? 16376.f : kF16Max);
 #undef S2_DECODE
 #undef S2_STAGE
 }
@@ -300,6 +304,8 @@ int s2_launch(S2Args a, hipStream_t st) {
     const long long nb = (long long)a.B * a.Do * a.tiles_h * a.tiles_w;
     MVSGI_REQUIRE(nb < (1ll << 31), "mvsgi_conv3d_s2rs: too many bricks");
     a.total_units = (int)nb;
+    MVSGI_SAT_WORDS(sat_words_);
+    a.sat = sat_words_;
     static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
     if (mvsgi::persistent_geometry(conv3d_s2rs_kernel<TH, NBUF, F16, O32P>, 256, lds_bytes, wgs, geo_cache, "mvsgi_conv3d_s2rs", geo)) return 1;

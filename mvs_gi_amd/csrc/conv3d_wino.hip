@@ -47,6 +47,7 @@ struct WinoArgs {
     float neg_slope;
     int tiles_h, groups_w, total_units;
     unsigned long long* dbg;   // -DMVSGI_WINO_STAMPS builds (ABL = 16): per wave of workgroup 0, cycles per step section
+    unsigned* sat;             // the range report's words (csrc/api.cpp)
 };
 
 // fp32 <- f16 half of a dword through the mixed-precision fma (one instruction where widen + add are two or three)
@@ -91,9 +92,10 @@ __device__ __forceinline__ float mix_sub_hi(float c, unsigned h) {
     return r;
 }
 // (lo-half value, hi-half value) -> the split's packed hi and lo dwords (clamped to fp16's range first)
-__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, unsigned& lo) {
+__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, unsigned& lo, float& satm) {
     v0 = sf_clamp<true>(v0);
     v1 = sf_clamp<true>(v1);
+    satm = sf_sat_acc(satm, v0, v1);         // range report (csrc/split_fmt.hpp)
     hi = sf_cvt_pk<true>(v0, v1);
     lo = sf_cvt_pk<true>(mix_sub_lo(v0, hi), mix_sub_hi(v1, hi));
 }
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
                 if constexpr (!A32 || WN_VCLAMP_A32) {      /* (fp32-padded records arrive clamped to +-16376: their sums of four cannot leave fp16's range) */ \
                     X0 = sf_clamp<true>(X0);                                                                \
                     X1 = sf_clamp<true>(X1);                                                                \
+                    satm = sf_sat_acc(satm, X0, X1);        /* range report: a sum of four left fp16's range */ \
                 }                                                                                           \
                 if constexpr (b_ > 0) vl[VN][b_ - 1][d_] = sf_cvt_pk<true>(L0, L1);     /* (the lo halves of the b before: not right behind the asm that made them) */ \
             } else {                                                                                        \
@@ -381,9 +384,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
             t_[2] = mix_add_lo(rl_[c_][1], mix_add_lo(rh_[c_][1], t_[2]));                                  \
             t_[3] = mix_add_hi(rl_[c_][1], mix_add_hi(rh_[c_][1], t_[3]));                                  \
         }                                                                                                   \
-        if constexpr (A32 && !OUT32) {      /* LeakyReLU + the fp32-padded format's range (the upper end rides in the med3) */ \
+        if constexpr (A32 && !OUT32) {      /* LeakyReLU, THEN the fp32-padded format's range (clamping inside the activation's med3 let \
+                                               t * neg_slope > 16376 through: any t > 16376 at slope 1, t > 1.6e6 at 0.01) + the range report */ \
             _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                                \
-                t_[e_] = __builtin_fmaxf(__builtin_amdgcn_fmed3f(t_[e_], t_[e_] * a.neg_slope, kWinoActMax), -kWinoActMax); \
+                t_[e_] = __builtin_amdgcn_fmed3f(__builtin_fmaxf(t_[e_], t_[e_] * a.neg_slope), -kWinoActMax, kWinoActMax); \
+            satm = sf_sat_acc(sf_sat_acc(satm, t_[0], t_[1]), t_[2], t_[3]);                                \
         } else {                                                                                            \
             _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) t_[e_] = __builtin_fmaxf(t_[e_], t_[e_] * a.neg_slope); \
         }                                                                                                   \
@@ -393,8 +398,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
             *reinterpret_cast<f32x4*>(yb + (long long)((O) + 1) * plane_bytes + lane_out32 + c_ * 64) = t_; \
         } else {                                                                                            \
             unsigned h0_, l0_, h1_, l1_;                                                                    \
-            split_pair(t_[0], t_[1], h0_, l0_);                                                             \
-            split_pair(t_[2], t_[3], h1_, l1_);                                                             \
+            split_pair(t_[0], t_[1], h0_, l0_, satm);                                                       \
+            split_pair(t_[2], t_[3], h1_, l1_, satm);                                                       \
             unsigned char* q_ = yb + (long long)((O) + 1) * plane_bytes + lane_out + c_ * 64;               \
             *reinterpret_cast<u32x2*>(q_) = u32x2{h0_, h1_};                                                \
             *reinterpret_cast<u32x2*>(q_ + 32) = u32x2{l0_, l1_};                                           \
@@ -484,6 +489,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     if constexpr (ABL & 16) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
     int ri = 0, rprev = 0;                             // residual image to request into / requested a step ago
+    float satm = 0.f;                                  // running maximum |clamped value| (range report, csrc/split_fmt.hpp)
     auto dsc = WN_DESC(ubase, true);
     auto dsc_next = dsc;
     // the first three planes of the stream; V of the first; raw of the second
@@ -521,6 +527,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino32_kernel(WinoArgs a) {
         WN_FINISH((DEPTH - 1) % 3)
         dsc = dsc_next;
     }
+    // fp32-padded records are clamped to +-16376 where they are written; on fp16 pairs the transform's sums and the output to +-65504
+    if constexpr (!(A32 && OUT32)) sf_sat_report(a.sat, kSatWino, satm, A32 ? kWinoActMax : kF16Max);
     if constexpr (ABL & 16) {
         if (blockIdx.x == 0 && lane == 0 && a.dbg)
             for (int k = 0; k < 8; ++k) a.dbg[wv * 8 + k] = tsum[k];
@@ -635,6 +643,8 @@ int mvsgi_conv3d_wino32_f16(const void* x_split, const void* w_packed, const flo
     const long long units = (long long)B * a.tiles_h * a.groups_w;
     MVSGI_REQUIRE(units < (1ll << 31), "mvsgi_conv3d_wino32_f16: too many units");
     a.total_units = (int)units;
+    MVSGI_SAT_WORDS(sat_words_);
+    a.sat = sat_words_;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #ifdef MVSGI_WINO_STAMPS      // diagnostic build: cycles per step section of workgroup 0 (tools/wino_probe.py)
     if (getenv("MVSGI_WINO_STAMP")) {

@@ -20,6 +20,7 @@ struct ConvArgs {
     unsigned long long* dbg;   // MVSGI_STAMPS diagnostic build only
     int f16;                   // split kernels: the fp16 split (hi = fp16(x), lo = fp16(x - hi), v_mfma_*_f16) instead of the bf16 split; host-side selector
     int ys_2d;                 // y_split is the 2-D format of resblock2d_rs.hip: no border along D (= images), two pixels along H and W
+    unsigned* sat;             // split kernels, fp16 split: the range report's words (csrc/api.cpp), set by the launcher
 };
 
 constexpr int kVS = 20;           // LDS floats per staged voxel: 16 channels + 4 pad

@@ -43,12 +43,43 @@ __device__ __forceinline__ float sf_clamp(const float x) {
     if constexpr (F16) return __builtin_amdgcn_fmed3f(x, -kF16Max, kF16Max);
     else return x;
 }
+// ---- range report (include/mvsgi.h: mvsgi_saturation_flags) ----
+// The fp16 split has a range the reference's fp32 does not (common_modules.py:105-115 computes in fp32, no clamp): every writer
+// of fp16 pieces clamps to +-65504, the writers of the Winograd level's fp32-padded records to +-16376.  A clamp that ENGAGES is
+// reported: each lane keeps the running maximum |value| it wrote (one v_max3_f32 per two elements, on the clamped values -- a
+// value that reached the bound was clamped or sat exactly on it) and a wave that saw the bound stores 1 into the library's word
+// of that kind -- pinned host memory (csrc/api.cpp), a plain store by one lane, no atomic, nothing on the normal path but the
+// compare.  The words are sticky until the host clears them.
+constexpr int kSatSweep = 0;       // the sweep's cost volume (the one un-normalised tensor of the path) left +-65504
+constexpr int kSatSplit = 1;       // an activation a conv layer wrote or staged in fp16 pieces left +-65504
+constexpr int kSatWino = 2;        // an activation of the Winograd level left +-16376 (or a transformed sum of four +-65504)
+__device__ __forceinline__ float sf_sat_acc(const float m, const float a, const float b) {
+    return __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(a)), __builtin_fabsf(b));       // v_max3_f32 m, |a|, |b|
+}
+__device__ __forceinline__ void sf_sat_report(unsigned* __restrict__ words, const int kind, const float m, const float bound) {
+    if (__builtin_amdgcn_ballot_w64(m >= bound) != 0) {        // wave-uniform; never taken inside the range
+        if ((threadIdx.x & 63) == 0) __builtin_nontemporal_store(1u, words + kind);
+    }
+}
+
 // x = hi + lo for four fp32 values (clamped first in the fp16 split)
 template <bool F16>
 __device__ __forceinline__ void sf_split4(const sf_f32x4 x, sf_u32x2& hi, sf_u32x2& lo) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const float a = sf_clamp<F16>(x[2 * p]), b = sf_clamp<F16>(x[2 * p + 1]);
+        const unsigned hb = sf_cvt_pk<F16>(a, b);
+        hi[p] = hb;
+        lo[p] = sf_cvt_pk<F16>(a - sf_widen_lo<F16>(hb), b - sf_widen_hi<F16>(hb));
+    }
+}
+// the same, keeping the lane's running maximum |clamped value| for the range report (fp16 split only)
+template <bool F16>
+__device__ __forceinline__ void sf_split4(const sf_f32x4 x, sf_u32x2& hi, sf_u32x2& lo, float& sat) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float a = sf_clamp<F16>(x[2 * p]), b = sf_clamp<F16>(x[2 * p + 1]);
+        if constexpr (F16) sat = sf_sat_acc(sat, a, b);
         const unsigned hb = sf_cvt_pk<F16>(a, b);
         hi[p] = hb;
         lo[p] = sf_cvt_pk<F16>(a - sf_widen_lo<F16>(hb), b - sf_widen_hi<F16>(hb));

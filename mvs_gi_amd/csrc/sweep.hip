@@ -438,9 +438,11 @@ __global__ __launch_bounds__(256, MVSGI_SWEEP_WAVES) void sweep_std_nhwc_v_kerne
                                                                const float* __restrict__ grids,
                                                                const unsigned char* __restrict__ vmask,
                                                                float* __restrict__ vol, SweepDims s, int dchunk,
-                                                               int nd, int rig_shared, unsigned char* __restrict__ vol_split) {
+                                                               int nd, int rig_shared, unsigned char* __restrict__ vol_split,
+                                                               unsigned* __restrict__ sat) {
 #pragma clang fp contract(off)
     static_assert(NCAM <= 4, "one camera per lane of a quad");
+    float satm = 0.f;          // fp16 split output: running maximum |value written| (range report, csrc/split_fmt.hpp)
     const int q = threadIdx.x & 3;
     const int WT = (s.Wo + 63) >> 6;
     int L = sweep_xcd_remap((int)blockIdx.x, (int)gridDim.x);
@@ -610,6 +612,7 @@ __global__ __launch_bounds__(256, MVSGI_SWEEP_WAVES) void sweep_std_nhwc_v_kerne
                 for (int p = 0; p < 2; ++p) {
                     if constexpr (F16) {
                         const float a_ = sf_clamp<true>(r[2 * p]), b_ = sf_clamp<true>(r[2 * p + 1]);
+                        satm = sf_sat_acc(satm, a_, b_);
                         const unsigned hb = sf_cvt_pk<true>(a_, b_);
                         hi[p] = hb;
                         lo[p] = sf_cvt_pk<true>(a_ - sf_widen_lo<true>(hb), b_ - sf_widen_hi<true>(hb));
@@ -663,6 +666,7 @@ __global__ __launch_bounds__(256, MVSGI_SWEEP_WAVES) void sweep_std_nhwc_v_kerne
         out += 2 * vstep;
         if (outs) outs += 2 * sstep;
     }
+    if constexpr (F16) sf_sat_report(sat, kSatSweep, satm, kF16Max);
 }
 
 // grid = ceil(Wo / 64) * N * D * Ho * B blocks (flat), logical order (b, ho, d, cam, w-tile)
@@ -849,28 +853,29 @@ int sweep_std_nhwc_valid_impl(const float* feats, const float* grids, const unsi
     MVSGI_REQUIRE((long long)Hi * Wi * C < (1ll << 29) && (long long)Wi * C * 4 < (1ll << 23) && nblk < (1ll << 31),
                   "mvsgi_sweep_std_nhwc_valid_f32: dimensions exceed the launch geometry (image bytes < 2^31, row bytes < 2^23)");
     hipStream_t st = mvsgi::as_stream(stream);
+    MVSGI_SAT_WORDS(sat);
     const dim3 grid((unsigned)nblk), block(256);
     if (fmt) {      // split-padded output in the fp16 split (C == 16 checked above)
         switch (N) {
-            case 1: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1, true, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split); break;
-            case 2: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<2, true, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split); break;
-            case 3: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<3, true, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split); break;
-            case 4: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<4, true, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split); break;
+            case 1: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1, true, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split, sat); break;
+            case 2: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<2, true, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split, sat); break;
+            case 3: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<3, true, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split, sat); break;
+            case 4: hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<4, true, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split, sat); break;
         }
         return mvsgi::check_launch("mvsgi_sweep_std_nhwc_valid_split");
     }
     switch (N) {
-        case 1: if (C == 16) hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
-                else hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1, false>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
+        case 1: if (C == 16) hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split, sat);
+                else hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<1, false>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split, sat);
                 break;
-        case 2: if (C == 16) hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<2, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
-                else hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<2, false>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
+        case 2: if (C == 16) hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<2, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split, sat);
+                else hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<2, false>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split, sat);
                 break;
-        case 3: if (C == 16) hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<3, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
-                else hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<3, false>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
+        case 3: if (C == 16) hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<3, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split, sat);
+                else hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<3, false>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split, sat);
                 break;
-        case 4: if (C == 16) hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<4, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
-                else hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<4, false>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split);
+        case 4: if (C == 16) hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<4, true>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split, sat);
+                else hipLaunchKernelGGL((sweep_std_nhwc_v_kernel<4, false>), grid, block, 0, st, feats, grids, vmask, vol, s, dchunk, (int)nd, rig_shared, vol_split, sat);
                 break;
     }
     return mvsgi::check_launch("mvsgi_sweep_std_nhwc_valid_f32");

@@ -270,6 +270,7 @@ def _owned_head_buffer(self, B, D, Hh, W, C, device):
 
 
 def regulator_forward(self, x: Tensor) -> Tensor:
+    H.check_range("cv_regulator: an earlier call")      # the fp16 split's range report (hip_ops.check_range; frames already completed)
     return cm._to_ncdhw_view(regulator_forward_ndhwc(self, H.as_ndhwc(x)))
 
 

@@ -1,7 +1,9 @@
 """Composition of the four stages, mirroring dsta_mvs/model/mvs_model/torch_only.py:4-36.
-The feature extractor is whatever nn.Module the caller supplies (PyTorch-ROCm; SURVEY.md
-§8(f) rank 1 -- outside the HIP path for now)."""
+The feature extractor is whatever nn.Module the caller supplies: this package's HIP extractors
+(dropin/feature_extractor.py) or the reference's own PyTorch module."""
 from torch import nn, Tensor
+
+from .. import hip_ops as H
 
 
 class SphericalSweepStereoBase(nn.Module):
@@ -30,7 +32,10 @@ def build_and_regulate(cv_builder: nn.Module, cv_regulator: nn.Module, feats: Te
     """costs = cv_regulator(cv_builder(...)) (torch_only.py:32-33).  When both modules are this package's and agree on it
     (builder.forward_split / regulator.takes_split), the cost volume crosses the module boundary as a module-owned split-padded
     buffer instead of an fp32 tensor: the regulator's stride-2 first layer then stages it by LDS-DMA (csrc/conv3d_s2rs.hip).
-    Each module's own forward() keeps the reference's tensor interface."""
+    Each module's own forward() keeps the reference's tensor interface.
+    On entry the fp16 split's range report is applied to the frames submitted BEFORE this one (hip_ops.check_range: the path is
+    asynchronous; a caller that synchronises can ask about the current frame with hip_ops.check_range(sync_device=...))."""
+    H.check_range("cv_builder -> cv_regulator: an earlier frame")
     fs, takes = getattr(cv_builder, "forward_split", None), getattr(cv_regulator, "takes_split", None)
     if fs is not None and takes is not None and feats.dim() == 5 and grids.dim() == 6 and \
             takes((feats.shape[0], grids.shape[2], grids.shape[3], grids.shape[4], 16)):

@@ -60,6 +60,76 @@ def get_conv_mode() -> str:
     return _CONV_MODE
 
 
+# ---- range report of the fp16 split (include/mvsgi.h: mvsgi_saturation_flags) ----
+# The reference computes in fp32 with no clamp (common_modules.py:105-115); the default arithmetic saturates what it writes or stages
+# in fp16 pieces.  Every kernel that clamps raises a sticky flag when a clamp ENGAGED; the wrappers below read it -- a load from
+# pinned host memory, no stream operation -- and turn it into an exception (MVSGI_RANGE_CHECK=raise, the default), a warning (=warn,
+# once per kind) or nothing (=off).  A flag says something about launches that have COMPLETED: the path's calls are asynchronous, so
+# the entry checks of HotPath / the drop-in modules report the frames before the current one; HotPath.check_range() and
+# InferencePipeline (which synchronise) report the frame itself.
+SAT_SWEEP, SAT_SPLIT, SAT_WINO = 1, 2, 4
+_SAT_TEXT = {SAT_SWEEP: "the sweep's cost volume reached +-65504 (un-normalised features?)",
+             SAT_SPLIT: "an activation written or staged in fp16 pieces reached +-65504",
+             SAT_WINO: "an activation of the Winograd-form level reached its +-16376 range (or a transformed sum +-65504)"}
+RANGE_CHECKS = ("raise", "warn", "off")
+_RANGE_CHECK = os.environ.get("MVSGI_RANGE_CHECK", "raise")
+if _RANGE_CHECK not in RANGE_CHECKS:
+    raise ValueError(f"MVSGI_RANGE_CHECK={_RANGE_CHECK!r} not in {RANGE_CHECKS}")
+_RANGE_WARNED = set()
+
+
+class MvsgiRangeError(RuntimeError):
+    """The fp16 split left its range: results since the last check are saturated, not the reference's."""
+
+
+def set_range_check(policy: str) -> None:
+    global _RANGE_CHECK
+    if policy not in RANGE_CHECKS:
+        raise ValueError(f"range check policy {policy!r} not in {RANGE_CHECKS}")
+    _RANGE_CHECK = policy
+
+
+def get_range_check() -> str:
+    return _RANGE_CHECK
+
+
+def saturation_flags(clear: bool = False) -> int:
+    """OR of the SAT_* bits raised by completed launches since the last clear (sticky; no synchronisation)."""
+    import ctypes
+    out = ctypes.c_uint(0)
+    if _lib.load().mvsgi_saturation_flags(1 if clear else 0, ctypes.byref(out)) != 0:
+        # the pinned words could not be allocated (no usable device): then no kernel has run either -- every launcher of a kernel
+        # that can clamp refuses to launch without them -- and there is nothing to report
+        return 0
+    return int(out.value)
+
+
+def check_range(where: str = "", sync_device=None) -> int:
+    """Apply the MVSGI_RANGE_CHECK policy to the flags raised so far (after synchronising `sync_device`, if given) and clear them.
+    -> the flags that were raised."""
+    if _RANGE_CHECK == "off":
+        return 0
+    if sync_device is not None:
+        torch.cuda.synchronize(sync_device)
+    f = saturation_flags(clear=False)
+    if not f:
+        return 0
+    saturation_flags(clear=True)
+    what = "; ".join(t for b, t in _SAT_TEXT.items() if f & b)
+    msg = (f"mvs_gi_amd{' (' + where + ')' if where else ''}: the fp16 split (MVSGI_CONV_MODE=f16x3, the default) left its range -- {what}. "
+           "Results computed since the last check are saturated, not the reference's fp32 results "
+           "(dsta_mvs/model/common/common_modules.py:105-115 has no clamp). Re-run with MVSGI_CONV_MODE=bf16x3 "
+           "(hip_ops.set_conv_mode('bf16x3'): fp32's range, ~8x the rounding error) or 'f32'; HotPath.precision_check(frames) measures "
+           "which arithmetic a checkpoint needs. MVSGI_RANGE_CHECK=warn|off relaxes this check.")
+    if _RANGE_CHECK == "raise":
+        raise MvsgiRangeError(msg)
+    if f not in _RANGE_WARNED:
+        _RANGE_WARNED.add(f)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=2)
+    return f
+
+
 def split_mode() -> bool:
     """The library's mode is one of the two 16-bit splits (the streaming split kernels serve the layer)."""
     return _CONV_MODE in ("bf16x3", "f16x3")

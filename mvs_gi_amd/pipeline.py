@@ -12,6 +12,7 @@ import torch
 
 from .configs import PathConfig
 from . import dropin
+from . import hip_ops as H
 from .dropin.torch_only import build_and_regulate
 
 
@@ -44,8 +45,16 @@ class HotPath:
         self.grid_masks = torch.from_numpy(consts["grid_masks"]).to(self.device)
         self.masks = torch.from_numpy(consts["masks"]).to(self.device)
 
+    def check_range(self, sync: bool = True) -> int:
+        """The range report of the fp16 split for the frames submitted so far: synchronises the device (sync=True), then raises
+        hip_ops.MvsgiRangeError / warns per MVSGI_RANGE_CHECK when a clamp of the default arithmetic engaged (the reference is fp32
+        and has none, common_modules.py:105-115).  __call__ / replay run the same check WITHOUT synchronising on entry: they report
+        the frames before the current one."""
+        return H.check_range("HotPath", self.device if sync else None)
+
     @torch.no_grad()
     def __call__(self, feats: torch.Tensor):
+        H.check_range("HotPath: an earlier frame")
         B = feats.shape[0]
         g, gm, m = self.grids, self.grid_masks, self.masks
         if g.shape[0] != B:          # rig constants are per-frame identical
@@ -83,6 +92,7 @@ class HotPath:
         (inv_dist, norm_costs), valid until the next replay."""
         if getattr(self, "_graph", None) is None:
             raise RuntimeError("HotPath.replay() before capture()")
+        H.check_range("HotPath: an earlier frame")
         if feats is not None and feats.data_ptr() != self._static_in.data_ptr():
             if tuple(feats.shape) != tuple(self._static_in.shape) or feats.dtype != self._static_in.dtype:
                 raise ValueError(f"HotPath.replay(): the graph was captured for feats {tuple(self._static_in.shape)} "
@@ -105,31 +115,53 @@ class HotPath:
         split on a sharp softmax (the error of either split grows with the sharpness of the checkpoint's softmax over the candidates,
         which only the trained weights know), the bf16 split when activations leave fp16's range (+-65504; +-16376 at the
         Winograd-form level-0 convs) or live far below 1e-3 -- else "f32".  The measurement a deployer makes once per checkpoint.
-        -> {"bf16x3_vs_f16x3": e, "bar": bar, "recommended": mode [, "bf16x3_vs_f32": e, "f16x3_vs_f32": e, "note": ...]}"""
-        from . import hip_ops as H
-        old = H.get_conv_mode()
-        outs = {}
+        The fp16 split's range report (hip_ops.saturation_flags) is read after its run: a clamp that engaged sends the question to
+        the exact mode too and excludes the fp16 split; a non-finite output of either split does the same for that split.
+        -> {"bf16x3_vs_f16x3": e, "bar": bar, "recommended": mode, "f16x3_saturated": flags, "finite": {...}
+            [, "bf16x3_vs_f32": e, "f16x3_vs_f32": e, "note": ...]}"""
+        old, old_policy = H.get_conv_mode(), H.get_range_check()
+        outs, finite = {}, {}
         try:
+            H.set_range_check("off")             # the flags are read by hand below
+            torch.cuda.synchronize(self.device)
+            H.saturation_flags(clear=True)
             for mode in ("bf16x3", "f16x3"):
                 H.set_conv_mode(mode)
                 outs[mode] = self(feats)[0].clone()
-            den = float(outs["f16x3"].abs().max()) or 1.0
-            e_b = float((outs["bf16x3"] - outs["f16x3"]).abs().max()) / den
-            res = {"bf16x3_vs_f16x3": e_b, "bar": bar, "recommended": "f16x3"}
-            if e_b > bar:
+                finite[mode] = bool(torch.isfinite(outs[mode]).all())
+            torch.cuda.synchronize(self.device)
+            sat = H.saturation_flags(clear=True)          # raised by the f16x3 run only: the bf16 split has no range to leave
+            den = float(outs["f16x3"].abs().max()) if finite["f16x3"] else float("nan")
+            if not np.isfinite(den) or den == 0.0:
+                den = float(outs["bf16x3"].abs().max()) if finite["bf16x3"] else 1.0
+                den = den if np.isfinite(den) and den > 0.0 else 1.0
+            e_b = float((outs["bf16x3"] - outs["f16x3"]).abs().max()) / den if finite["bf16x3"] and finite["f16x3"] else float("inf")
+            res = {"bf16x3_vs_f16x3": e_b, "bar": bar, "recommended": "f16x3", "f16x3_saturated": sat,
+                   "finite": dict(finite)}
+            # the exact mode arbitrates when the splits disagree, when either is not finite (an fp32 overflow poisons the bf16
+            # split too) and when the fp16 split's clamps engaged
+            if not (e_b <= bar) or sat:
                 H.set_conv_mode("f32")
                 exact = self(feats)[0]
-                e = {m: float((outs[m] - exact).abs().max()) / den for m in ("bf16x3", "f16x3")}
+                ok_exact = bool(torch.isfinite(exact).all())
+                den = float(exact.abs().max()) if ok_exact else den
+                den = den if np.isfinite(den) and den > 0.0 else 1.0
+                e = {m: (float((outs[m] - exact).abs().max()) / den if finite[m] and ok_exact else float("inf")) for m in ("bf16x3", "f16x3")}
+                if sat:
+                    e["f16x3"] = float("inf")          # a clamped result is excluded whatever its distance
                 res["bf16x3_vs_f32"], res["f16x3_vs_f32"] = e["bf16x3"], e["f16x3"]
                 best = min(e, key=e.get)
                 res["recommended"] = best if e[best] <= bar else "f32"
-                if e[best] > bar:
+                if sat:
+                    res["note"] = ("the fp16 split saturated on these frames (flags %d): its result is clamped" % sat)
+                elif e[best] > bar:
                     # two fp32-accumulating arithmetics of 22+ bits that differ by more than the bar: past this sharpness the
                     # reference's own summation order is one answer among several (DESIGN.md: ~0.993 mean max-probability on G16V)
                     res["note"] = "the bar is ill-conditioned for this checkpoint: fp32 summation orders differ by more"
             return res
         finally:
             H.set_conv_mode(old)
+            H.set_range_check(old_policy)
 
 
 class StreamedHotPath:
@@ -184,6 +216,7 @@ class StreamedHotPath:
     def replay(self, feats: Optional[torch.Tensor] = None):
         if getattr(self, "_graph", None) is None:
             raise RuntimeError("StreamedHotPath.replay() before capture()")
+        H.check_range("StreamedHotPath: an earlier step")
         if feats is not None and feats.data_ptr() != self._static_in.data_ptr():
             if tuple(feats.shape) != tuple(self._static_in.shape) or feats.dtype != self._static_in.dtype:
                 raise ValueError(f"StreamedHotPath.replay(): captured for feats {tuple(self._static_in.shape)}, got {tuple(feats.shape)}")
@@ -226,8 +259,11 @@ class InferencePipeline:
         if g is not None and tuple(t.shape) == tuple(self._static_imgs.shape):
             self._static_imgs.copy_(t, non_blocking=True)          # the upload lands in the graph's input buffer
             g.replay()
-            return self._static_inv.squeeze(0).squeeze(0).cpu().numpy()
-        return self.forward_device(t.to(self.hot.device)).squeeze(0).squeeze(0).cpu().numpy()
+            out = self._static_inv.squeeze(0).squeeze(0).cpu().numpy()
+        else:
+            out = self.forward_device(t.to(self.hot.device)).squeeze(0).squeeze(0).cpu().numpy()
+        H.check_range("InferencePipeline: this frame")       # the download synchronised: the report covers the frame just computed
+        return out
 
     @torch.no_grad()
     def forward_device(self, imgs_u8: torch.Tensor) -> torch.Tensor:

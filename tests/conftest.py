@@ -41,9 +41,9 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         return
     tr = terminalreporter
     tr.write_sep("=", "inverse-distance parity (bar: max_rel <= 1e-3)")
-    tr.write_line(f"{'case':44s} {'mode':7s} {'gain':>7s} {'max_rel':>10s} {'mean_l1_rel':>12s}  ref")
-    for case, mode, gain, mx, l1, ref in parity_log.ROWS:
-        tr.write_line(f"{case:44s} {mode:7s} {gain:7.2f} {mx:10.3e} {l1:12.3e}  ref={ref}")
+    tr.write_line(f"{'case':44s} {'mode':7s} {'gain':>7s} {'max_rel':>10s} {'max_pixel_rel':>13s} {'mean_l1_rel':>12s}  ref")
+    for case, mode, gain, mx, l1, ref, px in parity_log.ROWS:
+        tr.write_line(f"{case:44s} {mode:7s} {gain:7.2f} {mx:10.3e} {px:13.3e} {l1:12.3e}  ref={ref}")
     # the gain ladders climb past the point where the softmax is an arg-max: measured rows, asserted only up to the documented
     # operating rule (tests/test_gpu_parity.py LADDER_BAR) -- summarised apart from the rows that carry the 1e-3 bar
     rows = [r for r in parity_log.ROWS if "(ladder" not in r[0]]
@@ -52,6 +52,10 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         worst = max(r[3] for r in rows)
         n_or = sum(1 for r in rows if r[5] != "golden")
         tr.write_line(f"worst max_rel {worst:.3e} over {len(rows)} rows; {n_or} row(s) not against reference goldens")
+        for mode in sorted({r[1] for r in rows}):
+            px = [r[6] for r in rows if r[1] == mode and r[6] == r[6]]
+            if px:
+                tr.write_line(f"worst per-pixel relative error [{mode}]: {max(px):.3e} over {len(px)} rows (max over pixels of |d| / |ref|)")
     for mode in sorted({r[1] for r in lad}):
         m = [r for r in lad if r[1] == mode]
         inside = sum(1 for r in m if r[3] <= 1e-3)

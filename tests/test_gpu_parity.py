@@ -25,17 +25,31 @@ DEV = "cuda:0"
 @pytest.fixture(autouse=True)
 def _exact_mode_unless_parametrized():
     """Tests that are not parametrized over `conv_mode` hold the exact-fp32 tolerances; the library default
-    (bf16x3) is checked by test_default_conv_mode_is_bf16x3 and the `conv_mode` cases."""
+    (f16x3) is checked by tests/test_dropin_host.py::test_default_conv_mode_is_the_fp16_split and the `conv_mode` cases.  The fp16 split's sticky range report
+    (hip_ops.saturation_flags) starts every test cleared: the tests that saturate on purpose must not fail the next HotPath call."""
     old = H.get_conv_mode()
     H.set_conv_mode("f32")
+    torch.cuda.synchronize()
+    H.saturation_flags(clear=True)
     yield
     H.set_conv_mode(old)
+    torch.cuda.synchronize()
+    H.saturation_flags(clear=True)
 
 
 def _rel(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _pix(a, b):
+    """max over pixels of |a - b| / |b|: the per-pixel relative error of an inverse-distance map (inv_dist >= 0.96 by construction --
+    a convex combination of bf / dist candidates -- so the division is well defined).  _rel() divides by the MAP's maximum (192):
+    1e-3 of that is 0.19 absolute = 20 % of a far pixel; this is the figure a depth consumer sees (distance = bf / inv_dist)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float((np.abs(a - b) / np.maximum(np.abs(b), 1e-30)).max())
 
 
 def _ncdhw(y_ndhwc):
@@ -519,7 +533,7 @@ def test_small_cases_vs_reference_goldens(golden_dir, name, conv_mode):
         import parity_log
         parity_log.record(name, conv_mode, gain, err,
                           float(np.abs(inv.cpu().numpy() - z[f"inv_dist_g{gain:g}"]).mean() / np.abs(z[f"inv_dist_g{gain:g}"]).mean()),
-                          "golden")
+                          "golden", _pix(inv.cpu().numpy(), z[f"inv_dist_g{gain:g}"]))
         print(f"{name} [{conv_mode}] gain {gain}: inv_dist max-rel {err:.3e}")
         assert err <= 1e-3, (gain, err)          # the north-star bar
         if conv_mode == "f32":
@@ -602,8 +616,9 @@ def test_full_size_vs_reference_goldens(golden_dir, name, conv_mode):
         ref = z[f"inv_dist_g{gain:g}"]
         got = inv.cpu().numpy()
         err, l1 = _rel(got, ref), _l1(got, ref)
-        parity_log.record(name, conv_mode, gain, err, l1, "golden")
-        print(f"{name} [{conv_mode}] gain {gain}: max-rel {err:.3e} mean-L1-rel {l1:.3e} (ref=golden)")
+        px = _pix(got, ref)
+        parity_log.record(name, conv_mode, gain, err, l1, "golden", px)
+        print(f"{name} [{conv_mode}] gain {gain}: max-rel {err:.3e} per-pixel max-rel {px:.3e} mean-L1-rel {l1:.3e} (ref=golden)")
         assert err <= 1e-3, (gain, err)
         del hp
     torch.cuda.empty_cache()
@@ -630,7 +645,7 @@ def test_full_size_vs_oracle(name, conv_mode):
     hp = HotPath(cfg, w, inp, device=DEV)
     got = hp(feats)[0].cpu().numpy()
     err, l1 = _rel(got, ref), _l1(got, ref)
-    parity_log.record(name, conv_mode, gain, err, l1, "oracle")
+    parity_log.record(name, conv_mode, gain, err, l1, "oracle", _pix(got, ref))
     assert err <= 1e-3, (gain, err)
     del hp
     torch.cuda.empty_cache()
@@ -669,7 +684,7 @@ def test_full_size_at_bench_batch_streamed_vs_reference_golden(golden_dir, name,
         for fr in (0, n - 1):
             assert (fr - 3) % 8 != 0
             err = _rel(got[fr:fr + 1], ref)
-            parity_log.record(f"{name}(2x{part} streamed)[{fr}]", split, gain, err, _l1(got[fr:fr + 1], ref), "golden")
+            parity_log.record(f"{name}(2x{part} streamed)[{fr}]", split, gain, err, _l1(got[fr:fr + 1], ref), "golden", _pix(got[fr:fr + 1], ref))
             print(f"{name} 2x{part} streamed [{split}] frame {fr} gain {gain}: max-rel {err:.3e} (ref=golden)")
             assert err <= (1e-3 if split == "bf16x3" else 2e-4), (fr, err)      # the fp16 split: 5x inside the bar on these rows
         assert np.array_equal(got[0], got[n - 1]) and np.array_equal(got[3], got[n - 5]) and not np.array_equal(got[3], got[0])
@@ -701,7 +716,7 @@ def test_full_size_gain_ladder_vs_reference_goldens(golden_dir, name, conv_mode)
         got = hp(feats)[0].cpu().numpy()
         ref = z[f"inv_dist_g{gain:g}"]
         err, l1 = _rel(got, ref), _l1(got, ref)
-        parity_log.record(f"{name}(ladder, max-prob {mp:.3f})", conv_mode, float(gain), err, l1, "golden")
+        parity_log.record(f"{name}(ladder, max-prob {mp:.3f})", conv_mode, float(gain), err, l1, "golden", _pix(got, ref))
         print(f"{name} [{conv_mode}] ladder gain {gain:g} (mean max-prob {mp:.4f}): max-rel {err:.3e}")
         if mp <= LADDER_BAR[conv_mode]:
             assert err <= 1e-3, (float(gain), float(mp), err)
@@ -773,9 +788,11 @@ def test_unpickled_reference_modules_run_on_hip(golden_dir):
 
 # ------------------------------------------------------------------------------ properties
 def test_full_size_properties_batch_and_determinism():
-    """Size-independent properties at BASELINE.json's G16V size: a batch of 2 equals two
-    single-frame runs bit for bit (frames are independent -> frame sharding is exact), and
-    the path is deterministic run to run."""
+    """Size-independent properties at BASELINE.json's G16V size, in the EXACT-fp32 mode (this file's autouse fixture): a batch
+    of 2 equals two single-frame runs bit for bit (frames are independent), and the path is deterministic run to run.  In the
+    default fp16 split the level-0 convs' form follows the batch (Winograd / direct) and a frame's bits with it: there the
+    statement is a tolerance, tests/test_gpu_range.py::test_default_mode_frame_depends_on_its_launch_only_within_the_arithmetic;
+    what frame sharding relies on -- the same launch geometry gives the same bits on every rank -- is tests/test_bench_sharding.py's."""
     from mvs_gi_amd.configs import CONFIGS
     cfg = CONFIGS["G16V"]
     inp = synth.make_inputs(cfg, seed=3, batch=1)

@@ -180,8 +180,11 @@ def build(with_pairs, split=False):
         for e in range(4):
             items.append((1, f"u{op} = fin[{op}][{e}] * a.neg_slope;"))
             items.append((1, f"fin[{op}][{e}] = RS_LRELU_MAX(fin[{op}][{e}], u{op});"))
-            if split:      # fp16 split only (cost 0: the bf16 schedule keeps its placement): the lower end of the range clamp
-                items.append((0, f"RS16_F_SPL(RS_F_F16(fin[{op}][{e}] = RS_CLAMP_LO(fin[{op}][{e}]);))"))
+            if split:      # fp16 split only (cost 0: the bf16 schedule keeps its placement): the range clamp, BEHIND the activation (inside its max a slope of 1 -- or t * slope > 65504 -- passed unclamped)
+                items.append((0, f"RS16_F_SPL(RS_F_F16(fin[{op}][{e}] = RS_CLAMP(fin[{op}][{e}]);))"))
+        # fp16 split only: the lane's running maximum |clamped value| for the range report (one v_max3_f32 per two elements; csrc/split_fmt.hpp)
+        for p in range(2 if split else 0):
+            items.append((1, f"RS16_F_SPL(RS_F_F16(satm = sf_sat_acc(satm, fin[{op}][{2 * p}], fin[{op}][{2 * p + 1}]);))"))
         # split-padded output (the stride-2 kernel behind post_vol stages pre-split voxels by LDS-DMA): hi | lo, lanes kg and
         # kg ^ 1 trade halves so that a lane stores 16 contiguous bytes of the voxel record
         for p in range(2 if split else 0):

@@ -93,8 +93,11 @@ def epilogue_items(k):
     for e in range(4):
         s.append((1, f"u{k} = t{k}[{e}] * a.neg_slope;"))
         s.append((1, f"t{k}[{e}] = RS_LRELU_MAX(t{k}[{e}], u{k});"))
-        # fp16 split only (cost 0: the bf16 schedule keeps its placement): the lower end of the range clamp (RS_LRELU_MAX holds the upper)
-        s.append((0, f"RS_F_SPL(RS_F_F16(t{k}[{e}] = RS_CLAMP_LO(t{k}[{e}]);))"))
+        # fp16 split only (cost 0: the bf16 schedule keeps its placement): the range clamp, BEHIND the activation (inside its max a slope of 1 -- or t * slope > 65504 -- passed unclamped)
+        s.append((0, f"RS_F_SPL(RS_F_F16(t{k}[{e}] = RS_CLAMP(t{k}[{e}]);))"))
+    # fp16 split only: the lane's running maximum |clamped value| for the range report (one v_max3_f32 per two elements; csrc/split_fmt.hpp)
+    for p in range(2):
+        s.append((1, f"RS_F_SPL(RS_F_F16(satm = sf_sat_acc(satm, t{k}[{2 * p}], t{k}[{2 * p + 1}]);))"))
     for p in range(2):
         s.append((1, f"RS_F_SPL(hb{k}[{p}] = RS_CVT_PK(t{k}[{2 * p}], t{k}[{2 * p + 1}]);)"))
         s.append((1, f"RS_F_SPL(hf{k}[0] = RS_W_LO(hb{k}[{p}]);)"))
