@@ -38,4 +38,8 @@ FULL_CASES = {
                     gains=(4.0, 1.0)),
     "full_4cam-32": dict(cfg=CONFIGS["4cam-32"], seed=0, batch=1, grid_kind="smooth", grid_mask_dtype="bool",
                          gains=(0.05, 0.2)),
+    # the literal reading of BASELINE.json's configs[2] ("in48ch/fint96ch" at D = 16: sweep_hp_config104.yaml:12-13, SURVEY 8's
+    # "E16-class" row): the concat builder on 16 candidates with the (48, 96) regulator
+    "full_E16-48-96": dict(cfg=CONFIGS["E16-48-96"], seed=0, batch=1, grid_kind="smooth", grid_mask_dtype="bool",
+                           gains=(0.25, 1.0)),
 }

@@ -652,7 +652,7 @@ def test_full_size_vs_oracle(name, conv_mode):
 
 
 # (case, frames per part): bench.py's EXTRA_CONFIGS -- the batch at which each configuration is measured
-BENCH_PARTS = [("full_G16VV", 32), ("full_E8", 64), ("full_4cam-32", 16)]
+BENCH_PARTS = [("full_G16VV", 32), ("full_E8", 64), ("full_4cam-32", 16), ("full_E16-48-96", 32)]
 
 
 @pytest.mark.parametrize("split", ["bf16x3", "f16x3"])
@@ -884,7 +884,8 @@ def test_cold_compile_and_load_on_this_box(tmp_path):
     subprocess.run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", so] + objs, check=True, timeout=600)
     lib = ctypes.CDLL(so)
     lib.mvsgi_abi_version.restype = ctypes.c_int
-    assert lib.mvsgi_abi_version() == 1
+    from mvs_gi_amd import _lib
+    assert lib.mvsgi_abi_version() == _lib.ABI_VERSION
     x = torch.arange(2 * 3 * 5, dtype=torch.float32, device=DEV).reshape(2, 3, 5)          # [B, C, V]
     y = torch.empty((2, 5, 3), dtype=torch.float32, device=DEV)
     lib.mvsgi_ncv_to_nvc_f32.restype = ctypes.c_int

@@ -75,9 +75,10 @@ def test_regressor_variants(golden_dir):
     assert _rel(inv.numpy(), z["inv_updated"]) <= 1e-6
 
 
-@pytest.mark.parametrize("name", ["full_G16V", "full_E8"])
+@pytest.mark.parametrize("name", ["full_G16V", "full_E8", "full_E16-48-96"])
 def test_full_size_matches_reference(golden_dir, name):
-    """BASELINE.json configs[1] (G16V) and configs[0] (E8) at full size: inv_dist only."""
+    """BASELINE.json configs[1] (G16V), configs[0] (E8) and the literal reading of configs[2] ("in48ch/fint96ch" at D = 16) at
+    full size: inv_dist only."""
     from golden_cases import FULL_CASES
     case = FULL_CASES[name]
     cfg = case["cfg"]

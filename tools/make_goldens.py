@@ -283,6 +283,10 @@ def extractor_cases():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["small", "full", "edges", "extractor"]
+    only = [a.split(":", 1)[1] for a in which if a.startswith("case:")]         # `full ladder case:<name>`: that case alone
+    if only:
+        SMALL_CASES = {k: v for k, v in SMALL_CASES.items() if k in only}
+        FULL_CASES = {k: v for k, v in FULL_CASES.items() if k in only}
     if "extractor" in which:
         extractor_cases()
     if "edges" in which:
