@@ -417,8 +417,15 @@ int mvsgi_conv3d_s2rs_fmt(const void* x_split, const void* w_packed, const float
 int mvsgi_conv3d_s2rs_out_fmt(const void* x_split, const void* w_packed, const float* shift, void* y_split, int B, int D, int H, int W,
                               float neg_slope, float unscale, int fmt, int y_f32p, mvsgi_stream_t stream);
 int mvsgi_conv3d_up2_poly_plan_fmt(const float* w_oidhw_host, void* plan_host, int D, int H, int W, int fmt);
+/* y_is_split: 0 = fp32 [B][2D][2H][2W][16]; 1 = split-padded [B][2D+2][2H+2][2W+2][16], main kernel by the dispatcher: with
+ * MVSGI_SPLIT_F16, D == 8, H even, W a multiple of 32 and enough frames to fill the chip (mvsgi_conv3d_up2_poly_wino_pays) the
+ * Winograd form (csrc/conv3d_wino_up2.hip: polyphase over (H, W) x Winograd F(2x2, 3x3) x an explicit upsample along D, 2.25 x fewer
+ * matrix instructions; the same ResizeConv3d.forward, common_modules.py:332-355), else the direct register-stationary kernel;
+ * 3 = split-padded, the direct kernel whatever the dispatcher would choose; 5 = split-padded, the Winograd form (rejected where it
+ * does not apply) */
 int mvsgi_conv3d_up2_poly_fmt(const void* x_split, const void* plan_dev, const float* scale, const float* shift, void* y,
                               int y_is_split, int B, int D, int H, int W, float neg_slope, int fmt, mvsgi_stream_t stream);
+int mvsgi_conv3d_up2_poly_wino_pays(int B, int D, int H, int W);      /* 1: y_is_split = 1 in the fp16 split runs the Winograd form */
 
 /* ---- Winograd F(2x2, 3x3) x direct-D form of the 32 -> 32 convolutions (csrc/conv3d_wino.hip) -------------------------
  * BaseConvBlk3d.forward (dsta_mvs/model/common/common_modules.py:107-115) for Cin = Cout = 32, stride 1, on split-padded

@@ -112,6 +112,7 @@ SIGNATURES = {
     "mvsgi_conv3d_wino32_pack_weights": (c_int, [_P] * 4),
     "mvsgi_conv3d_wino32_f16": (c_int, [_P] * 6 + [c_int] * 6 + [c_float, _P]),
     "mvsgi_conv3d_up2_poly_fmt": (c_int, [_P] * 5 + [c_int] * 5 + [c_float, c_int, _P]),
+    "mvsgi_conv3d_up2_poly_wino_pays": (c_int, [c_int] * 4),
     "mvsgi_ncv_to_nvc_f32": (c_int, [_P, _P, c_int, c_int, c_longlong, _P]),
     "mvsgi_nvc_to_ncv_f32": (c_int, [_P, _P, c_int, c_int, c_longlong, _P]),
 }

@@ -107,4 +107,11 @@ void rs32_pack_weights_host(const float* w_oidhw_32x32x27, void* packed, bool f1
 int rs32_up2_launch(const void* x_split, const void* w_sets, const float* scale32, const float* shift32, void* y, int y_is_split,
                     int B, int D, int H, int W, float neg_slope, bool f16, hipStream_t st);
 
+// csrc/conv3d_wino_up2.hip: the polyphase ResizeConv3d's main kernel in Winograd form (fp16 split, split-padded output)
+constexpr size_t kWinoUp2RoleBytes = (size_t)4 * 4 * 3 * 2 * 2 * 64 * 16;      // one row phase's weights in the kernel's lane order
+void wino_up2_pack_role(const float* w32_oidhw, unsigned short* wp, float* unscale32);
+bool wino_up2_applies(int D, int H, int W);
+int wino_up2_launch(const void* x_split, const void* w_roles, const float* unw, const float* scale16, const float* shift16, void* y_split,
+                    int B, int D, int H, int W, float neg_slope, hipStream_t st);
+
 }  // namespace mvsgi

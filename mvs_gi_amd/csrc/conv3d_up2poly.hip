@@ -126,7 +126,9 @@ struct PolyHeader {
     int sum_tpf;        // 16-cell tiles per frame over all face roles
     int pad0;
     long long off_roles_split;      // the same roles addressing a SPLIT-PADDED output [B][2D+2][2H+2][2W+2][64 B]
-    int pad[8];
+    long long off_wino;             // fp16 plans where csrc/conv3d_wino_up2.hip applies: its two row-phase weight sets, else 0
+    long long off_wino_unscale;     // ... and their [ph 2][pw 2][16] inverse pre-scaling
+    int pad[4];
 };
 static_assert(sizeof(PolyHeader) == 128, "header");
 
@@ -153,6 +155,12 @@ PolyHeader layout(int D, int H, int W) {
     o += (size_t)ng * h.n_edge_cells * 8 * kEdgeSetFloats * 4;
     h.off_edgecells = (long long)(o = align256(o));
     o += (size_t)h.n_edge_cells * 4 * 4;
+    if (mvsgi::wino_up2_applies(D, H, W)) {      // (room in every plan of such a geometry: the layout does not depend on the split)
+        h.off_wino = (long long)(o = align256(o));
+        o += 2 * mvsgi::kWinoUp2RoleBytes;
+        h.off_wino_unscale = (long long)(o = align256(o));
+        o += 2 * 32 * 4;
+    }
     h.total = (long long)align256(o);
     int tpf = 0, sum = 0;
     for (const Group& g : groups_of(D)) {
@@ -354,6 +362,20 @@ extern "C" int mvsgi_conv3d_up2_poly_plan_fmt(const float* w_oidhw_host, void* p
                 }
                 mvsgi::rs32_pack_weights_host(w32.data(), P + h.off_main + (size_t)((pd * 4 + cls) * 2 + ph) * mvsgi::kRs32PackedBytes, f16);
             }
+    // ---- the main kernel in Winograd form (csrc/conv3d_wino_up2.hip; fp16 split): per row phase ph the 32 -> 32 layer
+    //      [pw * 16 + co] with interior matrices along H and W and the ORIGINAL depth taps (the kernel upsamples along D itself) ----
+    if (f16 && h.off_wino) {
+        M3 ident{};
+        for (int t = 0; t < 3; ++t) ident.m[t][t] = 1.0;
+        for (int ph = 0; ph < 2; ++ph) {
+            for (int pw = 0; pw < 2; ++pw) {
+                fold(ident, class_matrix(ph, INT), class_matrix(pw, INT), w, f0.data());
+                memcpy(w32.data() + (size_t)pw * 16 * 32 * 27, f0.data(), f0.size() * 4);
+            }
+            mvsgi::wino_up2_pack_role(w32.data(), reinterpret_cast<unsigned short*>(P + h.off_wino + (size_t)ph * mvsgi::kWinoUp2RoleBytes),
+                                      reinterpret_cast<float*>(P + h.off_wino_unscale) + ph * 32);
+        }
+    }
     // ---- face roles ----
     const int Hp = H + 2, Wp = W + 2, Hh = 2 * H, Wh = 2 * W;
     const std::vector<Group> gs = groups_of(D);
@@ -454,8 +476,9 @@ namespace {
 // edges (writes), faces (the H-face roles accumulate on the edge cells), then the register-stationary main kernel; ob = 1: the
 // output is a split-padded tensor [B][2D+2][2H+2][2W+2][64 B] (the corrections use its voxel records as fp32 until the main
 // kernel overwrites them with the split result)
+// form: 0 = the dispatcher's choice of main kernel, 1 = the direct register-stationary kernel always, 2 = the Winograd form always (A/B, tests)
 int poly_launch(const void* x_split, const void* plan_dev, const float* scale, const float* shift, void* y, int ob, int B, int D, int H,
-                int W, float neg_slope, int fmt, hipStream_t st) {
+                int W, float neg_slope, int fmt, hipStream_t st, int form = 0) {
     MVSGI_REQUIRE(x_split && plan_dev && scale && shift && y, "mvsgi_conv3d_up2_poly: null pointer");
     MVSGI_REQUIRE(fmt == 0 || fmt == MVSGI_SPLIT_F16, "mvsgi_conv3d_up2_poly: fmt %d not in {0, MVSGI_SPLIT_F16}", fmt);
     MVSGI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "mvsgi_conv3d_up2_poly: bad dims");
@@ -517,6 +540,23 @@ int poly_launch(const void* x_split, const void* plan_dev, const float* scale, c
                            static_cast<const unsigned char*>(x_split), P, static_cast<unsigned char*>(y), B, x_frame, y_frame, h.off_facew,
                            ob ? h.off_roles_split : h.off_roles, fg);
     if (mvsgi::check_launch("mvsgi_conv3d_up2_poly(faces)")) return 1;
+    // the main kernel: in the fp16 split with a split-padded output, the Winograd form (2.25 x fewer matrix instructions) where it
+    // applies and its units fill their rounds of one unit per CU (a unit occupies a CU for ~25 us)
+    MVSGI_REQUIRE(form != 2 || (fmt && ob && h.off_wino), "mvsgi_conv3d_up2_poly: the Winograd form needs the fp16 split, a split-padded output, "
+                  "D == 8, H %% 2 == 0 and W %% 32 == 0 (got D, H, W = %d, %d, %d)", D, H, W);
+    if (form == 2)
+        return mvsgi::wino_up2_launch(x_split, P + h.off_wino, reinterpret_cast<const float*>(P + h.off_wino_unscale), scale, shift, y,
+                                      B, D, H, W, neg_slope, st);
+    if (fmt && ob && form == 0 && h.off_wino) {
+        const long long units = (long long)B * (H / 2) * (W / 32);
+        long long nwalk = cus / 16;
+        if (nwalk > mvsgi::cdiv(units, 8)) nwalk = mvsgi::cdiv(units, 8);
+        if (nwalk < 1) nwalk = 1;
+        const long long rounds = mvsgi::cdiv(mvsgi::cdiv(units, 8), nwalk);
+        if (10 * units >= 7 * rounds * 8 * nwalk)
+            return mvsgi::wino_up2_launch(x_split, P + h.off_wino, reinterpret_cast<const float*>(P + h.off_wino_unscale), scale, shift, y,
+                                          B, D, H, W, neg_slope, st);
+    }
     return mvsgi::rs32_up2_launch(x_split, P + h.off_main, scale, shift, y, ob, B, D, H, W, neg_slope, fmt != 0, st);
 }
 
@@ -537,8 +577,26 @@ extern "C" int mvsgi_conv3d_up2_poly_split(const void* x_split, const void* plan
     return poly_launch(x_split, plan_dev, scale, shift, y_split, 1, B, D, H, W, neg_slope, 0, mvsgi::as_stream(stream));
 }
 
-// either output (y_is_split: 0 = fp32 [B][2D][2H][2W][16], 1 = split-padded) in either split: input, plan and a split output all in `fmt`
+// either output (y_is_split: 0 = fp32 [B][2D][2H][2W][16], 1 = split-padded, 3 = split-padded with the DIRECT main kernel whatever
+// the dispatcher would choose, 5 = split-padded with the WINOGRAD-form main kernel or an error) in either split: input, plan and a
+// split output all in `fmt`
 extern "C" int mvsgi_conv3d_up2_poly_fmt(const void* x_split, const void* plan_dev, const float* scale, const float* shift, void* y,
                                          int y_is_split, int B, int D, int H, int W, float neg_slope, int fmt, mvsgi_stream_t stream) {
-    return poly_launch(x_split, plan_dev, scale, shift, y, y_is_split ? 1 : 0, B, D, H, W, neg_slope, fmt, mvsgi::as_stream(stream));
+    MVSGI_REQUIRE(y_is_split == 0 || y_is_split == 1 || y_is_split == 3 || y_is_split == 5, "mvsgi_conv3d_up2_poly: y_is_split %d not in {0, 1, 3, 5}",
+                  y_is_split);
+    return poly_launch(x_split, plan_dev, scale, shift, y, y_is_split ? 1 : 0, B, D, H, W, neg_slope, fmt, mvsgi::as_stream(stream),
+                       y_is_split == 3 ? 1 : (y_is_split == 5 ? 2 : 0));
+}
+
+// the main kernel the dispatcher launches for a split-padded fp16 output of this geometry and batch: 1 = the Winograd form
+// (csrc/conv3d_wino_up2.hip), 0 = the direct register-stationary kernel
+extern "C" int mvsgi_conv3d_up2_poly_wino_pays(int B, int D, int H, int W) {
+    if (!mvsgi::wino_up2_applies(D, H, W) || B < 1) return 0;
+    const int cus = mvsgi::device_cus();
+    const long long units = (long long)B * (H / 2) * (W / 32);
+    long long nwalk = cus / 16;
+    if (nwalk > mvsgi::cdiv(units, 8)) nwalk = mvsgi::cdiv(units, 8);
+    if (nwalk < 1) nwalk = 1;
+    const long long rounds = mvsgi::cdiv(mvsgi::cdiv(units, 8), nwalk);
+    return 10 * units >= 7 * rounds * 8 * nwalk ? 1 : 0;
 }

@@ -533,12 +533,25 @@ def conv3d_up2_poly(x: "SplitAct", plan: torch.Tensor, scale, shift, neg_slope=0
     return y
 
 
-def conv3d_up2_poly_split(x: "SplitAct", plan: torch.Tensor, scale, shift, out: "SplitAct", neg_slope=0.01) -> "SplitAct":
-    """conv3d_up2_poly with the result written split-padded into `out` (B, 2D, 2H, 2W, 16)."""
+POLY_WINO = os.environ.get("MVSGI_POLY_WINO", "1") != "0"      # 0: the polyphase layer's main kernel stays the direct register-stationary one in the fp16 split too
+
+
+def conv3d_up2_poly_wino_pays(B: int, D: int, Hh: int, W: int) -> bool:
+    """conv3d_up2_poly_split on fp16 pairs of this (low-resolution) geometry and batch runs its main kernel in Winograd form
+    (csrc/conv3d_wino_up2.hip): D == 8, H even, W a multiple of 32 and enough units to fill the chip."""
+    return POLY_WINO and bool(_lib.load().mvsgi_conv3d_up2_poly_wino_pays(int(B), int(D), int(Hh), int(W)))
+
+
+def conv3d_up2_poly_split(x: "SplitAct", plan: torch.Tensor, scale, shift, out: "SplitAct", neg_slope=0.01, direct: bool = False,
+                          wino: bool = False) -> "SplitAct":
+    """conv3d_up2_poly with the result written split-padded into `out` (B, 2D, 2H, 2W, 16).  In the fp16 split the library picks
+    the main kernel: the Winograd form where conv3d_up2_poly_wino_pays(), else the direct kernel; `direct` (or MVSGI_POLY_WINO=0)
+    keeps the direct kernel, `wino` forces the Winograd form (an error where it does not apply)."""
     lib = _lib.load()
     if x.C != 32 or scale.numel() != 16 or out.shape != (x.B, 2 * x.D, 2 * x.H, 2 * x.W, 16):
         raise AssertionError(f"conv3d_up2_poly_split: input {x.shape}, output {out.shape}")
-    _lib.check(lib.mvsgi_conv3d_up2_poly_fmt(x.buf.data_ptr(), plan.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.buf.data_ptr(), 1,
+    _lib.check(lib.mvsgi_conv3d_up2_poly_fmt(x.buf.data_ptr(), plan.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.buf.data_ptr(),
+                                             5 if wino else (3 if (direct or not POLY_WINO) else 1),
                                              x.B, x.D, x.H, x.W, float(neg_slope), _fmt_code(x.fmt), _stream_ptr(x.buf)),
                "mvsgi_conv3d_up2_poly_split")
     out.fmt = x.fmt

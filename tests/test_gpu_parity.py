@@ -2211,8 +2211,46 @@ def test_conv3d_up2_polyphase_in_the_fp16_split_vs_interpolate_then_conv(shape):
         + torch.from_numpy(sh).double().view(1, -1, 1, 1, 1)
     ref = torch.where(ref > 0, ref, ref * 0.01).permute(0, 2, 3, 4, 1).float().numpy()
     assert _rel(y.cpu().numpy(), ref) <= 5e-6
-    ys = H.conv3d_up2_poly_split(xs, plan, _g(sc) * un, _g(sh), out=H.SplitAct(B, 2 * d, 2 * h, 2 * w, 16, x.device), neg_slope=0.01)
-    assert ys.fmt == "f16" and torch.equal(ys.buf, H.act_to_split(y, fmt="f16").buf)
+    ys = H.conv3d_up2_poly_split(xs, plan, _g(sc) * un, _g(sh), out=H.SplitAct(B, 2 * d, 2 * h, 2 * w, 16, x.device), neg_slope=0.01, direct=True)
+    assert ys.fmt == "f16" and torch.equal(ys.buf, H.act_to_split(y, fmt="f16").buf)          # (the direct main kernel: the same sums)
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 2, 32), (1, 8, 4, 64), (3, 8, 6, 32), (2, 8, 40, 160), (7, 8, 40, 160)])
+def test_conv3d_up2_polyphase_winograd_form_vs_interpolate_then_conv(shape):
+    """K3w (csrc/conv3d_wino_up2.hip): the polyphase ResizeConv3d's main kernel as polyphase over (H, W) x Winograd F(2x2, 3x3) x an
+    explicit depth upsample on the transformed planes, against interpolate -> conv in float64 (common_modules.py:332-355) on the
+    low-resolution input it staged and against the direct main kernel -- one unit, one unit per role and XCD, ragged walks (600 and
+    2100 units on 256 workgroups); face and edge corrections through the residual path; every output plane incl. the first and the last
+    (the upsample's clamp and the zero padding of the UPSAMPLED grid along D need no boundary weights in this form)."""
+    B, d, h, w = shape
+    rng = np.random.default_rng(sum(shape) + 19)
+    x = _g(rng.standard_normal((B, d, h, w, 32), dtype=np.float32))
+    wt = (rng.standard_normal((16, 32, 3, 3, 3)) / np.sqrt(27 * 32)).astype(np.float32)
+    sc, sh = _bn(rng, 16)
+    xs = H.act_to_split(x, fmt="f16")
+    plan, un = H.conv3d_up2_poly_plan(_g(wt), d, h, w, fmt="f16")
+    up = F.interpolate(H.act_from_split(xs).cpu().double().permute(0, 4, 1, 2, 3), scale_factor=2, mode="trilinear", align_corners=False)
+    ref = F.conv3d(up, torch.from_numpy(wt).double(), padding=1) * torch.from_numpy(sc).double().view(1, -1, 1, 1, 1) \
+        + torch.from_numpy(sh).double().view(1, -1, 1, 1, 1)
+    ref = torch.where(ref > 0, ref, ref * 0.01).permute(0, 2, 3, 4, 1).numpy()
+    out = H.SplitAct(B, 2 * d, 2 * h, 2 * w, 16, x.device)
+    yw = H.act_from_split(H.conv3d_up2_poly_split(xs, plan, _g(sc) * un, _g(sh), out=out, neg_slope=0.01, wino=True)).cpu().numpy()
+    border = out.buf.clone()
+    border[:, 1:-1, 1:-1, 1:-1] = 0
+    assert out.fmt == "f16" and int(border.abs().max()) == 0                       # the zero border is never written
+    err = np.abs(yw - ref).reshape(B, 2 * d, -1).max(axis=(0, 2)) / np.abs(ref).max()
+    print(f"winograd-form polyphase {shape}: max-rel per output plane {np.array2string(err, precision=2)}")
+    assert err.max() <= 5e-6, err
+    yd = H.act_from_split(H.conv3d_up2_poly_split(xs, plan, _g(sc) * un, _g(sh), out=H.SplitAct(B, 2 * d, 2 * h, 2 * w, 16, x.device),
+                                                  neg_slope=0.01, direct=True)).cpu().numpy()
+    assert _rel(yw, yd) <= 5e-6
+    # a second call over its own output (the corrections overwrite the face records first), and the dispatcher's own choice
+    again = H.act_from_split(H.conv3d_up2_poly_split(xs, plan, _g(sc) * un, _g(sh), out=out, neg_slope=0.01, wino=True)).cpu().numpy()
+    assert np.array_equal(again, yw)
+    auto = H.act_from_split(H.conv3d_up2_poly_split(xs, plan, _g(sc) * un, _g(sh), out=out, neg_slope=0.01)).cpu().numpy()
+    assert np.array_equal(auto, yw if H.conv3d_up2_poly_wino_pays(B, d, h, w) else yd)
+    with pytest.raises(RuntimeError, match="Winograd form needs"):
+        H.conv3d_up2_poly_split(H.act_to_split(x), H.conv3d_up2_poly_plan(_g(wt), d, h, w), _g(sc), _g(sh), out=out, wino=True)
 
 
 def test_sweep_split_padded_output_in_the_fp16_split(golden_dir):
