@@ -322,6 +322,11 @@ const char* const kVariantNames[] = {
     "conv3d_bf16x3_kernel<2, 2, 2, 2, 2, 4, 8, 2, 3, false, false, false, false>",
     "conv3d_bf16x3_kernel<3, 2, 2, 2, 2, 4, 8, 2, 3, false, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 1, 4, 2, 4, 8, 2, 3, false, false, false, false>",
     "conv3d_bf16x3_kernel<3, 4, 1, 4, 2, 4, 8, 2, 3, false, false, false, false>",
+#ifdef MVSGI_EXPERIMENTAL
+    "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 2, 16, 2, 3, false, false, false, false>", "conv3d_bf16x3_kernel<2, 2, 2, 2, 2, 2, 16, 2, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<3, 2, 2, 2, 2, 2, 16, 2, 3, false, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 1, 4, 2, 2, 16, 2, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<3, 4, 1, 4, 2, 2, 16, 2, 3, false, false, false, false>",
+#endif
     "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, true, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1, 3, true, false, false, false>",
     "conv3d_bf16x3_kernel<2, 2, 4, 1, 2, 4, 16, 1, 3, true, false, false, false>", "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1, 3, true, false, false, false>",
     "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, true, false, false, false>", "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, true, false, false, false>",
@@ -413,7 +418,8 @@ int select_variant(const ConvArgs& a, int impl) {
 #ifdef MVSGI_EXPERIMENTAL
             if (const char* f = mvsgi::exp_env("MVSGI_B3_FORCE")) {
                 static const struct { const char* n; int v; } tab[] = {{"S2_N32", B3_S2_N32}, {"S2_N32B", B3_S2_N32B}, {"S2_N64", B3_S2_N64}, {"S2_N96", B3_S2_N96},
-                    {"S2_N128", B3_S2_N128}, {"S2_N192", B3_S2_N192}};
+                    {"S2_N128", B3_S2_N128}, {"S2_N192", B3_S2_N192}, {"S2W_N32B", B3_S2W_N32B}, {"S2W_N64", B3_S2W_N64}, {"S2W_N96", B3_S2W_N96},
+                    {"S2W_N128", B3_S2W_N128}, {"S2W_N192", B3_S2W_N192}};
                 for (const auto& t : tab) if (!strcmp(f, t.n)) return t.v;
             }
 #endif
@@ -421,6 +427,7 @@ int select_variant(const ConvArgs& a, int impl) {
             // 12 input voxels per output voxel and slice, once per cout block (96 -> 192 at 32 frames: 879 us in 64-cout units, 688 in
             // 192-cout units; 192 -> 384: 478 -> 352; 16 -> 96: 933 -> 744)
             const long long s2bricks = (long long)a.B * mvsgi::cdiv(a.Do, 2) * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 8);
+            // (Round 6: 2 x 2 x 16 bricks -- conflict-free stride-2 fragment reads -- measured equal or slower, conv3d_variants.hpp)
             if (CT % 12 == 0 && s2bricks * (CT / 12) >= 512) return B3_S2_N192;
             if (CT % 8 == 0 && s2bricks * (CT / 8) >= 512) return B3_S2_N128;
             if (CT % 6 == 0 && s2bricks * (CT / 6) >= 512) return B3_S2_N96;

@@ -6,6 +6,14 @@ enum Variant {
     V_S1_N16_B256, V_S1_N32_B256, V_S1_N32_B64, V_S1_N64_B128, V_S1_N64_B64, V_S2_N32_B64, V_S2_N64_B64,
     // split-bf16 kernel: 16-wide bricks (conflict-free LDS reads); N = couts per workgroup
     B3_N16, B3_N32, B3_N48, B3_N64, B3_N64_H5, B3_N96, B3_N96_H5, B3_N128_P, B3_N128_PH5, B3_N192_PH5, B3_N32_S, B3_N64_S, B3_N16_T, B3_N32_T, B3_N16_TW, B3_S2_N32, B3_S2_N32B, B3_S2_N64, B3_S2_N96, B3_S2_N128, B3_S2_N192,
+#ifdef MVSGI_EXPERIMENTAL
+    // stride-2 bricks 2 x 2 x 16 (the W variants; round 6): a 16-voxel tile is 16 outputs of ONE row, whose stride-2 fragment reads
+    // walk the 16 sixteen-byte units of a bank row with stride 10 (all even) while their pair partners, an odd number of units away,
+    // take the odd ones -- against the 2 x 4 x 8 bricks' two-row tiles, which hit every bank row twice.  Measured
+    // (profiles/r06_stride2_brick_shapes.txt): LDS conflict cycles -63 %, LDS-active cycles -30 %, and the layers' time -1.5 % ... +7.7 %
+    // (8 % more halo to stage): the conflicts are not what bounds these layers.  Kept for the A/B (MVSGI_B3_FORCE=S2W_N96 ...), not dispatched.
+    B3_S2W_N32B, B3_S2W_N64, B3_S2W_N96, B3_S2W_N128, B3_S2W_N192,
+#endif
     // split-bf16 kernel with the trilinear x2 upsample fused into its producers (even bricks only)
     B3U_N16, B3U_N32, B3U_N32_M, B3U_N48, B3U_N64, B3U_N96,
     // Cout == 16 plane schedule (weights from mvsgi_conv3d_pack_weights_bf16x3_c16), plain and fused-upsample

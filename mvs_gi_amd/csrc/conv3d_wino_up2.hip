@@ -83,9 +83,21 @@ __host__ __device__ constexpr int step_request(int s) { return s == 0 ? 2 : (s =
 __host__ __device__ constexpr int step_read(int s) { return s == 14 ? 8 : (s == 15 ? 9 : ((s & 1) && s <= 11 ? (s + 3) / 2 : -1)); }
 }  // namespace wu
 
+// (lo-half value, hi-half value) -> the split's packed hi and lo dwords under MODE.FP16_OVFL: the conversions saturate by themselves
+__device__ __forceinline__ void split_pair_ovfl(float v0, float v1, unsigned& hi, unsigned& lo, float& satm) {
+    satm = sf_sat_acc(satm, v0, v1);         // range report (csrc/split_fmt.hpp): on the unclamped values
+    hi = sf_cvt_pk<true>(v0, v1);
+    lo = sf_cvt_pk<true>(mix_sub_lo(v0, hi), mix_sub_hi(v1, hi));
+}
+
 __global__ __launch_bounds__(256, 1) void conv3d_wino_up2_kernel(WinoUp2Args a) {
     using namespace wu;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // MODE.FP16_OVFL (hwreg 1, bit 23): an fp32 -> fp16 conversion whose result overflows gives +-65504 instead of +-inf
+    // (tools/ubench/fp16_ovfl_trapsts.hip: v_cvt_pk_f16_f32(70000) = 0x7bff; true infinities stay infinities) -- the range clamp
+    // of the fp16 split (one v_med3_f32 per value, 40 per step of this vector-issue-bound kernel) for free.  The range report
+    // still sees every value in front of its conversion.
+    __builtin_amdgcn_s_setreg((1 - 1) << 11 | 23 << 6 | 1, 1u);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);                 // this wave's row of the transform space
     const int n = lane & 15, kg = lane >> 4;
@@ -262,9 +274,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino_up2_kernel(WinoUp2Args a) 
                     X0 = Pq[b_][0];                                                                         \
                     X1 = Pq[b_][1];                                                                         \
                 }                                                                                           \
-                X0 = sf_clamp<true>(X0);                  /* sums of four fp16-range values */              \
-                X1 = sf_clamp<true>(X1);                                                                    \
-                satm = sf_sat_acc(satm, X0, X1);                                                            \
+                satm = sf_sat_acc(satm, X0, X1);          /* sums of four fp16-range values: saturated by the conversion (MODE.FP16_OVFL) */ \
                 if constexpr (b_ > 0) vl[VN][b_ - 1][d_] = sf_cvt_pk<true>(L0, L1);     /* (the lo halves of the b before: not right behind the asm that made them) */ \
             } else {                                                                                        \
                 const unsigned h_ = sf_cvt_pk<true>(X0, X1);                                                \
@@ -308,8 +318,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino_up2_kernel(WinoUp2Args a) 
             t_[e_] = __builtin_fmaf(t_[e_], ema_[c_][e_], __builtin_fmaf(rf_[c_][e_], esc_[e_], esh_[e_])); \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) t_[e_] = __builtin_fmaxf(t_[e_], t_[e_] * a.neg_slope); \
         unsigned h0_, l0_, h1_, l1_;                                                                        \
-        split_pair(t_[0], t_[1], h0_, l0_, satm);                                                           \
-        split_pair(t_[2], t_[3], h1_, l1_, satm);                                                           \
+        split_pair_ovfl(t_[0], t_[1], h0_, l0_, satm);                                                      \
+        split_pair_ovfl(t_[2], t_[3], h1_, l1_, satm);                                                      \
         unsigned char* q_ = yb + (long long)((O) + 1) * oplane_bytes + lane_out + c_ * 64;                  \
         *reinterpret_cast<u32x2*>(q_) = u32x2{h0_, h1_};                                                    \
         *reinterpret_cast<u32x2*>(q_ + 32) = u32x2{l0_, l1_};                                               \

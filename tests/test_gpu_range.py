@@ -209,6 +209,25 @@ def test_winograd_level_clamps_behind_the_activation_and_reports():
     assert _flags() == H.SAT_WINO
 
 
+def test_polyphase_winograd_form_saturates_in_the_conversion_and_reports():
+    """K3w (csrc/conv3d_wino_up2.hip) carries no clamp instruction: it runs under MODE.FP16_OVFL, where the fp32 -> fp16 conversions of
+    its transformed planes and of its output saturate at +-65504 by themselves (tools/ubench/fp16_ovfl_trapsts.hip); the range report
+    sees the values in front of the conversion."""
+    plan, un = H.conv3d_up2_poly_plan(_g(_centre(16, 32)), 8, 4, 32, "f16")
+    xs = H.act_to_split(torch.full((2, 8, 4, 32, 32), 100.0, device=DEV), fmt="f16")
+    for s, want in ((100.0, 0), (700.0, H.SAT_SPLIT), (-7.0e6, H.SAT_SPLIT)):
+        y = H.act_from_split(H.conv3d_up2_poly_split(xs, plan, un * s, _zeros(16), H.SplitAct(2, 16, 8, 64, 16, DEV), neg_slope=1.0, wino=True))
+        assert _flags() == want, s
+        assert bool(torch.isfinite(y).all()) and float(y.abs().max()) <= 2 * 65504.0
+        if not want:
+            assert abs(float(y.abs().max()) - 100.0 * s) <= 1.0
+    # the transformed planes: x1 + x2 of a constant 6e4 volume = 1.2e5 saturates in the conversion of V
+    xs = H.act_to_split(torch.full((2, 8, 4, 32, 32), 6.0e4, device=DEV), fmt="f16")
+    assert _flags() == 0
+    y = H.act_from_split(H.conv3d_up2_poly_split(xs, plan, un * 1.0e-3, _zeros(16), H.SplitAct(2, 16, 8, 64, 16, DEV), neg_slope=1.0, wino=True))
+    assert _flags() == H.SAT_SPLIT and bool(torch.isfinite(y).all())
+
+
 # ------------------------------------------------------------------------------------------------ the Python layer's policy
 def _small_hot_path(gain=1e-5):
     case = SMALL_CASES["std_d16_rand"]
