@@ -621,12 +621,23 @@ __global__ void rs16_pack_weights_kernel(const float* __restrict__ w, bf16x8* __
 
 // OSPLIT: the output goes to a split-padded tensor of the input's geometry (the hand-over to csrc/conv3d_s2rs.hip, which stages
 // pre-split voxels by LDS-DMA) instead of plain fp32 channels-last.
-template <bool OSPLIT, bool F16 = false>
-__global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
+// LOADERS (round 6, an experiment: -DMVSGI_RS16_LOADERS=1): the workgroup has four more waves, one per SIMD, that do nothing but issue
+// the LDS-DMA pieces of the next brick (wave 4 + r those of compute wave r).  An issuing wave sits 100-185 cycles on every 1 KiB piece
+// (with ONE wave per SIMD the 14 pieces per phase were 23 % of a phase in which the matrix pipe got nothing: 866 vs 1127 us
+// per 64 frames without the DMA); the idea was that a loader wave sits there beside a compute wave whose MFMAs keep issuing (the
+// kernel's 240 registers fit two waves per SIMD once the accumulators live in ordinary registers).  Measured, 16 frames of
+// [16, 80, 320], same box: fp32 output 278 vs 288 us, split-padded output (the product's) 329 vs 324 us with the pieces paced
+// 3 x 64 cycles apart; a burst (no pacing) and 5 x 64 are slower on both.  The stall is not hidden by a sibling wave: not kept.
+#ifndef MVSGI_RS16_LOADER_SLEEP
+#define MVSGI_RS16_LOADER_SLEEP 3      // x 64 cycles between a loader wave's pieces
+#endif
+template <bool OSPLIT, bool F16 = false, bool LOADERS = false>
+__global__ __launch_bounds__(LOADERS ? 512 : 256, 1) void conv3d_rs16_kernel(Rs16Args a) {
     using namespace rs16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = the brick's h-row of this wave
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3;                                      // = the brick's h-row of this wave (compute), or of its compute wave (loader)
     const int col = lane & 15, kg = lane >> 4;
     const bool second = kg & 1;
     const int half = kg >> 1;
@@ -736,14 +747,22 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
         _Pragma("unroll") for (int o = 0; o < 4; ++o)                                                            \
             voy[o] = (hok_ & (int)(c1.od * TD + o < a.D) & (int)(c1.ow * TW + col < a.W)) ? voy0[o] : 0xffffff00u; \
     }
+// (LOADERS: two waves per SIMD = 256 registers per wave, which hipcc splits 128 / 128 between the two files: the 120 weight registers
+// stay in the accumulator file, the four accumulators move to ordinary registers)
 #define RS_MF(ACC, WREG, XREG)                                                                                         \
-    if constexpr (F16) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }  \
+    if constexpr (LOADERS) {                                                                                           \
+        if constexpr (F16) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(ACC) : "a"(WREG), "v"(XREG)); }  \
+        else { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(ACC) : "a"(WREG), "v"(XREG)); }           \
+    } else if constexpr (F16) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }  \
     else { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }
 // first MFMA of a brick on an accumulator: C = 0.  Declared read-write all the same ("+a"): a fresh definition would let the
 // allocator move the accumulator to other registers and reconcile with v_accvgpr_mov at the loop's back edge -- directly in
 // front of asm MFMAs whose hazards it cannot pad
 #define RS_MF0(ACC, WREG, XREG)                                                                                        \
-    if constexpr (F16) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }   \
+    if constexpr (LOADERS) {                                                                                           \
+        if constexpr (F16) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "+v"(ACC) : "a"(WREG), "v"(XREG)); }   \
+        else { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "+v"(ACC) : "a"(WREG), "v"(XREG)); }            \
+    } else if constexpr (F16) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }   \
     else { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "+a"(ACC) : "a"(WREG), "v"(XREG)); }
 // the split's conversions inside the generated schedules (tools/gen_rs*_schedule.py); RS_LRELU_MAX is LeakyReLU's max, RS_CLAMP the
 // fp16 split's range clamp on a split output: one v_med3_f32 BEHIND the activation (round 5 folded the upper end into the
@@ -759,6 +778,39 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
 #define RS16_F_SPL(...) if constexpr (OSPLIT) { __VA_ARGS__ }
 #define RS16_F_F32(...) if constexpr (!OSPLIT) { __VA_ARGS__ }
 
+    if constexpr (LOADERS) {
+        if (wave8 >= 4) {
+            // ---- a loader wave: brick 0 -> image 0, then during phase ph brick ph + 1 -> the other image; the same barriers as the
+            // compute waves (one behind the prologue, one per phase).  The image filled in phase ph was read in phase ph - 1: every
+            // compute wave passed that phase's barrier behind its last fragment read. ----
+            {
+                const auto dsc_x = RS16_DESC(c0, 1);
+                const int nxt_img = 0;
+#pragma unroll
+                for (int m = 0; m < DPW; ++m) RS16_DMA(m)
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int ph = 0; ph < n; ++ph) {
+                const int nxt_img = (ph & 1) ? 0 : BUF1;
+                const auto dsc_x = RS16_DESC(nx, (int)(ph + 1 < n));
+#pragma unroll
+                for (int m = 0; m < DPW; ++m) {
+                    RS16_DMA(m)
+                    // paced over the phase (~5300 cycles): in a burst the workgroup's 56 requests queue up in the CU's address path
+                    // in front of the compute waves' fragment reads
+                    __builtin_amdgcn_s_sleep(MVSGI_RS16_LOADER_SLEEP);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                c0 = nx;
+                RS16_STEP(nx, c0)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            return;
+        }
+    }
+#define RS16_F_OWN(...) if constexpr (!LOADERS) { __VA_ARGS__ }
     __amdgpu_buffer_rsrc_t dsc_x, dsc_y;
     u32x2 hb0, hb1, hb2, hb3, lb0, lb1, lb2, lb3, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
     f32x2v hf0, hf1, hf2, hf3;
@@ -766,11 +818,13 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
     hf0 = hf1 = hf2 = hf3 = f32x2v{0.f, 0.f};
     unsigned voy[4] = {0xffffff00u, 0xffffff00u, 0xffffff00u, 0xffffff00u};
     dsc_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, 0, 0x00020000);
-    {   // prologue: image 0 <- brick 0
+    if constexpr (!LOADERS) {   // prologue: image 0 <- brick 0
         dsc_x = RS16_DESC(c0, 1);
         const int nxt_img = 0;
 #pragma unroll
         for (int m = 0; m < DPW; ++m) RS16_DMA(m)
+    } else {
+        dsc_x = RS16_DESC(c0, 1);
     }
     f32x4 acc[4], fin[4];
     bf16x8 xh[3][2], xl[3][2];
@@ -821,6 +875,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs16_kernel(Rs16Args a) {
 #undef RS_F_STORE16
 #undef RS16_F_SPL
 #undef RS16_F_F32
+#undef RS16_F_OWN
 }
 
 }  // namespace
@@ -1041,14 +1096,21 @@ int rs16_run(const void* x, const void* w_packed_rs, const float* scale, const f
     a.total_units = (int)nb;
     MVSGI_SAT_WORDS(sat_words_);
     a.sat = sat_words_;
+    // -DMVSGI_RS16_LOADERS=1 builds the eight-wave kernel (four compute + four loader waves, LOADERS above): measured equal within
+    // +-3 % (profiles/r06_post_vol_loader_waves.txt) -- the product stays on four waves
+#ifndef MVSGI_RS16_LOADERS
+#define MVSGI_RS16_LOADERS 0
+#endif
+    constexpr bool kLoaders = MVSGI_RS16_LOADERS != 0;
     static mvsgi::PersistentGeom geo_cache[4][mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
-    void (*kern)(Rs16Args) = fmt ? (y_is_split ? conv3d_rs16_kernel<true, true> : conv3d_rs16_kernel<false, true>)
-                                 : (y_is_split ? conv3d_rs16_kernel<true, false> : conv3d_rs16_kernel<false, false>);
-    if (mvsgi::persistent_geometry(kern, 256, rs16::LDS_BYTES, 1, geo_cache[(y_is_split ? 1 : 0) + (fmt ? 2 : 0)], "mvsgi_conv3d_rs16_split", geo))
+    void (*kern)(Rs16Args) = fmt ? (y_is_split ? conv3d_rs16_kernel<true, true, kLoaders> : conv3d_rs16_kernel<false, true, kLoaders>)
+                                 : (y_is_split ? conv3d_rs16_kernel<true, false, kLoaders> : conv3d_rs16_kernel<false, false, kLoaders>);
+    constexpr int kThreads = kLoaders ? 512 : 256;
+    if (mvsgi::persistent_geometry(kern, kThreads, rs16::LDS_BYTES, 1, geo_cache[(y_is_split ? 1 : 0) + (fmt ? 2 : 0)], "mvsgi_conv3d_rs16_split", geo))
         return 1;
     const long long resident = (long long)geo.cus / 8 * 8 > 0 ? (long long)geo.cus / 8 * 8 : 8;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(256), rs16::LDS_BYTES, mvsgi::as_stream(stream), a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nb <= resident ? nb : resident)), dim3(kThreads), rs16::LDS_BYTES, mvsgi::as_stream(stream), a);
     return mvsgi::check_launch("mvsgi_conv3d_rs16_split");
 }
 }  // namespace

@@ -171,7 +171,7 @@ def build(with_pairs, split=False):
     early = os.environ.get("RS16_DMA_EARLY_F32", "1") == "1"
     if with_pairs and (split or early):
         for m in range(14):
-            S.place(dma_start + dma_step * m, 2.0, f"RS_F_DMA(RS16_DMA({m}))")
+            S.place(dma_start + dma_step * m, 2.0, f"RS16_F_OWN(RS_F_DMA(RS16_DMA({m})))")
     # epilogue: scale / shift, LeakyReLU, fp32 store -- one instruction per statement
     s = 36
     ep_end = s
@@ -210,7 +210,7 @@ def build(with_pairs, split=False):
         s = ep_end + 2
         step = max((n - 40 - s) // 14, 3)
         for m in range(14):
-            s = S.place(s, 2.0, f"RS_F_DMA(RS16_DMA({m}))") + step
+            s = S.place(s, 2.0, f"RS16_F_OWN(RS_F_DMA(RS16_DMA({m})))") + step
     # the read bases move to the other image once this phase's last reads are out; the walk moves on
     if with_pairs:
         for k, b in enumerate(("b_in", "b_2a", "b_2b")):
