@@ -76,6 +76,7 @@ _RANGE_CHECK = os.environ.get("MVSGI_RANGE_CHECK", "raise")
 if _RANGE_CHECK not in RANGE_CHECKS:
     raise ValueError(f"MVSGI_RANGE_CHECK={_RANGE_CHECK!r} not in {RANGE_CHECKS}")
 _RANGE_WARNED = set()
+_RANGE_SEEN = 0             # OR of every flag check_range() has reported (and cleared) in this process
 
 
 class MvsgiRangeError(RuntimeError):
@@ -104,6 +105,11 @@ def saturation_flags(clear: bool = False) -> int:
     return int(out.value)
 
 
+def range_flags_seen() -> int:
+    """OR of the flags check_range() has reported so far in this process (it clears the library's sticky words when it reports)."""
+    return _RANGE_SEEN
+
+
 def check_range(where: str = "", sync_device=None) -> int:
     """Apply the MVSGI_RANGE_CHECK policy to the flags raised so far (after synchronising `sync_device`, if given) and clear them.
     -> the flags that were raised."""
@@ -115,8 +121,10 @@ def check_range(where: str = "", sync_device=None) -> int:
     if not f:
         return 0
     saturation_flags(clear=True)
+    global _RANGE_SEEN
+    _RANGE_SEEN |= f
     what = "; ".join(t for b, t in _SAT_TEXT.items() if f & b)
-    msg = (f"mvs_gi_amd{' (' + where + ')' if where else ''}: the fp16 split (MVSGI_CONV_MODE=f16x3, the default) left its range -- {what}. "
+    msg = (f"mvs_gi_amd{' (' + where + ')' if where else ''}: the fp16 split (MVSGI_CONV_MODE=f16x3, the default) left its range (flags 0x{f:x}) -- {what}. "
            "Results computed since the last check are saturated, not the reference's fp32 results "
            "(dsta_mvs/model/common/common_modules.py:105-115 has no clamp). Re-run with MVSGI_CONV_MODE=bf16x3 "
            "(hip_ops.set_conv_mode('bf16x3'): fp32's range, ~8x the rounding error) or 'f32'; HotPath.precision_check(frames) measures "

@@ -164,6 +164,39 @@ class HotPath:
             H.set_range_check(old_policy)
 
 
+def overlapping_copy_stream(device, compute_stream: Optional[torch.cuda.Stream] = None, tries: int = 8) -> torch.cuda.Stream:
+    """A HIP stream whose copies run BESIDE the kernels of `compute_stream` (default: the current stream) -- for a caller that
+    feeds frames from pinned host memory while the previous batch is computed (double buffering, as the reference's robot would feed
+    `api/inference_class.py:120-127` at more than one frame in flight).  HIP multiplexes its streams onto a few hardware queues (four by
+    default, assigned round-robin at creation), and a stream that shares the compute stream's queue is served in submission order: its
+    uploads wait for the kernels submitted before them (MI355X, 64 G16V frames from uint8 images: 40.3 ms per batch = 0.66 of the
+    resident rate on such a stream, 27.4 ms = 0.975 on any other; `tools/host_feed_probe.py --queues`).  Candidates are tested with a
+    spin kernel on the compute stream and a small pinned copy on the candidate; the first whose copy finishes inside the spin wins."""
+    device = torch.device(device)
+    comp = compute_stream if compute_stream is not None else torch.cuda.current_stream(device)
+    host = torch.empty(1 << 20, dtype=torch.uint8).pin_memory()
+    dst = torch.empty(1 << 20, dtype=torch.uint8, device=device)
+    keep, last = [], None
+    for _ in range(max(1, tries)):
+        cand = torch.cuda.Stream(device=device)
+        keep.append(cand)                     # (held until the choice is made: a released stream object may be handed out again)
+        last = cand
+        torch.cuda.synchronize(device)
+        c0, c1, k1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        with torch.cuda.stream(comp):
+            c0.record(comp)
+            torch.cuda._sleep(4_000_000)      # ~2 ms of spinning at ~2 GHz
+            c1.record(comp)
+        with torch.cuda.stream(cand):
+            cand.wait_event(c0)
+            dst.copy_(host, non_blocking=True)
+            k1.record(cand)
+        torch.cuda.synchronize(device)
+        if c0.elapsed_time(k1) < 0.5 * c0.elapsed_time(c1):
+            return cand
+    return last
+
+
 class StreamedHotPath:
     """The batch of one step cut into `n_streams` independent parts, each through its own HotPath replica (own module-owned
     activation buffers; parameters and rig constants replicated: < 150 MB) on its own HIP stream, forked from and joined to the

@@ -328,3 +328,26 @@ def test_default_mode_frame_depends_on_its_launch_only_within_the_arithmetic():
     print(f"default mode, one G16V frame at B = 1 vs 2, 3, 4: max |d| / max |ref| {worst:.3e}, per pixel {worst_px:.3e}, bit-equal {equal}")
     assert worst <= 1e-4 and worst_px <= 2e-3, (worst, worst_px)
     assert not all(equal)           # if this ever holds the dispatch no longer depends on the batch: update DESIGN.md §5
+
+
+def test_overlapping_copy_stream_overlaps_uploads_with_compute():
+    """pipeline.overlapping_copy_stream: the returned stream's pinned H2D copy finishes INSIDE a spin kernel of the compute stream
+    (a stream on the compute stream's hardware queue would be served behind it: tools/host_feed_probe.py --queues)."""
+    from mvs_gi_amd.pipeline import overlapping_copy_stream
+    for _ in range(5):              # whatever position of the round-robin the process is at
+        torch.cuda.Stream(device=DEV)
+        cs = overlapping_copy_stream(DEV)
+        comp = torch.cuda.current_stream(DEV)
+        host = torch.empty(8 << 20, dtype=torch.uint8).pin_memory()
+        dst = torch.empty(8 << 20, dtype=torch.uint8, device=DEV)
+        torch.cuda.synchronize()
+        c0, c1, k1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        c0.record(comp)
+        torch.cuda._sleep(6_000_000)
+        c1.record(comp)
+        with torch.cuda.stream(cs):
+            cs.wait_event(c0)
+            dst.copy_(host, non_blocking=True)
+            k1.record(cs)
+        torch.cuda.synchronize()
+        assert c0.elapsed_time(k1) < 0.7 * c0.elapsed_time(c1), (c0.elapsed_time(k1), c0.elapsed_time(c1))
