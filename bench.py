@@ -48,7 +48,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="G16V")
-    ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step, cut into --streams equal parts")
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step, cut into --streams equal parts (round 6: 2 x 128; "
+                    "2 x 64 until round 5: 6231 vs 6300 frames/s alternating on one box)")
     ap.add_argument("--streams", type=int, default=2,
                     help="independent parts of a step's batch, each on its own HIP stream inside the step's one hipGraph "
                          "(StreamedHotPath: one part's kernel tails are filled by the other's launches; MI355X, G16V: 2 x 64 frames "
