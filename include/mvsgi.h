@@ -83,6 +83,7 @@ const char* mvsgi_last_error(void);
 #define MVSGI_SAT_SPLIT 2u     /* an activation written or staged in fp16 pieces by a conv layer reached +-65504                */
 #define MVSGI_SAT_WINO  4u     /* an activation of the Winograd level reached +-16376, or a transformed sum of four +-65504      */
 int mvsgi_saturation_flags(int clear, unsigned* flags);
+int mvsgi_saturation_words(unsigned* words8);      /* diagnostics: the 8 raw words (a kernel only ever stores 1 into one of them) */
 
 /* ---- K1: fused spherical sweep -------------------------------------------------------
  * Replaces SphericalSweepStdMasked.sweep (cost_volume_builder/spherical_sweep_avg.py:38-136)

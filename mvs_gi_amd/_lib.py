@@ -26,6 +26,7 @@ SIGNATURES = {
     "mvsgi_abi_version": (c_int, []),
     "mvsgi_last_error": (c_char_p, []),
     "mvsgi_saturation_flags": (c_int, [c_int, _P]),
+    "mvsgi_saturation_words": (c_int, [_P]),
     "mvsgi_sweep_std_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 10 + [_P]),
     "mvsgi_sweep_cat_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P]),
     "mvsgi_sweep_std_nhwc_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 10 + [_P]),

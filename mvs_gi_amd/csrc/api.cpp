@@ -47,3 +47,11 @@ extern "C" int mvsgi_saturation_flags(int clear, unsigned* flags) {
     if (flags) *flags = f;
     return 0;
 }
+
+// diagnostics: the raw words behind mvsgi_saturation_flags (a kernel only ever stores 1: any other value is a stray write)
+extern "C" int mvsgi_saturation_words(unsigned* words8) {
+    volatile unsigned* w = mvsgi::sat_words();
+    MVSGI_REQUIRE(w != nullptr && words8 != nullptr, "mvsgi_saturation_words: no report words / null pointer");
+    for (int i = 0; i < mvsgi::kSatWords; ++i) words8[i] = w[i];
+    return 0;
+}

@@ -105,6 +105,15 @@ def saturation_flags(clear: bool = False) -> int:
     return int(out.value)
 
 
+def saturation_words():
+    """The raw report words (diagnostics): a kernel only ever stores 1 into the word of its kind."""
+    import ctypes
+    out = (ctypes.c_uint * 8)()
+    if _lib.load().mvsgi_saturation_words(out) != 0:
+        return [0] * 8
+    return [int(v) for v in out]
+
+
 def range_flags_seen() -> int:
     """OR of the flags check_range() has reported so far in this process (it clears the library's sticky words when it reports)."""
     return _RANGE_SEEN
@@ -120,11 +129,12 @@ def check_range(where: str = "", sync_device=None) -> int:
     f = saturation_flags(clear=False)
     if not f:
         return 0
+    words = saturation_words()
     saturation_flags(clear=True)
     global _RANGE_SEEN
     _RANGE_SEEN |= f
     what = "; ".join(t for b, t in _SAT_TEXT.items() if f & b)
-    msg = (f"mvs_gi_amd{' (' + where + ')' if where else ''}: the fp16 split (MVSGI_CONV_MODE=f16x3, the default) left its range (flags 0x{f:x}) -- {what}. "
+    msg = (f"mvs_gi_amd{' (' + where + ')' if where else ''}: the fp16 split (MVSGI_CONV_MODE=f16x3, the default) left its range (flags 0x{f:x}, words {words[:4]}) -- {what}. "
            "Results computed since the last check are saturated, not the reference's fp32 results "
            "(dsta_mvs/model/common/common_modules.py:105-115 has no clamp). Re-run with MVSGI_CONV_MODE=bf16x3 "
            "(hip_ops.set_conv_mode('bf16x3'): fp32's range, ~8x the rounding error) or 'f32'; HotPath.precision_check(frames) measures "
