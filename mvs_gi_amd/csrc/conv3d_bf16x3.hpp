@@ -307,6 +307,14 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
     constexpr int NSLOT = ((kPairs + WB - 1) / WB) * WB;
     static_assert(NSLOT % WB == 0 && NSLOT >= kPairs, "pipeline geometry");
     constexpr bool RPRE = MW * NW <= 8;            // residual tiles requested during the last slot (register budget)
+    // the producers' third register set (requests three units ahead) for the small-launch variants (one or two tiles per wave): an
+    // experiment (-DMVSGI_PF3=1), measured round 6 -- 64 -> 64 on one [4, 20, 80] frame 12.9 vs 12.7 us, 128 -> 128 on [2, 10, 40]
+    // 15.2 vs 13.8 (its LDS-staged weight sets spill), the one-frame step 0.498 vs 0.482 ms: the one-frame layers are not bound by
+    // the age of their loads
+#ifndef MVSGI_PF3
+#define MVSGI_PF3 0
+#endif
+    constexpr bool PF3 = MVSGI_PF3 && KD == 3 && !UPS && !PLANE && !V32 && S == 1 && MW * NW <= 2;
     constexpr int WBYTES = WLDS ? NW * kPairs * 2048 : 0;      // the unit's weight slice in LDS, behind its activation image
     constexpr int BUFW = BUF + WBYTES;             // one buffer of the double-buffered LDS (image + weights)
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -648,6 +656,43 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
         }
         STAMP()
         MVSGI_PLAN((int)blockIdx.x)
+        if constexpr (PF3) {
+            // Small launches (one or two tiles per wave: a frame to a few): a slice's MFMAs are 0.3-0.7 us, a global-load round trip
+            // 1.5-2 us, and with two register sets a step waits for loads that are ONE step old -- the step time was the load latency
+            // (profiles/r06_b1_kernel_stats.txt: 12.7-13.7 us per layer for 4-8 slices of ~0.4 us of MFMAs).  Three sets: the loads
+            // of unit u+3 go out while unit u+1, requested TWO steps ago, is split and written.
+            f32x4 preC[NIT], wpreC[WNIT];
+            (void)wpreC;
+            unsigned okC = 0;
+            (void)okC;
+            MVSGI_ISSUE(preA, okA, wpreA)                  // unit 0
+            MVSGI_PUT(preA, okA, ldsb)
+            MVSGI_WPUT(wpreA, ldsb)
+            MVSGI_ISSUE(preA, okA, wpreA)                  // unit 1 in flight (unconditional requests: see below)
+            MVSGI_ISSUE(preB, okB, wpreB)                  // unit 2 in flight
+            STAMP()
+            __syncthreads();                               // image 0 holds unit 0
+            STAMP()
+            for (int u = 0; u < U; u += 3) {
+                // A holds unit u+1, B unit u+2 (both in flight); request u+3 into C, then finish u+1
+                MVSGI_STEP(preC, okC, preA, okA, ldsb + ((u + 1) & 1) * BUFW, u + 1 < U && !(MVSGI_ABL & 8), wpreC, wpreA)
+                STAMP()
+                __syncthreads();                           // unit u multiplied, image of unit u+1 complete
+                STAMP()
+                if (u + 1 < U) {
+                    MVSGI_STEP(preA, okA, preB, okB, ldsb + ((u + 2) & 1) * BUFW, u + 2 < U && !(MVSGI_ABL & 8), wpreA, wpreB)
+                    STAMP()
+                    __syncthreads();
+                    STAMP()
+                }
+                if (u + 2 < U) {
+                    MVSGI_STEP(preB, okB, preC, okC, ldsb + ((u + 3) & 1) * BUFW, u + 3 < U && !(MVSGI_ABL & 8), wpreB, wpreC)
+                    STAMP()
+                    __syncthreads();
+                    STAMP()
+                }
+            }
+        } else {
         MVSGI_ISSUE(preA, okA, wpreA)                      // unit 0
         MVSGI_PUT(preA, okA, ldsb)
         MVSGI_WPUT(wpreA, ldsb)
@@ -670,6 +715,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
                 __syncthreads();
                 STAMP()
             }
+        }
         }
 #undef MVSGI_ISSUE
 #undef MVSGI_WISSUE
