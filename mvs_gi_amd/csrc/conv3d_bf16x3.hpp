@@ -315,8 +315,22 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
 #define MVSGI_PF3 0
 #endif
     constexpr bool PF3 = MVSGI_PF3 && KD == 3 && !UPS && !PLANE && !V32 && S == 1 && MW * NW <= 2;
+    // WARM (an experiment, -DMVSGI_WARM=1): in the small launches (one or two tiles per wave, weights straight from L2) the idle
+    // producers pull the weight slice of the unit they are staging through L2 with LDS-DMA requests into a dummy KiB per wave, on
+    // the theory that the consumers' fragment requests (LA slots = 700 cycles of MFMAs ahead) meet cold lines.  Measured round 6:
+    // 64 -> 64 on one [4, 20, 80] frame 14.4 vs 12.6 us, the one-frame step 0.501 vs 0.491 ms -- SLOWER: the weights are not cold
+    // (442 KB per layer stay in a 4 MiB L2 between units) and the extra requests queue in the CU's address path.  In-kernel stamps of
+    // that layer: a slice's 84 MFMAs (1344 cycles at the matrix rate) take 4200 cycles, its unit 5000, the producers idle 55 % of
+    // every step: the four consumer waves each fetch the SAME weight fragments (16 KiB per 96-cycle slot and CU through a path
+    // that returns 64 B / clk: 256 cycles per slot) and restart their fragment pipelines behind every slice's barrier.
+#ifndef MVSGI_WARM
+#define MVSGI_WARM 0
+#endif
+    constexpr bool WARM = MVSGI_WARM && KD == 3 && !UPS && !PLANE && !V32 && !WLDS && S == 1 && MW * NW <= 2;
+
     constexpr int WBYTES = WLDS ? NW * kPairs * 2048 : 0;      // the unit's weight slice in LDS, behind its activation image
     constexpr int BUFW = BUF + WBYTES;             // one buffer of the double-buffered LDS (image + weights)
+    constexpr int WARM_LDS = 2 * BUFW;             // WARM: 4 KiB behind the two buffers, one dummy KiB per producer wave
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     float satm = 0.f;          // fp16 split: running maximum |value staged or written in fp16 pieces| (range report)
 
@@ -560,7 +574,13 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
         f32x4 wpreA[WNIT], wpreB[WNIT];
         (void)wpreA; (void)wpreB;
         const char* wsrc = reinterpret_cast<const char*>(a.wp) + (wave - 4) * 1024 + lane * 16;
+        // WARM: the packed weights as a buffer ([cin slice][cout tile][pair][hi | lo][64 lanes][16 B]; requests past its end move nothing)
+        const __amdgpu_buffer_rsrc_t wdesc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(reinterpret_cast<const void*>(a.wp)), 0, WARM ? (int)((long long)nchunks * CT * kPairs * 2048) : 0, 0x00020000);
+        (void)wdesc;
         int pct0 = 0;            // first cout tile of the unit the plan stands at
+        int wct0 = 0;            // WARM: the same for units of WN * NW tiles
+        (void)wct0;
         __amdgpu_buffer_rsrc_t xdesc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0, 0x00020000);
         unsigned cpk[NIT];       // id | ih << 8 | iw << 16
 #pragma unroll
@@ -578,6 +598,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
             int cb_, b_, od_, oh_, ow_;                                                                 \
             MVSGI_DECODE(UNIT, cb_, b_, od_, oh_, ow_)                                                  \
             pct0 = cb_ * NW < CT - NW ? cb_ * NW : CT - NW;                                             \
+            wct0 = cb_ * (WN * NW) < CT - WN * NW ? cb_ * (WN * NW) : (CT > WN * NW ? CT - WN * NW : 0);  /* first of the unit's WN * NW cout tiles */ \
             const int id0_ = od_ * SD - KD / 2, ih0_ = oh_ * S - 1, iw0_ = ow_ * S - 1;                 \
             const int bbase_ = ((id0_ * a.Hin + ih0_) * a.Win + iw0_) * a.Cin * 4;                      \
             _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                        \
@@ -607,6 +628,13 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
         if constexpr (WLDS) {                                                                           \
             const char* ws_ = wsrc + ((long long)cc2 * CT + pct0) * (kPairs * 2048);                     \
             _Pragma("unroll") for (int it = 0; it < WNIT; ++it) WPRE[it] = *reinterpret_cast<const f32x4*>(ws_ + it * 4096); \
+        }
+#define MVSGI_WARM_ISSUE()      /* WARM: the weight slice of unit (k2, cc2), NW tiles in a row, through L2 into a dummy KiB of LDS */ \
+        if constexpr (WARM) {                                                                           \
+            const unsigned wo_ = (unsigned)(((long long)cc2 * CT + wct0) * (kPairs * 2048)) + (unsigned)((wave - 4) * 1024 + lane * 16); \
+            _Pragma("unroll") for (int it = 0; it < WN * NW * kPairs * 2048 / 4096; ++it)               \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wdesc, (__attribute__((address_space(3))) void*)(ldsb + WARM_LDS + (wave - 4) * 1024), \
+                                                         16, wo_ + it * 4096u, 0, 0, 0);                \
         }
 #define MVSGI_WPUT(WPRE, DST)                                                                           \
         if constexpr (WLDS) {                                                                           \
@@ -645,6 +673,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
 #define MVSGI_STEP(NEW, OKNEW, OLD, OKOLD, DST, DOPUT, WNEW, WOLD)                                      \
         {                                                                                               \
             MVSGI_ISSUE_BEGIN()                                                                         \
+            MVSGI_WARM_ISSUE()                                                                          \
             MVSGI_WISSUE(WNEW)                                                                          \
             if (DOPUT) { MVSGI_WPUT(WOLD, DST) }                                                        \
             _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                        \
@@ -720,6 +749,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
 #undef MVSGI_ISSUE
 #undef MVSGI_WISSUE
 #undef MVSGI_WPUT
+#undef MVSGI_WARM_ISSUE
 #undef MVSGI_PUT
 #undef MVSGI_ISSUE_BEGIN
 #undef MVSGI_ISSUE1
@@ -1245,7 +1275,8 @@ template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD 
 int launch_bf16x3(ConvArgs a, hipStream_t st) {
     constexpr int ITD = (TD - 1) * (KD == 1 ? 1 : S) + KD, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
     constexpr int ROWP = V32 ? ((ITW * kVSB + 255) / 256) * 256 : ITW * kVSB;
-    constexpr size_t lds_bytes = (size_t)2 * (ITD * ITH * ROWP + (WLDS ? NW * pairs_of(KD) * 2048 : 0));   // double-buffered image (+ weight slice)
+    constexpr bool WARM = MVSGI_WARM && KD == 3 && !UPS && !PLANE && !V32 && !WLDS && S == 1 && MW * NW <= 2;      // (conv3d_x3_body)
+    constexpr size_t lds_bytes = (size_t)2 * (ITD * ITH * ROWP + (WLDS ? NW * pairs_of(KD) * 2048 : 0)) + (WARM ? 4096 : 0);   // double-buffered image (+ weight slice) (+ the warm-up's dummy KiB per producer wave)
     static_assert(lds_bytes <= 160 * 1024, "LDS images too large");
     void (*kern)(ConvArgs);
     if constexpr (F16) kern = conv3d_f16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32, WLDS>;
