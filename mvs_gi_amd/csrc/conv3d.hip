@@ -317,6 +317,7 @@ const char* const kVariantNames[] = {
 #endif
     "conv3d_bf16x3_kernel<2, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, false>",
     "conv3d_bf16x3_kernel<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>",
+    "conv3d_bf16x3_kernel<1, 2, 2, 2, 1, 4, 16, 1, 3, false, false, false, false>",
     "conv3d_bf16x3_kernel<2, 1, 4, 1, 2, 4, 8, 2, 3, false, false, false, false>",
     "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 8, 2, 3, false, false, false, false>",
     "conv3d_bf16x3_kernel<2, 2, 2, 2, 2, 4, 8, 2, 3, false, false, false, false>",
@@ -330,6 +331,7 @@ const char* const kVariantNames[] = {
     "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, true, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 4, 1, 4, 4, 16, 1, 3, true, false, false, false>",
     "conv3d_bf16x3_kernel<2, 2, 4, 1, 2, 4, 16, 1, 3, true, false, false, false>", "conv3d_bf16x3_kernel<3, 4, 4, 1, 4, 4, 16, 1, 3, true, false, false, false>",
     "conv3d_bf16x3_kernel<2, 4, 2, 2, 2, 4, 16, 1, 3, true, false, false, false>", "conv3d_bf16x3_kernel<3, 4, 2, 2, 2, 4, 16, 1, 3, true, false, false, false>",
+    "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 2, 16, 1, 3, true, false, false, false>",
     "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, false, true, false, false>", "conv3d_bf16x3_kernel<1, 4, 4, 1, 4, 4, 16, 1, 3, true, true, false, false>",
     "conv3d_bf16x3_kernel<1, 2, 4, 1, 4, 4, 16, 1, 3, false, false, true, false>", "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 16, 1, 3, false, false, true, false>",
     "conv3d_bf16x3_kernel<1, 4, 2, 2, 4, 4, 16, 1, 3, false, false, true, false>",
@@ -362,7 +364,7 @@ int select_variant_up2(const ConvArgs& a, int w_layout) {
     const long long mid = (long long)a.B * mvsgi::cdiv(a.Do, 2) * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
 #ifdef MVSGI_EXPERIMENTAL
     if (const char* f = mvsgi::exp_env("MVSGI_B3U_FORCE")) {
-        static const struct { const char* n; int v; } tab[] = {{"N32", B3U_N32}, {"N32_M", B3U_N32_M}, {"N48", B3U_N48}, {"N64", B3U_N64}, {"N96", B3U_N96}};
+        static const struct { const char* n; int v; } tab[] = {{"N32", B3U_N32}, {"N32_M", B3U_N32_M}, {"N48", B3U_N48}, {"N64", B3U_N64}, {"N96", B3U_N96}, {"N32_TB", B3U_N32_TB}};
         for (const auto& t : tab) if (!strcmp(f, t.n)) return t.v;
     }
 #endif
@@ -370,6 +372,11 @@ int select_variant_up2(const ConvArgs& a, int w_layout) {
     if (CT == 2) return big >= 384 ? B3U_N32 : B3U_N32_M;
     if (CT == 3) return B3U_N48;
     if (CT % 6 == 0 && mid * (CT / 6) >= 384) return B3U_N96;
+    // a launch that 64-voxel bricks x 32 couts cover in ONE round of the chip (an up block at one frame): waves as (voxel half, cout
+    // tile), as B3_N32_TB below.  128 -> 64 onto [4,20,80] x 1 frame: 50 units of B3U_N64 30.2 us, 200 of these 17.2; 384 -> 192 onto
+    // [2,10,40]: 77.6 -> 40.7; two frames 30.5 / 29.4, four 34.4 / 56.2 (tools/up2_small_probe.py)
+    if (CT % 2 == 0 && (long long)a.B * mvsgi::cdiv(a.Do, 2) * mvsgi::cdiv(a.Ho, 2) * mvsgi::cdiv(a.Wo, 16) * (CT / 2) <= mvsgi::device_cus())
+        return B3U_N32_TB;
     return B3U_N64;
 }
 
@@ -439,14 +446,14 @@ int select_variant(const ConvArgs& a, int impl) {
         const long long big = (long long)a.B * mvsgi::cdiv(a.Do, 4) * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
         const long long mid = (long long)a.B * mvsgi::cdiv(a.Do, 2) * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
         if (CT == 1) return B3_N16;
-        if (CT == 2) return big >= 384 ? B3_N32 : B3_N32_S;
+        if (CT == 2) return big >= 384 ? B3_N32 : B3_N32_TB;      // (B3_N32_S until round 6: see the small-launch rule below)
         if (CT == 3) return B3_N48;
         const bool h5ok = a.Ho % 5 == 0 && a.Ho % 4 != 0;
 #ifdef MVSGI_EXPERIMENTAL
         if (const char* f = mvsgi::exp_env("MVSGI_B3_FORCE")) {       // force a variant by its enum name suffix (tools/ only)
             static const struct { const char* n; int v; } tab[] = {{"N64", B3_N64}, {"N64_H5", B3_N64_H5}, {"N96", B3_N96}, {"N96_H5", B3_N96_H5},
                 {"N128_P", B3_N128_P}, {"N128_PH5", B3_N128_PH5}, {"N192_PH5", B3_N192_PH5}, {"N64_S", B3_N64_S},
-                {"N16_T", B3_N16_T}, {"N32_T", B3_N32_T}, {"N16_TW", B3_N16_TW}, {"N32_S", B3_N32_S}};
+                {"N16_T", B3_N16_T}, {"N32_T", B3_N32_T}, {"N16_TW", B3_N16_TW}, {"N32_S", B3_N32_S}, {"N32_TB", B3_N32_TB}};
             for (const auto& t : tab) if (!strcmp(f, t.n)) return t.v;
         }
 #endif
@@ -476,11 +483,17 @@ int select_variant(const ConvArgs& a, int impl) {
         // 128 -> 128 [2,10,40] x 1: 13.2 / 18.9 / 20.0, x 2: 23.1 / 18.8 / 19.9, x 4: 32.6 / 34.5 / 20.2 -- round 3's rule picked
         // the variant with AT LEAST 256 units instead (x 4: 35.4 us).  The 16-cout units take their weight slice through LDS
         // (conv3d_bf16x3.hpp, WLDS: the four consumer waves share it; 13.2 -> 12.7 us).
+        // Round 6: the 32-cout units as (voxel half, cout tile) waves (B3_N32_TB) instead of four waves on both cout tiles (B3_N32_T):
+        // in-kernel stamps of the latter (tools/stamp_probe.py) showed a slice's 84 MFMAs per wave (1344 cycles) taking 4200 -- each
+        // of the four waves fetching the SAME 4 weight fragments per slot, 16 KiB per slot and CU through a vector-memory path that
+        // returns 64 B per clock.  Two waves per cout tile halve that (8 KiB of weights, 16 KiB of LDS reads per slot: balanced):
+        // 64 -> 64 x 1 frame 12.5 -> 9.7 us, x 2: 20.7 -> 15.4; 128 -> 128 x 2: 19.4 -> 13.9, x 8: 50.5 -> 34.9 (N64_S: 36.8).  It takes
+        // a launch whenever its rounds cost less than the 64-cout units' (a round of it ~ 0.7 of theirs).
         const long long tiny = (long long)a.B * a.Do * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
         const long long cus = mvsgi::device_cus();
-        if (tiny * CT <= cus) return B3_N16_TW;
-        if (tiny * mvsgi::cdiv(CT, 2) <= cus) return B3_N32_T;
-        return B3_N64_S;
+        if (tiny * CT <= cus) return B3_N16_TW;                 // (128 -> 128 [2,10,40] x 1 frame: 13.2 us against B3_N32_TB's 13.7)
+        const long long rounds32 = mvsgi::cdiv(tiny * mvsgi::cdiv(CT, 2), cus), rounds64 = mvsgi::cdiv(tiny * mvsgi::cdiv(CT, 4), cus);
+        return 2 * rounds32 <= 3 * rounds64 ? B3_N32_TB : B3_N64_S;
     }
     if (a.stride == 1) {
         if (CT == 1) return V_S1_N16_B256;

@@ -358,6 +358,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
 #else
 #define STAMP()
 #endif
+    STAMP()      // kernel entry (stamp 0 of every wave; the exit stamp is its last)
 
 // digit order of a unit id above the w-tile: D before H (bricks stacked along D share halo planes and stay an XCD round apart)
 // or, in the -DMVSGI_ORDER_HD diagnostic build, H before D (round 1's order)
@@ -1254,6 +1255,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
 #undef MVSGI_MFMAS
     }
 #undef MVSGI_DECODE
+    STAMP()
 #undef STAMP
     if constexpr (F16) sf_sat_report(a.sat, kSatSplit, satm, 65504.f);
 }

@@ -5,7 +5,7 @@ enum Variant {
     V_DIRECT1, V_DIRECT4, V_HEAD,
     V_S1_N16_B256, V_S1_N32_B256, V_S1_N32_B64, V_S1_N64_B128, V_S1_N64_B64, V_S2_N32_B64, V_S2_N64_B64,
     // split-bf16 kernel: 16-wide bricks (conflict-free LDS reads); N = couts per workgroup
-    B3_N16, B3_N32, B3_N48, B3_N64, B3_N64_H5, B3_N96, B3_N96_H5, B3_N128_P, B3_N128_PH5, B3_N192_PH5, B3_N32_S, B3_N64_S, B3_N16_T, B3_N32_T, B3_N16_TW, B3_S2_N32, B3_S2_N32B, B3_S2_N64, B3_S2_N96, B3_S2_N128, B3_S2_N192,
+    B3_N16, B3_N32, B3_N48, B3_N64, B3_N64_H5, B3_N96, B3_N96_H5, B3_N128_P, B3_N128_PH5, B3_N192_PH5, B3_N32_S, B3_N64_S, B3_N16_T, B3_N32_T, B3_N16_TW, B3_N32_TB, B3_S2_N32, B3_S2_N32B, B3_S2_N64, B3_S2_N96, B3_S2_N128, B3_S2_N192,
 #ifdef MVSGI_EXPERIMENTAL
     // stride-2 bricks 2 x 2 x 16 (the W variants; round 6): a 16-voxel tile is 16 outputs of ONE row, whose stride-2 fragment reads
     // walk the 16 sixteen-byte units of a bank row with stride 10 (all even) while their pair partners, an odd number of units away,
@@ -15,7 +15,7 @@ enum Variant {
     B3_S2W_N32B, B3_S2W_N64, B3_S2W_N96, B3_S2W_N128, B3_S2W_N192,
 #endif
     // split-bf16 kernel with the trilinear x2 upsample fused into its producers (even bricks only)
-    B3U_N16, B3U_N32, B3U_N32_M, B3U_N48, B3U_N64, B3U_N96,
+    B3U_N16, B3U_N32, B3U_N32_M, B3U_N48, B3U_N64, B3U_N96, B3U_N32_TB,
     // Cout == 16 plane schedule (weights from mvsgi_conv3d_pack_weights_bf16x3_c16), plain and fused-upsample
     B3P_N16, B3PU_N16,
     // 32x32x16 schedule (Cout % 32 == 0, stride 1; weights from mvsgi_conv3d_pack_weights_bf16x3_v32), plain / fused upsample
