@@ -470,9 +470,40 @@ int select_variant(const ConvArgs& a, int impl) {
         if (CT % 6 == 0 && h5ok && !mvsgi::exp_env("MVSGI_NO_H5") &&
             (long long)a.B * mvsgi::cdiv(a.Do, 2) * (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16) * (CT / 6) >= 384) return B3_N96_H5;
         if (CT % 6 == 0 && mid * (CT / 6) >= 384) return B3_N96;
+        static const bool h5 = !mvsgi::exp_env("MVSGI_NO_H5");
+        const long long cus = mvsgi::device_cus();
+        // A launch of a few rounds (2 ... 24 frames of the (16, 32) regulator's levels 1 and 2: under four rounds of the 128-voxel x
+        // 64-cout units): a workgroup fills a CU, the launch runs in rounds of one unit per CU, and WHICH unit shape puts the launch
+        // into the fewest, fullest rounds changes with every frame count -- the variant of the lowest estimated time instead of unit
+        // thresholds.  A unit of Cin / 16 slices takes a + b * slices; a further round of a launch 0.85 of its first (measured per
+        // launch, hipGraph of 20, profiles/r06_mid_batch_units_probe.txt; us):
+        //   64 -> 64 [4,20,80]   x 3: 23.1 (TB) / 23.7 (64_S) / 19.0 (N64) / 22.5 (N64_H5);  x 4: 29.8 / 24.3 / 19.8 / 22.9;
+        //                        x 6: 39.2 / 35.2 / 34.7 / 24.8;  x 12: 73.7 / 55.7 / 50.9 / 45.6
+        //   128 -> 128 [2,10,40] x 4: 25.9 / 21.1 / 29.3 / 36.7;  x 8: 37.7 / 38.6 / 29.5 / 36.7;  x 16: 63.9 / 57.3 / 56.8 / 37.8
+        // (the rules below picked 64_S, 64_S, 64_S, N64 and 64_S, TB, 64_S there).  CT % 6 == 0 layers keep their 96-cout rules.
+        if (CT % 4 == 0 && CT % 6 != 0 && mid * (CT / 4) < 4 * cus && !mvsgi::exp_env("MVSGI_NO_UNIT_COST")) {
+            const long long tiny = (long long)a.B * a.Do * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
+            if (tiny * CT <= cus) return B3_N16_TW;             // one round of 16-cout units with the weight slice in LDS (below)
+            const long long slices = a.Cin / 16;
+            struct Cand { int v; long long units, a_ns, b_ns; };
+            const Cand cand[] = {
+                {B3_N32_TB, tiny * (CT / 2), 5700, 1000},
+                {B3_N64_S, tiny * (CT / 4), 6600, 1700},
+                {B3_N64, mid * (CT / 4), 8700, 2600},
+                {B3_N64_H5, (h5 && a.Ho % 5 == 0) ? (long long)a.B * mvsgi::cdiv(a.Do, 2) * (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16) * (CT / 4) : 0, 8400, 3500},
+            };
+            int best = B3_N64;
+            long long best_cost = -1;
+            for (const Cand& c : cand) {
+                if (c.units <= 0) continue;
+                const long long rounds = mvsgi::cdiv(c.units, cus);
+                const long long cost = (c.a_ns + c.b_ns * slices) * (100 + 85 * (rounds - 1));
+                if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = c.v; }
+            }
+            return best;
+        }
         // planes whose height is a multiple of 5 but not of 4 (the 10 x 40 planes of UNet level 2): 2 x 5 x 16 bricks cover them
         // exactly where 2 x 4 x 16 ones pad 10 rows to 12 (17 % of the MFMAs) and stage 7 % more halo per voxel
-        static const bool h5 = !mvsgi::exp_env("MVSGI_NO_H5");
         if (h5 && h5ok && (long long)a.B * mvsgi::cdiv(a.Do, 2) * (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16) * mvsgi::cdiv(CT, 4) >= 384)
             return B3_N64_H5;
         if (mid * mvsgi::cdiv(CT, 4) >= 384) return B3_N64;
@@ -490,7 +521,6 @@ int select_variant(const ConvArgs& a, int impl) {
         // 64 -> 64 x 1 frame 12.5 -> 9.7 us, x 2: 20.7 -> 15.4; 128 -> 128 x 2: 19.4 -> 13.9, x 8: 50.5 -> 34.9 (N64_S: 36.8).  It takes
         // a launch whenever its rounds cost less than the 64-cout units' (a round of it ~ 0.7 of theirs).
         const long long tiny = (long long)a.B * a.Do * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);
-        const long long cus = mvsgi::device_cus();
         if (tiny * CT <= cus) return B3_N16_TW;                 // (128 -> 128 [2,10,40] x 1 frame: 13.2 us against B3_N32_TB's 13.7)
         const long long rounds32 = mvsgi::cdiv(tiny * mvsgi::cdiv(CT, 2), cus), rounds64 = mvsgi::cdiv(tiny * mvsgi::cdiv(CT, 4), cus);
         return 2 * rounds32 <= 3 * rounds64 ? B3_N32_TB : B3_N64_S;

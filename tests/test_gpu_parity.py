@@ -183,7 +183,10 @@ CONV_SHAPES = [
     (1, 96, 192, 3, 6, 10, 2, False, 0.01),
     (1, 64, 32, 5, 7, 9, 1, False, 1.0),        # identity activation
     (32, 128, 128, 2, 10, 40, 1, True, 0.01),   # UNet level 2 at 32 frames: the 2 x 5 x 16 brick variant (H a multiple of 5, not of 4)
-    (32, 64, 64, 3, 15, 21, 1, True, 0.01),     # the same variant, ragged in D and W
+    (32, 64, 64, 3, 15, 21, 1, True, 0.01),     # ragged in D and W (two rounds of 2 x 4 x 16 bricks by the unit-cost rule)
+    (40, 64, 64, 3, 15, 21, 1, True, 0.01),     # ... 2 x 5 x 16 bricks, ragged in D and W
+    (6, 64, 64, 4, 20, 80, 1, True, 0.01),      # UNet level 1 at six frames: 2 x 5 x 16 bricks put the launch into one round
+    (8, 128, 128, 2, 10, 40, 1, True, 0.01),    # UNet level 2 at eight frames: 2 x 4 x 16 bricks, one round
     (32, 32, 96, 4, 10, 40, 1, True, 0.01),     # 96-cout units on 2 x 5 x 16 bricks (the fint96 regulators' level 2 at D = 16)
     (24, 32, 128, 1, 10, 40, 1, True, 0.01),    # one-plane volume (E8's level 2): 1 x 5 x 16 bricks, 128-cout units
     (64, 16, 192, 1, 10, 40, 1, False, 0.01),   # ... 192-cout units
@@ -200,10 +203,11 @@ EXPECTED_VARIANT = {        # (B, Cin, Cout, D, H, W) -> brick / unit shape the 
     (1, 16, 32, 8, 16, 16): "<1, 2, 2, 2, 2, 4, 8, 2", (1, 16, 32, 7, 9, 13): "<1, 2, 2, 2, 2, 4, 8, 2",       # stride 2, 32 couts
     (1, 128, 128, 2, 5, 9): "<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>",      # one frame: 16-cout units, weights through LDS
     (2, 64, 64, 4, 8, 16): "<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>",
-    (32, 128, 128, 2, 10, 40): "<2, 5, 2, 2, 2, 5, 16", (32, 64, 64, 3, 15, 21): "<2, 5, 2, 2, 2, 5, 16",
+    (32, 128, 128, 2, 10, 40): "<2, 5, 2, 2, 2, 5, 16", (32, 64, 64, 3, 15, 21): "<2, 4, 2, 2, 2, 4, 16",      # (two full rounds of 2 x 4 x 16 bricks: the unit-cost rule)
     (32, 32, 96, 4, 10, 40): "<3, 5, 2, 2, 2, 5, 16", (24, 32, 128, 1, 10, 40): "<2, 5, 1, 4, 1, 5, 16",
     (64, 16, 192, 1, 10, 40): "<3, 5, 1, 4, 1, 5, 16", (96, 16, 128, 1, 7, 21): "<2, 4, 1, 4, 1, 4, 16",
     (1, 32, 384, 1, 10, 40): "<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>", (2, 32, 384, 1, 10, 40): "<1, 2, 2, 2, 1, 4, 16, 1, 3, false, false, false, false>",     # 32-cout units: waves as (voxel half, cout tile)
+    (40, 64, 64, 3, 15, 21): "<2, 5, 2, 2, 2, 5, 16", (6, 64, 64, 4, 20, 80): "<2, 5, 2, 2, 2, 5, 16", (8, 128, 128, 2, 10, 40): "<2, 4, 2, 2, 2, 4, 16",
     (1, 64, 64, 4, 20, 80): "<1, 2, 2, 2, 1, 4, 16, 1, 3, false, false, false, false>", (2, 64, 64, 4, 20, 80): "<2, 2, 2, 2, 1, 4, 16, 1, 3, false, false, false, false>",
     (64, 16, 96, 8, 16, 24): "<3, 2, 2, 2, 2, 4, 8, 2", (48, 32, 128, 7, 17, 23): "<2, 4, 1, 4, 2, 4, 8, 2", (64, 16, 192, 8, 16, 24): "<3, 4, 1, 4, 2, 4, 8, 2",
 }
@@ -295,7 +299,7 @@ def test_conv3d_f16x3_vs_oracle(shape):
     assert err <= 5e-6, err
     yb = H.conv3d(xg, wg, H.pack_conv_weights_bf16x3(wg), _g(scale), _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3)
     eb = _rel(_ncdhw(yb), yref)                          # ... and closer than the bf16 split on the same problem (a residual of
-    assert eb >= err and (res or eb > 1.5 * err), (eb, err)   # O(1) beside the x 0.01 convolution hides both splits behind the final add's rounding)
+    assert (eb > 1.5 * err) if not res else (eb >= err or err <= 2.5e-7), (eb, err)   # O(1) beside the x 0.01 convolution hides both splits behind the final add's rounding: an ulp either way)
     if Cout == 16 and stride == 1:
         wpc, un = H.pack_conv_weights_f16x3(wg, H.CONV_BF16X3_C16)
         yp = H.conv3d(xg, wg, wpc, _g(scale) * un, _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3_C16 | H.CONV_F16)

@@ -13,8 +13,11 @@ from mvs_gi_amd import hip_ops as H  # noqa: E402
 dev = "cuda:0"
 rng = np.random.default_rng(0)
 variants = sys.argv[1].split() if len(sys.argv) > 1 else ["", "N16_T", "N16_TW", "N32_T", "N64_S"]
-for shape in [(1, 64, 64, 4, 20, 80), (1, 128, 128, 2, 10, 40), (2, 64, 64, 4, 20, 80), (2, 128, 128, 2, 10, 40), (4, 64, 64, 4, 20, 80),
-              (4, 128, 128, 2, 10, 40), (8, 64, 64, 4, 20, 80), (8, 128, 128, 2, 10, 40), (1, 32, 48, 3, 7, 19)]:
+SHAPES = [(1, 64, 64, 4, 20, 80), (1, 128, 128, 2, 10, 40), (2, 64, 64, 4, 20, 80), (2, 128, 128, 2, 10, 40), (4, 64, 64, 4, 20, 80),
+          (4, 128, 128, 2, 10, 40), (8, 64, 64, 4, 20, 80), (8, 128, 128, 2, 10, 40), (1, 32, 48, 3, 7, 19)]
+if len(sys.argv) > 2:       # "B cin cout d h w; B cin cout d h w; ..."
+    SHAPES = [tuple(int(v) for v in t.split()) for t in sys.argv[2].split(";") if t.strip()]
+for shape in SHAPES:
     B, cin, cout, d, h, w = shape
     x = torch.from_numpy(rng.standard_normal((B, d, h, w, cin), dtype=np.float32)).to(dev)
     wt = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32)).to(dev)
