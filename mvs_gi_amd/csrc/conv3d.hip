@@ -369,7 +369,14 @@ int select_variant_up2(const ConvArgs& a, int w_layout) {
     }
 #endif
     if (CT == 1) return c16_layout ? B3PU_N16 : B3U_N16;
-    if (CT == 2) return big >= 384 ? B3U_N32 : B3U_N32_M;
+    if (CT == 2) {
+        // 256-voxel bricks from 384 units on; below, whichever of the two brick sizes makes the cheaper rounds (a 256-voxel unit takes
+        // ~1.6 x a 128-voxel one, a further round 0.85 of the first): 64 -> 32 onto [8,40,160] at one frame 24.2 -> 20.4 us (200 units
+        // in one round against 400 in two; tools/up2_small_probe.py)
+        if (big >= 384) return B3U_N32;
+        const long long cus = mvsgi::device_cus(), r32 = mvsgi::cdiv(big, cus), rm = mvsgi::cdiv(mid, cus);
+        return 157 * (100 + 85 * (r32 - 1)) < 100 * (100 + 85 * (rm - 1)) ? B3U_N32 : B3U_N32_M;
+    }
     if (CT == 3) return B3U_N48;
     if (CT % 6 == 0 && mid * (CT / 6) >= 384) return B3U_N96;
     // a launch that 64-voxel bricks x 32 couts cover in ONE round of the chip (an up block at one frame): waves as (voxel half, cout
@@ -440,7 +447,11 @@ int select_variant(const ConvArgs& a, int impl) {
             if (CT % 6 == 0 && s2bricks * (CT / 6) >= 512) return B3_S2_N96;
             // 32 couts per unit: waves as (voxel half, cout tile) -- 2 weight + 4 activation fragment reads per slot and wave instead of
             // 4 + 2 with all four waves on both cout tiles (4cam-32's first layer, 64 -> 32: 1362 -> 1221 us per 16 frames)
-            return CT <= 3 ? B3_S2_N32B : B3_S2_N64;
+            // ... and for a launch they cover in one round of the chip where the 64-cout units leave most CUs idle (round 6, hipGraph
+            // of 20 launches: 64 -> 128 from [4,20,80] at 1 / 2 / 4 frames 13.7 -> 10.8, 13.9 -> 11.2, 14.6 -> 12.8 us, at 8: 16.0 vs 21.4;
+            // 32 -> 64 from [8,40,160] at one frame 10.0 -> 8.9, at two 10.9 vs 13.4)
+            if (CT <= 3 || s2bricks * mvsgi::cdiv(CT, 2) <= mvsgi::device_cus()) return B3_S2_N32B;
+            return B3_S2_N64;
         }
         // workgroups a 256-voxel (N <= 48) / 128-voxel (N >= 64) brick decomposition would give
         const long long big = (long long)a.B * mvsgi::cdiv(a.Do, 4) * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16);

@@ -196,6 +196,8 @@ CONV_SHAPES = [
     (64, 16, 192, 8, 16, 24, 2, False, 0.0),    # stride 2 in 192-cout units
     (1, 32, 384, 1, 10, 40, 1, True, 0.01),     # one-plane volume at ONE frame (E8's level 2 on the latency path): the small-launch rule, not 18 128-cout units
     (2, 32, 384, 1, 10, 40, 1, False, 0.01),    # ... at two frames
+    (1, 64, 128, 4, 20, 80, 2, False, 0.01),    # the stride-2 conv into UNet level 2 at one frame: 60 units of 32 couts, not 30 of 64
+    (8, 64, 128, 4, 20, 80, 2, False, 0.01),    # ... at eight frames: 64-cout units
     (1, 64, 64, 4, 20, 80, 1, True, 0.01),      # UNet level 1 at one frame: 200 units of 32 couts, waves as (voxel half, cout tile)
     (2, 64, 64, 4, 20, 80, 1, True, 0.01),      # ... at two frames: 200 units of 64 couts
 ]
@@ -208,6 +210,7 @@ EXPECTED_VARIANT = {        # (B, Cin, Cout, D, H, W) -> brick / unit shape the 
     (64, 16, 192, 1, 10, 40): "<3, 5, 1, 4, 1, 5, 16", (96, 16, 128, 1, 7, 21): "<2, 4, 1, 4, 1, 4, 16",
     (1, 32, 384, 1, 10, 40): "<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>", (2, 32, 384, 1, 10, 40): "<1, 2, 2, 2, 1, 4, 16, 1, 3, false, false, false, false>",     # 32-cout units: waves as (voxel half, cout tile)
     (40, 64, 64, 3, 15, 21): "<2, 5, 2, 2, 2, 5, 16", (6, 64, 64, 4, 20, 80): "<2, 5, 2, 2, 2, 5, 16", (8, 128, 128, 2, 10, 40): "<2, 4, 2, 2, 2, 4, 16",
+    (1, 64, 128, 4, 20, 80): "<1, 2, 2, 2, 2, 4, 8, 2", (8, 64, 128, 4, 20, 80): "<2, 2, 2, 2, 2, 4, 8, 2",
     (1, 64, 64, 4, 20, 80): "<1, 2, 2, 2, 1, 4, 16, 1, 3, false, false, false, false>", (2, 64, 64, 4, 20, 80): "<2, 2, 2, 2, 1, 4, 16, 1, 3, false, false, false, false>",
     (64, 16, 96, 8, 16, 24): "<3, 2, 2, 2, 2, 4, 8, 2", (48, 32, 128, 7, 17, 23): "<2, 4, 1, 4, 2, 4, 8, 2", (64, 16, 192, 8, 16, 24): "<3, 4, 1, 4, 2, 4, 8, 2",
 }
@@ -399,6 +402,7 @@ def test_conv3d_v32_schedule_vs_oracle(shape):
     (1, 128, 64, 2, 10, 40, True),     # an up block at one frame: 2 x 2 x 16 bricks x 32 couts (200 units, one round of the chip)
     (2, 128, 64, 2, 10, 40, True),     # ... at two frames: 2 x 4 x 16 bricks x 64 couts
     (1, 64, 64, 3, 5, 9, False),       # the one-round units on ragged bricks
+    (1, 64, 32, 4, 20, 80, True),      # the last up block at one frame: 200 units of 4 x 4 x 16 in one round, not 400 of 2 x 4 x 16 in two
 ])
 def test_conv3d_fused_upsample_vs_interpolate_then_conv(shape):
     """mvsgi_conv3d_up2_f32 == conv3d(F.interpolate(x, scale 2, trilinear, align_corners=False)):
@@ -420,6 +424,8 @@ def test_conv3d_fused_upsample_vs_interpolate_then_conv(shape):
     rg = _g(r).permute(0, 2, 3, 4, 1).contiguous() if res else None
     got = H.conv3d_up2(xg, H.pack_conv_weights_bf16x3(_g(w)), _g(scale), _g(shift), res=rg, neg_slope=0.01)
     assert "true" in H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout)
+    if shape[:6] == (1, 64, 32, 4, 20, 80):
+        assert "<2, 4, 4, 1, 4, 4, 16," in H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout)
     if shape[:6] in ((1, 128, 64, 2, 10, 40), (2, 128, 64, 2, 10, 40)):
         assert ("<1, 2, 2, 2, 2, 2, 16," if B == 1 else "<2, 4, 2, 2, 2, 4, 16,") in H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout)
     assert _rel(_ncdhw(got), yref) <= 1e-4

@@ -13,7 +13,7 @@ from mvs_gi_amd import hip_ops as H  # noqa: E402
 
 dev = "cuda:0"
 rng = np.random.default_rng(0)
-variants = sys.argv[1].split(",") if len(sys.argv) > 1 else ["", "N64", "N32_TB", "N32_M"]
+variants = sys.argv[1].split(",") if len(sys.argv) > 1 else ["", "N64", "N32_TB", "N32_M", "N32"]
 # (frames, Cin, Cout, low-resolution D, H, W): the up blocks of the (16, 32) regulator at 16 and 8 candidates, and a ragged one
 for shape in [(1, 128, 64, 2, 10, 40), (2, 128, 64, 2, 10, 40), (4, 128, 64, 2, 10, 40), (8, 128, 64, 2, 10, 40),
               (1, 64, 32, 4, 20, 80), (2, 64, 32, 4, 20, 80), (4, 64, 32, 4, 20, 80),
