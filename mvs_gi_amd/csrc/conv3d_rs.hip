@@ -237,21 +237,31 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
         a.wp += (long long)((up_pd * 4 + cls) * 2 + up_ph) * a.wp_set;
     }
 
-    // ---- weights: resident in the accumulator half of the register file for the whole launch ----
-    bf16x8 wh[kPairs][2], wl[kPairs][2];
-#pragma unroll
-    for (int p = 0; p < kPairs; ++p)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bf16x8* q = a.wp + ((long long)((s * 2 + j) * kPairs + p) * 2) * 64 + lane;
-            wh[p][j] = q[0];
-            wl[p][j] = q[64];
-        }
-#pragma unroll
-    for (int p = 0; p < kPairs; ++p)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) asm volatile("" : "+a"(wh[p][j]), "+a"(wl[p][j]));
+#ifdef MVSGI_RS_STAMPS
+    unsigned long long t_entry_;      // kernel entry: stamp 0 of every wave (tools/rs_stamps.py)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry_)::"memory");
+#endif
+#ifndef MVSGI_RS_WEIGHTS_FIRST
+#define MVSGI_RS_WEIGHTS_FIRST 1      // 0: the weights behind the plans and the first image's requests (an experiment, round 6: slower)
+#endif
+#define RS_PIN_WEIGHTS()                                                                             \
+    _Pragma("unroll") for (int p = 0; p < kPairs; ++p)                                               \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
+            const bf16x8* q = a.wp + ((long long)((s * 2 + j) * kPairs + p) * 2) * 64 + lane;        \
+            wh[p][j] = q[0];                                                                         \
+            wl[p][j] = q[64];                                                                        \
+        }                                                                                            \
+    _Pragma("unroll") for (int p = 0; p < kPairs; ++p)                                               \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) asm volatile("" : "+a"(wh[p][j]), "+a"(wl[p][j])); \
     __builtin_amdgcn_sched_barrier(0);
+    // ---- weights: resident in the accumulator half of the register file for the whole launch.  At one frame a workgroup lives for
+    // one or two bricks and this prologue is a fifth of it (in-kernel stamps of [8,40,160] x 1 frame, tools/rs_stamps.py 1 8 40 160,
+    // cycles from kernel entry: weights resident 5.0-7.8 k, first image landed 8.8 k, phase 0 from 10.2 k, two phases of 6.9 k,
+    // two drain phases of 3.5 k, exit 33.9 k).  Requesting them BEHIND the first image's LDS-DMA (-DMVSGI_RS_WEIGHTS_FIRST=0) is
+    // slower: the plans (3.4 k cycles of index arithmetic) then run before any request is out instead of under the weights'
+    // 56 KiB per wave -- phase 0 from 11.9 k, exit 35.5 k ----
+    bf16x8 wh[kPairs][2], wl[kPairs][2];
+    if constexpr (MVSGI_RS_WEIGHTS_FIRST) { RS_PIN_WEIGHTS() }
 
     // ---- fragment read bases (image 0, HI region); group 0 = own tiles (rows 2s, 2s+1), group 1 = the partner's ----
     const int chunk = 2 * s + half;
@@ -456,6 +466,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 #define STAMP()
 #endif
 
+#ifdef MVSGI_RS_STAMPS
+    if (a.dbg && blockIdx.x == 8) { if (lane == 0) a.dbg[wave * 256] = t_entry_; nst = 1; }
+    STAMP()      // plans made (MVSGI_RS_WEIGHTS_FIRST: weights resident too)
+#endif
     // prologue: image 0 <- brick 0
     {
         const auto dsc_x = RS_DESC(a.x, c0, true);
@@ -463,6 +477,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 #pragma unroll
         for (int m = 0; m < DPW; ++m) RS_DMA(m)
     }
+    if constexpr (!MVSGI_RS_WEIGHTS_FIRST) { RS_PIN_WEIGHTS() }
     f32x4 acc[8], keepA[4], keepB[4], snd[4];
     bf16x8 xh[2][4], xl[2][4];
     u32x4 rres[4], rresB[4], outp[4];
@@ -477,6 +492,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
     for (int i = 0; i < 4; ++i) xh[1][i] = xl[1][i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    STAMP()      // image 0 landed
 
     f32x4 pt0, pt1, pt2, pt3, t0, t1_, t2, t3;
     u32x2 sa0, sb0, sa1, sb1, sa2, sb2, sa3, sb3, hb0, hb1, hb2, hb3, lb0, lb1, lb2, lb3;
@@ -535,6 +551,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
         if constexpr (F16 && !OUTF32) satm = ph < 2 ? 0.f : satm;
         __builtin_amdgcn_s_barrier();
     }
+    STAMP()      // kernel exit
     if constexpr (F16 && !OUTF32) sf_sat_report(a.sat, kSatSplit, satm, kF16Max);
 #undef RS_VOY
 #undef RS_VOC
@@ -545,6 +562,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_rs32_kernel(RsArgs a) {
 #undef RS_RES_OFF
 #undef t1
 #undef STAMP
+#undef RS_PIN_WEIGHTS
 #undef RS_MF
 #undef RS_MF0
 #undef RS_W_LO

@@ -15,11 +15,17 @@ if "MVSGI_LIB" not in os.environ:
     if r.returncode or not rows:
         print(r.stdout[-2000:], r.stderr[-4000:])
         sys.exit(1)
+    if os.environ.get("RS_RAW"):      # short launches (a frame): [entry, weights resident, image 0 landed, then per phase: start, body end, waits done ..., exit]
+        for l in rows[-4:]:
+            t = [int(v) for v in l.split(":")[1].split()]
+            print(l.split(":")[0], [v for i, v in enumerate(t) if v > 0 or i == 0])
+        sys.exit(0)
     import statistics
     names = ["barrier -> phase start", "phase body (336 MFMAs + fillers)", "wait vmcnt / lgkmcnt"]
     for l in rows[-4:]:
         t = [int(v) for v in l.split(":")[1].split()]
         t = [v for i, v in enumerate(t) if v > 0 or i == 0]
+        t = t[3:]                                   # (entry, weights resident, image 0 landed)
         ph = [t[i:i + 3] for i in range(0, len(t) - 3, 3)]
         segs = [[] for _ in range(3)]
         for k in range(3, len(ph) - 3):          # steady-state phases only
