@@ -454,7 +454,7 @@ def kernels_block(agg, hbm_agg):
     return out
 
 
-def read_pmc_traffic(kernel_name: str):
+def read_pmc_traffic(kernel_name: str, frames_per_launch=None):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc summary
     (profiles/pmc_traffic.json, written by tools/summarize_rocprof.py from separate --pmc passes of this same
     command): (bytes | None, source string).  The counters cannot be read from inside the process, so the line
@@ -472,8 +472,13 @@ def read_pmc_traffic(kernel_name: str):
             parts = [one(next((n for n in d if n.startswith(k.split(" (")[0].strip())), "")) if p_ is None else p_
                      for k, p_ in zip(key.split(" + "), parts)]
             v = sum(parts) if all(p_ is not None for p_ in parts) else None
-        return v, (f"profiles/pmc_traffic.json ({d.get('_source', 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE')})"
-                   if v is not None else None)
+        src = f"profiles/pmc_traffic.json ({d.get('_source', 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE')})"
+        # the counters were taken at the summary's own launch size; these kernels' bytes are proportional to the frames of a launch
+        n0 = d.get("_frames_per_launch")
+        if v is not None and n0 and frames_per_launch and int(n0) != int(frames_per_launch):
+            v = v * frames_per_launch / n0
+            src += f", measured at {n0} frames per launch and scaled to this run's {frames_per_launch}"
+        return v, (src if v is not None else None)
     except Exception:
         return None, None
 
@@ -857,7 +862,7 @@ def main(argv=None):
     achieved = dflops / (dms * 1e-3) / 1e12
     conv_ms = sum(v[2] for v in agg.values())
     attributed_ms = conv_ms + sum(v[2] for v in hbm_agg.values())
-    traffic, traffic_src = read_pmc_traffic(dname)
+    traffic, traffic_src = read_pmc_traffic(dname, B // S if args.config == "G16V" else None)      # (the committed summary is G16V's)
     res = {
         "metric": f"stereo frames/sec/GPU ({cfg.tag}, {cfg.num_cams}-cam, D={cfg.num_cands}) + inv-dist L1 vs reference",
         "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -19,7 +19,7 @@ $S stats $R/$OUT/stats_s1 $R/$OUT/bench_streams1_b128_kernel_stats.txt > /dev/nu
 rm -rf $R/$OUT/stats_s1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_fetch -- $B1 --steps 2 --warmup 1 --settle-seconds 0 > $R/$OUT/pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_write -- $B1 --steps 2 --warmup 1 --settle-seconds 0 > $R/$OUT/pmc_write.log 2>&1 || exit 1
-$S pmc $R/$OUT/pmc_traffic_G16V.json $R/$OUT/pmc_fetch $R/$OUT/pmc_write > /dev/null || exit 1
+PMC_FRAMES_PER_LAUNCH=128 $S pmc $R/$OUT/pmc_traffic_G16V.json $R/$OUT/pmc_fetch $R/$OUT/pmc_write > /dev/null || exit 1
 rm -rf $R/$OUT/pmc_fetch $R/$OUT/pmc_write
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES"
 SQ2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VALU"
@@ -42,6 +42,6 @@ for T in G16VV E8 4cam-32 E16-48-96; do
   rm -rf $R/$OUT/stats_$T
   timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pf_$T -- $C --steps 2 --warmup 1 --settle-seconds 0 > $R/$OUT/pf_$T.log 2>&1 || exit 1
   timeout -k 10 280 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pw_$T -- $C --steps 2 --warmup 1 --settle-seconds 0 > $R/$OUT/pw_$T.log 2>&1 || exit 1
-  $S pmc $R/$OUT/pmc_traffic_$T.json $R/$OUT/pf_$T $R/$OUT/pw_$T > /dev/null || exit 1
+  PMC_FRAMES_PER_LAUNCH=$PB $S pmc $R/$OUT/pmc_traffic_$T.json $R/$OUT/pf_$T $R/$OUT/pw_$T > /dev/null || exit 1
   rm -rf $R/$OUT/pf_$T $R/$OUT/pw_$T
 done

@@ -54,8 +54,10 @@ def pmc(dirs, out):
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
             e["hbm_bytes_per_launch"] = (2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024
         res[k] = e
+    if os.environ.get("PMC_FRAMES_PER_LAUNCH"):       # frames per launch of the profiled command (bench.py scales to its own launch size)
+        res["_frames_per_launch"] = int(os.environ["PMC_FRAMES_PER_LAUNCH"])
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
-    for k, e in sorted(res.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch", 0))[:12]:
+    for k, e in sorted(((k, e) for k, e in res.items() if isinstance(e, dict)), key=lambda kv: -kv[1].get("hbm_bytes_per_launch", 0))[:12]:
         print(k[:70], {n: round(v, 1) for n, v in e.items()})
 
 
