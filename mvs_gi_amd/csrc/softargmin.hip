@@ -320,6 +320,9 @@ extern "C" int mvsgi_softargmin_div_f32(const float* costs, const float* inv_idx
         int xt = (int)(mvsgi::cdiv(W, 4) * 4);
         const int xt_max = (D > 16 && D <= 32) ? 512 : 640;      // = the kernels' launch bounds
         while ((xt > xt_max || (size_t)2 * D * (xt + 4) * 4 > 64 * 1024) && xt > 64) xt = (int)(mvsgi::cdiv(xt / 2, 4) * 4);
+        // a frame or two: narrower column tiles until the launch has a workgroup or two per CU (one [16, 80, 320] frame: 81 workgroups
+        // of 320 columns -> 324 of 80)
+        while (xt > 64 && (long long)B * (H + 1) * mvsgi::cdiv(W, xt) < 2ll * mvsgi::device_cus()) xt = (int)(mvsgi::cdiv(xt / 2, 4) * 4);
         const size_t lds = (size_t)2 * D * (xt + 4) * 4;
         const long long xtiles = mvsgi::cdiv(W, xt), units = (long long)B * (H + 1) * xtiles;
         if (lds <= 160 * 1024 && units < (1ll << 31)) {
