@@ -48,8 +48,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="G16V")
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step, cut into --streams equal parts (round 6: 2 x 128; "
-                    "2 x 64 until round 5: 6231 vs 6300 frames/s alternating on one box)")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step, cut into --streams equal parts.  Default: G16V 256 "
+                    "(round 6: 2 x 128; 2 x 64 until round 5: 6231 vs 6300 frames/s alternating on one box); the other configurations "
+                    "--streams x their EXTRA_CONFIGS part size (4cam-32 at 256 frames does not fit the card)")
     ap.add_argument("--streams", type=int, default=2,
                     help="independent parts of a step's batch, each on its own HIP stream inside the step's one hipGraph "
                          "(StreamedHotPath: one part's kernel tails are filled by the other's launches; MI355X, G16V: 2 x 64 frames "
@@ -76,7 +77,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-dump-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-dump", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-dump-configs", default="", help=argparse.SUPPRESS)      # tags whose oracle frame is dumped beside --cpu-dump
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.batch is None:
+        args.batch = 256 if args.config == "G16V" else dict(EXTRA_CONFIGS).get(args.config, 32) * max(1, args.streams)
+    return args
 
 
 # ------------------------------------------------------------------------------------------

@@ -323,6 +323,8 @@ const char* const kVariantNames[] = {
     "conv3d_bf16x3_kernel<2, 2, 2, 2, 2, 4, 8, 2, 3, false, false, false, false>",
     "conv3d_bf16x3_kernel<3, 2, 2, 2, 2, 4, 8, 2, 3, false, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 1, 4, 2, 4, 8, 2, 3, false, false, false, false>",
     "conv3d_bf16x3_kernel<3, 4, 1, 4, 2, 4, 8, 2, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<2, 5, 2, 2, 2, 10, 8, 1, 3, false, false, false, false>", "conv3d_bf16x3_kernel<3, 5, 2, 2, 2, 10, 8, 1, 3, false, false, false, false>",
+    "conv3d_bf16x3_kernel<2, 5, 1, 4, 1, 10, 8, 1, 3, false, false, false, false>", "conv3d_bf16x3_kernel<3, 5, 1, 4, 1, 10, 8, 1, 3, false, false, false, false>",
 #ifdef MVSGI_EXPERIMENTAL
     "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 2, 16, 2, 3, false, false, false, false>", "conv3d_bf16x3_kernel<2, 2, 2, 2, 2, 2, 16, 2, 3, false, false, false, false>",
     "conv3d_bf16x3_kernel<3, 2, 2, 2, 2, 2, 16, 2, 3, false, false, false, false>", "conv3d_bf16x3_kernel<2, 4, 1, 4, 2, 2, 16, 2, 3, false, false, false, false>",
@@ -460,11 +462,14 @@ int select_variant(const ConvArgs& a, int impl) {
         if (CT == 2) return big >= 384 ? B3_N32 : B3_N32_TB;      // (B3_N32_S until round 6: see the small-launch rule below)
         if (CT == 3) return B3_N48;
         const bool h5ok = a.Ho % 5 == 0 && a.Ho % 4 != 0;
+        // 10 x 8 bricks instead of 5 x 16 where they cover the plane exactly and the 16-wide ones pad it (round 6; 128 -> 128 on
+        // [2,10,40] x 128 frames: 231 -> 203 us, x 64: 126 -> 114, x 32: 81 -> 76; tools/wlds_probe.py, same sums bit for bit)
+        const bool w8 = a.Ho % 10 == 0 && a.Wo % 16 == 8 && !mvsgi::exp_env("MVSGI_NO_W8");
 #ifdef MVSGI_EXPERIMENTAL
         if (const char* f = mvsgi::exp_env("MVSGI_B3_FORCE")) {       // force a variant by its enum name suffix (tools/ only)
             static const struct { const char* n; int v; } tab[] = {{"N64", B3_N64}, {"N64_H5", B3_N64_H5}, {"N96", B3_N96}, {"N96_H5", B3_N96_H5},
                 {"N128_P", B3_N128_P}, {"N128_PH5", B3_N128_PH5}, {"N192_PH5", B3_N192_PH5}, {"N64_S", B3_N64_S},
-                {"N16_T", B3_N16_T}, {"N32_T", B3_N32_T}, {"N16_TW", B3_N16_TW}, {"N32_S", B3_N32_S}, {"N32_TB", B3_N32_TB}};
+                {"N16_T", B3_N16_T}, {"N32_T", B3_N32_T}, {"N16_TW", B3_N16_TW}, {"N32_S", B3_N32_S}, {"N32_TB", B3_N32_TB}, {"N64_W8", B3_N64_W8}, {"N96_W8", B3_N96_W8}, {"N128_PW8", B3_N128_PW8}, {"N192_PW8", B3_N192_PW8}};
             for (const auto& t : tab) if (!strcmp(f, t.n)) return t.v;
         }
 #endif
@@ -472,14 +477,14 @@ int select_variant(const ConvArgs& a, int impl) {
         // half of its MFMAs on padding.  All four consumer waves share the brick's voxel tiles and split the couts.
         if (a.Do == 1 && CT >= 8 && CT % 4 == 0) {
             const long long rows5 = (long long)a.B * (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16);
-            if (h5ok && CT % 12 == 0 && rows5 * (CT / 12) >= 384) return B3_N192_PH5;
+            if (h5ok && CT % 12 == 0 && rows5 * (CT / 12) >= 384) return w8 ? B3_N192_PW8 : B3_N192_PH5;
             // (a launch of a few frames has too few of these units to fill the chip -- 384 -> 384 at one frame: 18 workgroups walking
             // 24 slices each -- and falls through to the small-launch rule below)
-            if (h5ok && CT % 8 == 0 && rows5 * (CT / 8) >= mvsgi::device_cus() / 2) return B3_N128_PH5;
+            if (h5ok && CT % 8 == 0 && rows5 * (CT / 8) >= mvsgi::device_cus() / 2) return w8 ? B3_N128_PW8 : B3_N128_PH5;
             if (CT % 8 == 0 && (long long)a.B * mvsgi::cdiv(a.Ho, 4) * mvsgi::cdiv(a.Wo, 16) * (CT / 8) >= 384) return B3_N128_P;
         }
         if (CT % 6 == 0 && h5ok && !mvsgi::exp_env("MVSGI_NO_H5") &&
-            (long long)a.B * mvsgi::cdiv(a.Do, 2) * (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16) * (CT / 6) >= 384) return B3_N96_H5;
+            (long long)a.B * mvsgi::cdiv(a.Do, 2) * (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16) * (CT / 6) >= 384) return w8 ? B3_N96_W8 : B3_N96_H5;
         if (CT % 6 == 0 && mid * (CT / 6) >= 384) return B3_N96;
         static const bool h5 = !mvsgi::exp_env("MVSGI_NO_H5");
         const long long cus = mvsgi::device_cus();
@@ -501,7 +506,8 @@ int select_variant(const ConvArgs& a, int impl) {
                 {B3_N32_TB, tiny * (CT / 2), 5700, 1000},
                 {B3_N64_S, tiny * (CT / 4), 6600, 1700},
                 {B3_N64, mid * (CT / 4), 8700, 2600},
-                {B3_N64_H5, (h5 && a.Ho % 5 == 0) ? (long long)a.B * mvsgi::cdiv(a.Do, 2) * (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16) * (CT / 4) : 0, 8400, 3500},
+                {w8 ? B3_N64_W8 : B3_N64_H5, !(h5 && a.Ho % 5 == 0) ? 0 : (long long)a.B * mvsgi::cdiv(a.Do, 2) * (CT / 4) *
+                                                 (w8 ? (a.Ho / 10) * (a.Wo / 8) : (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16)), 8400, 3500},
             };
             int best = B3_N64;
             long long best_cost = -1;
@@ -516,7 +522,7 @@ int select_variant(const ConvArgs& a, int impl) {
         // planes whose height is a multiple of 5 but not of 4 (the 10 x 40 planes of UNet level 2): 2 x 5 x 16 bricks cover them
         // exactly where 2 x 4 x 16 ones pad 10 rows to 12 (17 % of the MFMAs) and stage 7 % more halo per voxel
         if (h5 && h5ok && (long long)a.B * mvsgi::cdiv(a.Do, 2) * (a.Ho / 5) * mvsgi::cdiv(a.Wo, 16) * mvsgi::cdiv(CT, 4) >= 384)
-            return B3_N64_H5;
+            return w8 ? B3_N64_W8 : B3_N64_H5;
         if (mid * mvsgi::cdiv(CT, 4) >= 384) return B3_N64;
         // a few frames (latency path): 64-voxel bricks.  A workgroup of this kernel fills a CU (8 waves x 256 registers), so a launch
         // runs in rounds of one unit per CU and a round costs its unit's Cin / 16 slices end to end: the couts per unit are the

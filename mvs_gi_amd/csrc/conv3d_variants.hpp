@@ -6,6 +6,8 @@ enum Variant {
     V_S1_N16_B256, V_S1_N32_B256, V_S1_N32_B64, V_S1_N64_B128, V_S1_N64_B64, V_S2_N32_B64, V_S2_N64_B64,
     // split-bf16 kernel: 16-wide bricks (conflict-free LDS reads); N = couts per workgroup
     B3_N16, B3_N32, B3_N48, B3_N64, B3_N64_H5, B3_N96, B3_N96_H5, B3_N128_P, B3_N128_PH5, B3_N192_PH5, B3_N32_S, B3_N64_S, B3_N16_T, B3_N32_T, B3_N16_TW, B3_N32_TB, B3_S2_N32, B3_S2_N32B, B3_S2_N64, B3_S2_N96, B3_S2_N128, B3_S2_N192,
+    // 10 x 8 bricks: planes 8 mod 16 wide and a multiple of 10 high without padding (the siblings of the *_H5 / *_PH5 variants)
+    B3_N64_W8, B3_N96_W8, B3_N128_PW8, B3_N192_PW8,
 #ifdef MVSGI_EXPERIMENTAL
     // stride-2 bricks 2 x 2 x 16 (the W variants; round 6): a 16-voxel tile is 16 outputs of ONE row, whose stride-2 fragment reads
     // walk the 16 sixteen-byte units of a bank row with stride 10 (all even) while their pair partners, an odd number of units away,

@@ -185,6 +185,8 @@ CONV_SHAPES = [
     (32, 128, 128, 2, 10, 40, 1, True, 0.01),   # UNet level 2 at 32 frames: the 2 x 5 x 16 brick variant (H a multiple of 5, not of 4)
     (32, 64, 64, 3, 15, 21, 1, True, 0.01),     # ragged in D and W (two rounds of 2 x 4 x 16 bricks by the unit-cost rule)
     (40, 64, 64, 3, 15, 21, 1, True, 0.01),     # ... 2 x 5 x 16 bricks, ragged in D and W
+    (40, 64, 64, 3, 10, 24, 1, True, 0.01),     # 2 x 10 x 8 bricks (W = 8 mod 16, H a multiple of 10), ragged in D
+    (48, 32, 96, 2, 15, 40, 1, True, 0.01),     # W = 8 mod 16 but H not a multiple of 10: 2 x 5 x 16 bricks stay
     (6, 64, 64, 4, 20, 80, 1, True, 0.01),      # UNet level 1 at six frames: 2 x 5 x 16 bricks put the launch into one round
     (8, 128, 128, 2, 10, 40, 1, True, 0.01),    # UNet level 2 at eight frames: 2 x 4 x 16 bricks, one round
     (32, 32, 96, 4, 10, 40, 1, True, 0.01),     # 96-cout units on 2 x 5 x 16 bricks (the fint96 regulators' level 2 at D = 16)
@@ -205,10 +207,11 @@ EXPECTED_VARIANT = {        # (B, Cin, Cout, D, H, W) -> brick / unit shape the 
     (1, 16, 32, 8, 16, 16): "<1, 2, 2, 2, 2, 4, 8, 2", (1, 16, 32, 7, 9, 13): "<1, 2, 2, 2, 2, 4, 8, 2",       # stride 2, 32 couts
     (1, 128, 128, 2, 5, 9): "<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>",      # one frame: 16-cout units, weights through LDS
     (2, 64, 64, 4, 8, 16): "<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>",
-    (32, 128, 128, 2, 10, 40): "<2, 5, 2, 2, 2, 5, 16", (32, 64, 64, 3, 15, 21): "<2, 4, 2, 2, 2, 4, 16",      # (two full rounds of 2 x 4 x 16 bricks: the unit-cost rule)
-    (32, 32, 96, 4, 10, 40): "<3, 5, 2, 2, 2, 5, 16", (24, 32, 128, 1, 10, 40): "<2, 5, 1, 4, 1, 5, 16",
-    (64, 16, 192, 1, 10, 40): "<3, 5, 1, 4, 1, 5, 16", (96, 16, 128, 1, 7, 21): "<2, 4, 1, 4, 1, 4, 16",
+    (32, 128, 128, 2, 10, 40): "<2, 5, 2, 2, 2, 10, 8", (32, 64, 64, 3, 15, 21): "<2, 4, 2, 2, 2, 4, 16",      # (two full rounds of 2 x 4 x 16 bricks: the unit-cost rule)
+    (32, 32, 96, 4, 10, 40): "<3, 5, 2, 2, 2, 10, 8", (24, 32, 128, 1, 10, 40): "<2, 5, 1, 4, 1, 10, 8",
+    (64, 16, 192, 1, 10, 40): "<3, 5, 1, 4, 1, 10, 8", (96, 16, 128, 1, 7, 21): "<2, 4, 1, 4, 1, 4, 16",
     (1, 32, 384, 1, 10, 40): "<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>", (2, 32, 384, 1, 10, 40): "<1, 2, 2, 2, 1, 4, 16, 1, 3, false, false, false, false>",     # 32-cout units: waves as (voxel half, cout tile)
+    (40, 64, 64, 3, 10, 24): "<2, 5, 2, 2, 2, 10, 8", (48, 32, 96, 2, 15, 40): "<3, 5, 2, 2, 2, 5, 16",
     (40, 64, 64, 3, 15, 21): "<2, 5, 2, 2, 2, 5, 16", (6, 64, 64, 4, 20, 80): "<2, 5, 2, 2, 2, 5, 16", (8, 128, 128, 2, 10, 40): "<2, 4, 2, 2, 2, 4, 16",
     (1, 64, 128, 4, 20, 80): "<1, 2, 2, 2, 2, 4, 8, 2", (8, 64, 128, 4, 20, 80): "<2, 2, 2, 2, 2, 4, 8, 2",
     (1, 64, 64, 4, 20, 80): "<1, 2, 2, 2, 1, 4, 16, 1, 3, false, false, false, false>", (2, 64, 64, 4, 20, 80): "<2, 2, 2, 2, 1, 4, 16, 1, 3, false, false, false, false>",
