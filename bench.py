@@ -458,12 +458,15 @@ def kernels_block(agg, hbm_agg):
     return out
 
 
-def read_pmc_traffic(kernel_name: str, frames_per_launch=None):
+def read_pmc_traffic(kernel_name: str, frames_per_launch=None, tag: str = "G16V"):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc summary
     (profiles/pmc_traffic.json, written by tools/summarize_rocprof.py from separate --pmc passes of this same
     command): (bytes | None, source string).  The counters cannot be read from inside the process, so the line
     says where the number comes from instead of presenting it as measured in this run."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    # one summary per configuration (a kernel NAME serves different layers in different configurations): G16V's is
+    # profiles/pmc_traffic.json, the others' profiles/pmc_traffic_<tag>.json; none -> null
+    fn = "pmc_traffic.json" if tag == "G16V" else f"pmc_traffic_{tag}.json"
+    p = os.path.join(ROOT, "profiles", fn)
     try:
         d = json.load(open(p))
         key = kernel_name.split(" [")[0]
@@ -476,7 +479,7 @@ def read_pmc_traffic(kernel_name: str, frames_per_launch=None):
             parts = [one(next((n for n in d if n.startswith(k.split(" (")[0].strip())), "")) if p_ is None else p_
                      for k, p_ in zip(key.split(" + "), parts)]
             v = sum(parts) if all(p_ is not None for p_ in parts) else None
-        src = f"profiles/pmc_traffic.json ({d.get('_source', 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE')})"
+        src = f"profiles/{fn} ({d.get('_source', 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE')})"
         # the counters were taken at the summary's own launch size; these kernels' bytes are proportional to the frames of a launch
         n0 = d.get("_frames_per_launch")
         if v is not None and n0 and frames_per_launch and int(n0) != int(frames_per_launch):
@@ -866,7 +869,7 @@ def main(argv=None):
     achieved = dflops / (dms * 1e-3) / 1e12
     conv_ms = sum(v[2] for v in agg.values())
     attributed_ms = conv_ms + sum(v[2] for v in hbm_agg.values())
-    traffic, traffic_src = read_pmc_traffic(dname, B // S if args.config == "G16V" else None)      # (the committed summary is G16V's)
+    traffic, traffic_src = read_pmc_traffic(dname, B // S, args.config)
     res = {
         "metric": f"stereo frames/sec/GPU ({cfg.tag}, {cfg.num_cams}-cam, D={cfg.num_cands}) + inv-dist L1 vs reference",
         "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -10,6 +10,8 @@ mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-extras"
 S="python3 $R/tools/summarize_rocprof.py"
+# PART=1: the G16V passes only; PART=2: the other configurations only (a gpurun call is at most 20 minutes)
+if [ "$PART" != 2 ]; then
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_default -- $B --steps 5 --warmup 2 > $R/$OUT/stats_default.log 2>&1 || exit 1
 $S stats $R/$OUT/stats_default $R/$OUT/bench_default_kernel_stats.txt > /dev/null || exit 1
 rm -rf $R/$OUT/stats_default
@@ -33,6 +35,8 @@ timeout -k 10 280 python3 $R/bench.py --mode bf16x3 --steps 20 --warmup 5 --no-c
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_bf16 -- $BF --streams 1 --batch 128 --steps 5 --warmup 2 > $R/$OUT/stats_bf16.log 2>&1 || exit 1
 $S stats $R/$OUT/stats_bf16 $R/$OUT/bench_streams1_b128_bf16x3_kernel_stats.txt > /dev/null || exit 1
 rm -rf $R/$OUT/stats_bf16
+fi
+[ "$PART" = 1 ] && exit 0
 for T in G16VV E8 4cam-32 E16-48-96; do
   PB=32; [ $T = E8 ] && PB=64; [ $T = 4cam-32 ] && PB=16
   C="$B --config $T --streams 1 --batch $PB"
