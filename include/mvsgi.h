@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MVSGI_ABI_VERSION 2   /* 2: mvsgi_saturation_flags; the symbol set of round 5 (Winograd level, *_fmt entry points) */
+#define MVSGI_ABI_VERSION 3   /* 3: mvsgi_conv3d_d32_applies + MVSGI_CONV_BF16X3_D32; 2: mvsgi_saturation_flags; the symbol set of round 5 */
 
 typedef void* mvsgi_stream_t;
 
@@ -54,6 +54,12 @@ typedef void* mvsgi_stream_t;
 #define MVSGI_CONV_BF16X3_V32 5 /* the same arithmetic on v_mfma_f32_32x32x16_bf16 (one tap x 16 channels per MFMA, half the
                                    issue-port time per flop) where mvsgi_conv3d_v32_applies(); weights from
                                    mvsgi_conv3d_pack_weights_bf16x3_v32                                                  */
+#define MVSGI_CONV_BF16X3_D32 6 /* the same arithmetic on 32-channel slices: the K = 32 of an MFMA is ONE tap of 32 input channels
+                                   (27 k-steps per 32 channels; the tap-pair layout of MVSGI_CONV_BF16X3 needs 28, its 14th pair
+                                   half empty) and a unit has half as many slices to synchronise on.  Cin % 32 == 0, stride 1, launches
+                                   large enough for a 128- / 160-voxel brick: where mvsgi_conv3d_d32_applies(); weights from
+                                   mvsgi_conv3d_pack_weights_split(layout = MVSGI_CONV_BF16X3_D32 [| MVSGI_CONV_F16]), sized by
+                                   mvsgi_conv3d_packed_weight_bytes_bf16x3.  Same products, another summation order.          */
 
 #define MVSGI_CONV_F16 0x100   /* FLAG, OR-ed into MVSGI_CONV_BF16X3 / _C16 / _V32 (impl of mvsgi_conv3d_f32, w_layout of
                                   mvsgi_conv3d_up2_f32, layout of mvsgi_conv3d_pack_weights_split): the same kernels and packed
@@ -177,6 +183,9 @@ int mvsgi_conv3d_up2_f32(const float* x, const void* w_packed, int w_layout /* M
 const char* mvsgi_conv3d_up2_variant_f32(int B, int Cin, int Dl, int Hl, int Wl, int Cout, int w_layout);
 /* 32x32x16-MFMA schedule (MVSGI_CONV_BF16X3_V32): Cout % 32 == 0, stride 1, enough bricks to fill the chip */
 int mvsgi_conv3d_v32_applies(int B, int Cin, int Din, int Hin, int Win, int Cout, int stride);
+/* 1 when mvsgi_conv3d_f32 accepts impl = MVSGI_CONV_BF16X3_D32 [| MVSGI_CONV_F16] for this problem (replaces nothing in the reference:
+ * a second schedule of BaseConvBlk3d's convolution, dsta_mvs/model/common/common_modules.py:107-115) */
+int mvsgi_conv3d_d32_applies(int B, int Cin, int Din, int Hin, int Win, int Cout, int stride);
 size_t mvsgi_conv3d_packed_weight_bytes_bf16x3_v32(int Cout, int Cin);
 int mvsgi_conv3d_pack_weights_bf16x3_v32(const float* w_oidhw, void* w_packed, int Cout, int Cin, mvsgi_stream_t stream);
 /* weights of a Cout == 16 layer in the plane-schedule layout (MVSGI_CONV_BF16X3_C16) */

@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVSGI_LIB", os.path.join(_HERE, "libmvsgi_hip.so"))   # MVSGI_LIB: diagnostic builds
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MvsgiLibraryMissing(RuntimeError):
@@ -45,6 +45,7 @@ SIGNATURES = {
     "mvsgi_conv3d_up2_f32": (c_int, [_P, _P, c_int] + [_P] * 4 + [c_int] * 6 + [c_float, _P]),
     "mvsgi_conv3d_up2_variant_f32": (c_char_p, [c_int] * 7),
     "mvsgi_conv3d_v32_applies": (c_int, [c_int] * 7),
+    "mvsgi_conv3d_d32_applies": (c_int, [c_int] * 7),
     "mvsgi_conv3d_packed_weight_bytes_bf16x3_v32": (c_size_t, [c_int, c_int]),
     "mvsgi_conv3d_pack_weights_bf16x3_v32": (c_int, [_P, _P, c_int, c_int, _P]),
     "mvsgi_conv3d_packed_weight_bytes_bf16x3_c16": (c_size_t, [c_int]),

@@ -338,6 +338,9 @@ const char* const kVariantNames[] = {
     "conv3d_bf16x3_kernel<1, 2, 4, 1, 4, 4, 16, 1, 3, false, false, true, false>", "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 16, 1, 3, false, false, true, false>",
     "conv3d_bf16x3_kernel<1, 4, 2, 2, 4, 4, 16, 1, 3, false, false, true, false>",
     "conv3d_bf16x3_kernel<1, 2, 4, 1, 4, 4, 16, 1, 3, true, false, true, false>", "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 16, 1, 3, true, false, true, false>",
+#define MVSGI_B3D(V, ...) "conv3d_bf16x3_d32_kernel<" #__VA_ARGS__ ">",
+#include "conv3d_b3d_variants.inc"
+#undef MVSGI_B3D
 };
 static_assert(sizeof(kVariantNames) / sizeof(kVariantNames[0]) == V_COUNT, "one name per variant");
 
@@ -389,6 +392,31 @@ int select_variant_up2(const ConvArgs& a, int w_layout) {
     return B3U_N64;
 }
 
+int select_variant(const ConvArgs& a, int impl);
+
+// MVSGI_CONV_BF16X3_D32: the 32-channel-slice sibling of the variant the split kernel would take for this problem (Cin % 32 == 0,
+// stride 1, a launch large enough for one of the bricks of conv3d_b3d_variants.inc), or V_COUNT (no error text)
+int d32_variant(const ConvArgs& a) {
+    if (a.stride != 1 || a.Cin % 32 || a.Cout % 16 || mvsgi::exp_env("MVSGI_NO_D32")) return V_COUNT;
+    ConvArgs b = a;
+    static const float dummy = 0.f;
+    if (!b.wp) b.wp = reinterpret_cast<const f32x4*>(&dummy);      // (the query form has no weights)
+    switch (select_variant(b, MVSGI_CONV_BF16X3)) {
+        case B3_N64: return B3D_N64;
+        case B3_N64_H5: return B3D_N64_H5;
+        case B3_N64_W8: return B3D_N64_W8;
+        case B3_N96: return B3D_N96;
+        case B3_N96_H5: return B3D_N96_H5;
+        case B3_N96_W8: return B3D_N96_W8;
+        case B3_N128_P: return B3D_N128_P;
+        case B3_N128_PH5: return B3D_N128_PH5;
+        case B3_N128_PW8: return B3D_N128_PW8;
+        case B3_N192_PH5: return B3D_N192_PH5;
+        case B3_N192_PW8: return B3D_N192_PW8;
+        default: return V_COUNT;
+    }
+}
+
 // returns V_COUNT when the request cannot be served (error text already set)
 int select_variant(const ConvArgs& a, int impl) {
     const bool mfma_ok = (a.Cin % 16 == 0) && (a.Cout % 16 == 0);
@@ -410,6 +438,12 @@ int select_variant(const ConvArgs& a, int impl) {
         if (!a.wp) { mvsgi::fail("mvsgi_conv3d_f32: tiled path needs w_packed"); return V_COUNT; }
         if (a.Cout != 32 && mvsgi::exp_env("MVSGI_V32B")) return B3V_N64B;      // 128-voxel waves (experimental builds)
         return a.Cout == 32 ? B3V_N32 : B3V_N64;
+    }
+    if (impl == MVSGI_CONV_BF16X3_D32) {
+        const int v = d32_variant(a);
+        if (v == V_COUNT) mvsgi::fail("mvsgi_conv3d_f32: the 32-channel-slice kernels do not apply to this problem (see mvsgi_conv3d_d32_applies)");
+        else if (!a.wp) { mvsgi::fail("mvsgi_conv3d_f32: tiled path needs w_packed"); return V_COUNT; }
+        return v;
     }
     if (impl == MVSGI_CONV_BF16X3 && !mfma_ok) impl = MVSGI_CONV_AUTO;   // head / odd channels: exact paths
     if (impl == MVSGI_CONV_AUTO) impl = (mfma_ok || head_ok) ? MVSGI_CONV_MFMA : MVSGI_CONV_DIRECT;
@@ -566,6 +600,9 @@ int launch_variant(int v, const ConvArgs& a, hipStream_t st) {
 #define MVSGI_B3(V, ...) case V: return launch_bf16x3<__VA_ARGS__>(a, st);
 #include "conv3d_b3_variants.inc"
 #undef MVSGI_B3
+#define MVSGI_B3D(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, false, false, false, false, false, true>(a, st);
+#include "conv3d_b3d_variants.inc"
+#undef MVSGI_B3D
 #ifdef MVSGI_EXPERIMENTAL      // the dispatcher's 16-cout units are B3_N16_TW; this one is the A/B reference of tools/wlds_probe.py
         case B3_N16_T: return launch_bf16x3<1, 1, 4, 1, 1, 4, 16, 1>(a, st);
 #else
@@ -606,7 +643,7 @@ int fill_args(ConvArgs& a, const float* x, const float* w_oidhw, const float* w_
 int split_flag(ConvArgs& a, int& impl, const char* who) {
     a.f16 = (impl & MVSGI_CONV_F16) != 0;
     impl &= ~MVSGI_CONV_F16;
-    MVSGI_REQUIRE(!a.f16 || impl == MVSGI_CONV_BF16X3 || impl == MVSGI_CONV_BF16X3_C16 || impl == MVSGI_CONV_BF16X3_V32,
+    MVSGI_REQUIRE(!a.f16 || impl == MVSGI_CONV_BF16X3 || impl == MVSGI_CONV_BF16X3_C16 || impl == MVSGI_CONV_BF16X3_V32 || impl == MVSGI_CONV_BF16X3_D32,
                   "%s: MVSGI_CONV_F16 goes with MVSGI_CONV_BF16X3 / _C16 / _V32 (got %d)", who, impl);
     MVSGI_REQUIRE(!a.f16 || (a.Cin % 16 == 0 && a.Cout % 16 == 0), "%s: the fp16 split needs Cin, Cout multiples of 16 (got %d, %d)", who, a.Cin, a.Cout);
     return 0;
@@ -662,6 +699,11 @@ extern "C" int mvsgi_conv3d_pack_weights_split(const float* w_oidhw, void* w_pac
         const long long total = (long long)(Cin / 16) * (Cout / 32) * 27 * 64;
         hipLaunchKernelGGL(pack_weights_bf16x3_v32_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0, mvsgi::as_stream(stream),
                            w_oidhw, wp, Cout, Cin, f16);
+    } else if (layout == MVSGI_CONV_BF16X3_D32) {
+        MVSGI_REQUIRE(Cin % 32 == 0, "mvsgi_conv3d_pack_weights_split: the 32-channel-slice layout needs Cin %% 32 == 0 (got %d)", Cin);
+        const long long total = (long long)(Cin / 32) * (Cout / 16) * 27 * 64;
+        hipLaunchKernelGGL(pack_weights_bf16x3_d32_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0, mvsgi::as_stream(stream),
+                           w_oidhw, wp, Cout, Cin, f16);
     } else {
         return mvsgi::fail("mvsgi_conv3d_pack_weights_split: layout %d is not a split-kernel layout", layout);
     }
@@ -681,6 +723,16 @@ extern "C" int mvsgi_conv3d_pack_weights_bf16x3_v32(const float* w_oidhw, void* 
     hipLaunchKernelGGL(pack_weights_bf16x3_v32_kernel, dim3((unsigned)mvsgi::cdiv(total, 256)), dim3(256), 0,
                        mvsgi::as_stream(stream), w_oidhw, reinterpret_cast<bf16x8*>(w_packed), Cout, Cin, false);
     return mvsgi::check_launch("mvsgi_conv3d_pack_weights_bf16x3_v32");
+}
+
+// 1 when mvsgi_conv3d_f32 accepts MVSGI_CONV_BF16X3_D32 for this problem (weights packed with layout MVSGI_CONV_BF16X3_D32, sized
+// by mvsgi_conv3d_packed_weight_bytes_bf16x3: 27 fragments per 32 channels where the tap-pair layout has 28)
+extern "C" int mvsgi_conv3d_d32_applies(int B, int Cin, int Din, int Hin, int Win, int Cout, int stride) {
+    ConvArgs a{};
+    static const float dummy = 0.f;
+    if (fill_args(a, &dummy, &dummy, &dummy, &dummy, &dummy, nullptr, nullptr, B, Cin, Din, Hin, Win, Cout, stride, 1.f))
+        return 0;
+    return d32_variant(a) != V_COUNT ? 1 : 0;
 }
 
 // 1 when mvsgi_conv3d_f32 / mvsgi_conv3d_up2_f32 (pass the UPSAMPLED input size) accept MVSGI_CONV_BF16X3_V32 for this problem

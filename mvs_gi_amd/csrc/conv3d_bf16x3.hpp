@@ -32,7 +32,7 @@
 //     owns a contiguous run of bricks: neighbouring halos and the cout-blocks of a brick share L2.
 #pragma once
 #ifndef MVSGI_ABL
-#define MVSGI_ABL 0   // diagnostic builds: 1 no weight loads, 2 no LDS fragment reads, 4 no split, 8 no staging, 16 no MFMA
+#define MVSGI_ABL 0   // diagnostic builds: 1 no weight loads, 2 no LDS fragment reads, 4 no split, 8 no staging, 16 no MFMA, 32 no 14th pair
 #endif
 
 #include "split_fmt.hpp"      // the range report of the fp16 split (sf_sat_acc / sf_sat_report)
@@ -177,6 +177,36 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, bf16x8* 
     wp[o + 64] = __builtin_bit_cast(bf16x8, lo);
 }
 
+// 32-channel slices (D32): [Cout][Cin][27] -> [Cin/32][Cout/16][27 taps][hi|lo][64 lanes][8 bf16]
+//   lane = (kg << 4) | i holds W[cout = ct*16 + i][cin = (2*cc + (kg & 1)) * 16 + (kg >> 1) * 8 + j][tap]: the K = 32 of an MFMA is ONE tap
+//   of two 16-channel slices (the lane groups that took the pair's second tap take the second slice) -- 27 k-steps per 32 channels
+//   where the tap-pair layout needs 28 (its 14th pair is half empty)
+__global__ void pack_weights_bf16x3_d32_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout, int Cin, bool f16 = false) {
+    const int CT = Cout / 16;
+    const long long total = (long long)(Cin / 32) * CT * 27 * 64;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    long long r = idx >> 6;
+    const int tap = (int)(r % 27);
+    r /= 27;
+    const int ct = (int)(r % CT);
+    const int cc = (int)(r / CT);
+    const int kg = lane >> 4;
+    const int co = ct * 16 + (lane & 15);
+    const int ci = (2 * cc + (kg & 1)) * 16 + (kg >> 1) * 8;
+    u16x8 hi, lo;
+    for (int j = 0; j < 8; ++j) {
+        unsigned short h_, l_;
+        split_weight(w[((long long)co * Cin + ci + j) * 27 + tap], f16, h_, l_);
+        hi[j] = h_;
+        lo[j] = l_;
+    }
+    const long long o = ((((long long)cc * CT + ct) * 27 + tap) * 2) * 64 + lane;
+    wp[o] = __builtin_bit_cast(bf16x8, hi);
+    wp[o + 64] = __builtin_bit_cast(bf16x8, lo);
+}
+
 // Cout == 16 plane schedule: [16][Cin][27] -> [Cin/16][5 pairs][3 kd][hi|lo][64 lanes][8 bf16]
 //   lane = (kg << 4) | i holds W[cout = i][cin = cc*16 + (kg>>1)*8 + j][kd][in-plane tap 2p + (kg&1)]  (tap 9: zero)
 __global__ void pack_weights_bf16x3_c16_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cin, bool f16 = false) {
@@ -272,7 +302,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // stage the unit's weight slice (NW x 28 KiB, contiguous in the packed layout) into LDS beside the activation image, once per
 // workgroup, under the same per-unit barrier; the consumers read weight fragments like activation fragments (XB-deep, restarted
 // per unit): 16 ds_read_b128 per slot and CU instead of 8 KiB of vector-memory returns.
-template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD, bool UPS, bool PLANE, bool V32, bool WLDS, bool F16>
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD, bool UPS, bool PLANE, bool V32, bool WLDS, bool F16, bool D32 = false>
 __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
     // (NW == 1: the producers stage the tiles from pct0 = min(cb * NW, CT - NW) on, the consumers clamp tile by tile -- the two agree for one tile)
     static_assert(!WLDS || (WN == 1 && KD == 3 && !UPS && !PLANE && !V32 && S == 1 && NW == 1 && MW <= 2), "LDS-staged weights: one shared cout tile, one or two voxel tiles per wave");
@@ -285,12 +315,18 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
     static_assert(WM * MW * (V32 ? 32 : 16) == TD * TH * TW, "brick must be covered by the voxel tiles");
     static_assert(KD == 3 || (KD == 1 && TD == 1), "2-D bricks are one plane thick");
     constexpr int SD = KD == 1 ? 1 : S;               // images are never strided over
-    constexpr int kTaps = KD * 9, kPairs = pairs_of(KD);
+    // D32: 32-channel slices -- an MFMA's K = 32 is one tap of TWO 16-channel sub-images (the slice's LDS image is the two side by
+    // side, sub-image 1 at +SUB; the lane groups that take a pair's second tap take the second sub-image): 27 slots per 32 channels
+    // instead of 2 x 14, half the slices (barriers) per unit.  `kPairs` is then the number of taps.
+    static_assert(!D32 || (KD == 3 && S == 1 && !UPS && !PLANE && !V32 && !WLDS), "32-channel slices: plain stride-1 3x3x3 variants only");
+    constexpr int kTaps = KD * 9, kPairs = D32 ? KD * 9 : pairs_of(KD);
     constexpr int ITD = (TD - 1) * SD + KD, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
     constexpr int IV = ITD * ITH * ITW;
-    constexpr int NIT = (IV * 4 + 255) / 256;      // staging items per producer thread and unit
+    constexpr int QB = D32 ? 3 : 2;                // a staged voxel is 1 << QB items of 4 channels
+    constexpr int NIT = (IV * (1 << QB) + 255) / 256;      // staging items per producer thread and unit
     constexpr int ROWP = V32 ? ((ITW * kVSB + 255) / 256) * 256 : ITW * kVSB;    // LDS bytes per halo row
-    constexpr int BUF = ITD * ITH * ROWP;          // bytes of one LDS image
+    constexpr int SUB = ITD * ITH * ROWP;          // bytes of one 16-channel LDS image
+    constexpr int BUF = D32 ? 2 * SUB : SUB;       // bytes of one slice's image
     // weight pipeline of the consumers: WB register buffers, fragments requested LA slots ahead.
     // A slice has NSLOT slots = the tap pairs rounded up to a multiple of WB (rotation-only slots), so
     // that every register-buffer index is a compile-time constant.
@@ -339,7 +375,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
     const bool producer = wave >= 4;
     const int CT = a.Cout / (V32 ? 32 : 16);       // cout tiles
     const int ny = (CT + WN * NW - 1) / (WN * NW);
-    const int nchunks = a.Cin / 16;
+    const int nchunks = a.Cin / (D32 ? 32 : 16);
     const int total = a.total_units;               // bricks x cout blocks
     const int G = gridDim.x;
     // units of this workgroup: ids blockIdx.x + k*G (G % 8 == 0 or G == total, so id % 8 is this
@@ -587,10 +623,10 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int e = ptid + it * 256;
-            const int v = e >> 2, q = e & 3;
+            const int v = e >> QB, q = e & ((1 << QB) - 1);
             const int iw = v % ITW, ih = (v / ITW) % ITH, id = v / (ITW * ITH);
-            const bool live = e < IV * 4;             // surplus items of the last round: halo voxel 0 again (loaded, never stored)
-            ibase[it] = live ? (((id * a.Hin + ih) * a.Win + iw) * a.Cin + q * 4) * 4 : 0;       // bytes
+            const bool live = e < IV * (1 << QB);             // surplus items of the last round: halo voxel 0 again (loaded, never stored)
+            ibase[it] = (live && !D32) ? (((id * a.Hin + ih) * a.Win + iw) * a.Cin + q * 4) * 4 : 0;       // bytes (D32: unused, see MVSGI_PLAN)
             cpk[it] = live ? (unsigned)(id | (ih << 8) | (iw << 16)) : 0u;
         }
         static_assert(ITD < 255 && ITH < 255 && ITW < 255, "packed halo coordinates");
@@ -609,7 +645,9 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
                 const bool ok = gd < (unsigned)a.Din && gh < (unsigned)a.Hin && gw < (unsigned)a.Win;   \
                 /* outside the volume: an offset the frame's buffer descriptor does not cover -- the load returns zeros (the \
                    convolution's padding) with no select behind it */                                  \
-                goff[it] = ok ? ibase[it] + bbase_ : (int)0x80000000;                                   \
+                /* D32 (twice the items per thread): the offset from the coordinates instead of a register per item */ \
+                goff[it] = !ok ? (int)0x80000000 : D32 ? (((int)gd * a.Hin + (int)gh) * a.Win + (int)gw) * a.Cin * 4 + ((ptid + it * 256) & 7) * 16 \
+                                                       : ibase[it] + bbase_;                           \
             }                                                                                           \
             xdesc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (long long)b_ * a.Din * a.Hin * a.Win * a.Cin, 0, \
                                                       a.Din * a.Hin * a.Win * a.Cin * 4, 0x00020000);  \
@@ -619,7 +657,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
 #define MVSGI_ISSUE_BEGIN()                                                                             \
         if (cc2 == 0 && k2 > 0) { MVSGI_PLAN((int)blockIdx.x + k2 * G) }
 #define MVSGI_ISSUE1(PRE, IT)                                                                           \
-        PRE[IT] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xdesc, goff[IT] + cc2 * 64, 0, 0));
+        PRE[IT] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xdesc, goff[IT] + cc2 * (D32 ? 128 : 64), 0, 0));
 #define MVSGI_ISSUE_END(OK)                                                                             \
         {                                                                                               \
             if (++cc2 == nchunks) { cc2 = 0; ++k2; }                                                    \
@@ -652,8 +690,8 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
 #define MVSGI_PUT1(PRE, OK, DST, IT)                                                                    \
         {                                                                                               \
             const int e = ptid + (IT) * 256;                                                            \
-            if (e < IV * 4) {                                                                           \
-                const int v = e >> 2, q = e & 3;                                                        \
+            if (e < IV * (1 << QB)) {                                                                   \
+                const int v = e >> QB, q = e & 3, sub_ = D32 ? ((e >> 2) & 1) * SUB : 0;                \
                 u32x2 hi, lo;                                                                           \
                 if (MVSGI_ABL & 4) {     /* diagnostic: what a pre-split input would cost the producers (no split, no mask) */ \
                     hi = u32x2{__builtin_bit_cast(unsigned, PRE[IT][0] + 0.f), __builtin_bit_cast(unsigned, PRE[IT][1] + 0.f)}; \
@@ -662,8 +700,8 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
                     split_x4<F16>(PRE[IT], hi, lo, satm);                                                      \
                 }                                                                                       \
                 const int vo_ = V32 ? (v / ITW) * ROWP + (v % ITW) * kVSB : v * kVSB;                   \
-                *reinterpret_cast<u32x2*>((DST) + vo_ + q * 8) = hi;                                    \
-                *reinterpret_cast<u32x2*>((DST) + vo_ + 32 + q * 8) = lo;                               \
+                *reinterpret_cast<u32x2*>((DST) + sub_ + vo_ + q * 8) = hi;                             \
+                *reinterpret_cast<u32x2*>((DST) + sub_ + vo_ + 32 + q * 8) = lo;                        \
             }                                                                                           \
         }
 #define MVSGI_PUT(PRE, OK, DST)                                                                         \
@@ -980,7 +1018,8 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
             const int t0_ = 2 * p_, t1_ = (2 * p_ + 1 < kTaps) ? 2 * p_ + 1 : 2 * p_;                 \
             const int o0_ = (((t0_ / 9) * ITH + (t0_ / 3) % 3) * ITW + t0_ % 3) * kVSB;               \
             const int o1_ = (((t1_ / 9) * ITH + (t1_ / 3) % 3) * ITW + t1_ % 3) * kVSB;               \
-            const int off_ = second ? o1_ : o0_;                                                      \
+            const int od_ = (((p_ / 9) * ITH + (p_ / 3) % 3) * ITW + p_ % 3) * kVSB;      /* D32: tap p_ of sub-image 0 | 1 */ \
+            const int off_ = D32 ? od_ + (second ? SUB : 0) : (second ? o1_ : o0_);                   \
             _Pragma("unroll") for (int i = (I0); i < (I1); ++i) {                                     \
                 xh[BUFI][i] = *reinterpret_cast<const bf16x8*>(img + base[i] + off_);                 \
                 xl[BUFI][i] = *reinterpret_cast<const bf16x8*>(img + base[i] + off_ + 32);            \
@@ -1167,7 +1206,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
                         for (int j = 0; j < NW; ++j)
                             rres[i][j] = *reinterpret_cast<const f32x4*>(rb + (eoff[i] >= 0 ? eoff[i] + ctc[j] * 16 : 0));
                 }
-                if (s_ < kPairs) {
+                if (s_ < kPairs - ((MVSGI_ABL & 32) ? 1 : 0)) {       // (ABL 32: without the half-empty last pair -- the bound of 32-channel slices)
                     if (XB >= 2) {
                         // one scheduling region per slot: the fragment requests of a later slot (2*NW weight
                         // loads, 2*MW LDS reads) are interleaved one per RATIO MFMAs, so their issue
@@ -1272,17 +1311,31 @@ __global__ __launch_bounds__(512, 2) void conv3d_f16x3_kernel(ConvArgs a) {
     conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32, WLDS, true>(a);
 }
 
+// the same body on 32-channel slices (D32; plain stride-1 3x3x3 bricks): kernels of their own, so that the others keep their names
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW>
+__global__ __launch_bounds__(512, 2) void conv3d_bf16x3_d32_kernel(ConvArgs a) {
+    conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, false, false, false, false, false, true>(a);
+}
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW>
+__global__ __launch_bounds__(512, 2) void conv3d_f16x3_d32_kernel(ConvArgs a) {
+    conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, false, false, false, false, true, true>(a);
+}
+
 template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false, bool PLANE = false,
-          bool V32 = false, bool WLDS = false, bool F16 = false>
+          bool V32 = false, bool WLDS = false, bool F16 = false, bool D32 = false>
 int launch_bf16x3(ConvArgs a, hipStream_t st) {
     constexpr int ITD = (TD - 1) * (KD == 1 ? 1 : S) + KD, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
     constexpr int ROWP = V32 ? ((ITW * kVSB + 255) / 256) * 256 : ITW * kVSB;
     constexpr bool WARM = MVSGI_WARM && KD == 3 && !UPS && !PLANE && !V32 && !WLDS && S == 1 && MW * NW <= 2;      // (conv3d_x3_body)
-    constexpr size_t lds_bytes = (size_t)2 * (ITD * ITH * ROWP + (WLDS ? NW * pairs_of(KD) * 2048 : 0)) + (WARM ? 4096 : 0);   // double-buffered image (+ weight slice) (+ the warm-up's dummy KiB per producer wave)
+    static_assert(!D32 || (S == 1 && KD == 3 && !UPS && !PLANE && !V32 && !WLDS), "32-channel slices: plain stride-1 3x3x3 variants");
+    constexpr size_t lds_bytes = (size_t)2 * ((D32 ? 2 : 1) * ITD * ITH * ROWP + (WLDS ? NW * pairs_of(KD) * 2048 : 0)) + (WARM ? 4096 : 0);   // double-buffered image (+ weight slice) (+ the warm-up's dummy KiB per producer wave)
     static_assert(lds_bytes <= 160 * 1024, "LDS images too large");
     void (*kern)(ConvArgs);
-    if constexpr (F16) kern = conv3d_f16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32, WLDS>;
+    if constexpr (D32 && F16) kern = conv3d_f16x3_d32_kernel<NW, MW, WM, WN, TD, TH, TW>;
+    else if constexpr (D32) kern = conv3d_bf16x3_d32_kernel<NW, MW, WM, WN, TD, TH, TW>;
+    else if constexpr (F16) kern = conv3d_f16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32, WLDS>;
     else kern = conv3d_bf16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32, WLDS>;
+    MVSGI_REQUIRE(!D32 || a.Cin % 32 == 0, "conv3d: the 32-channel-slice kernels need Cin %% 32 == 0 (got %d)", a.Cin);
     static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
     if (mvsgi::persistent_geometry(kern, 512, lds_bytes, 2, geo_cache, "conv3d(bf16x3)", geo)) return 1;

@@ -45,12 +45,15 @@ NORM3D_TYPE: Dict[str, Type[nn.Module]] = {"batch": nn.BatchNorm3d, "instance": 
 # ------------------------------------------------------------------------------------------
 # MVSGI_V32=1: 32x32x16-MFMA kernels for the Cout % 32 == 0 layers (measured on par with the 16x16x32 kernels, so off by default)
 _USE_V32 = H.exp_env("MVSGI_V32", "0") != "0"
+# MVSGI_D32=0: keep the Cin % 32 == 0 stride-1 layers of large launches on the tap-pair layout (default: 32-channel slices,
+# csrc/conv3d_bf16x3.hpp D32 -- 27 k-steps per 32 channels instead of 28 and half the slices per unit: 6-9 % of those layers)
+_USE_D32 = os.environ.get("MVSGI_D32", "1") != "0"
 
 
 class ConvLaunch:
     """Device-resident launch arguments of one BaseConvBlk3d: PyTorch-layout weight, packed
     MFMA weight (or None), per-channel scale/shift (eval BatchNorm3d or bias), stride, slope."""
-    __slots__ = ("w", "wp", "wp_b3", "wp_c16", "wp_v32", "wp_rs", "wp_s2", "wp_poly", "wp_head", "head_sc", "scale", "shift", "stride",
+    __slots__ = ("w", "wp", "wp_b3", "wp_c16", "wp_v32", "wp_d32", "wp_rs", "wp_s2", "wp_poly", "wp_head", "head_sc", "scale", "shift", "stride",
                  "neg_slope", "cin", "cout", "key", "f16")
 
     def run(self, x_ndhwc: Tensor, res: Optional[Tensor] = None, impl: Optional[int] = None) -> Tensor:
@@ -59,7 +62,7 @@ class ConvLaunch:
             B, D, Hh, W, _ = x_ndhwc.shape
             layout = H.CONV_BF16X3_C16 if self._c16() else \
                 (H.CONV_BF16X3_V32 if _USE_V32 and self.cout % 32 == 0 and H.conv3d_v32_applies(B, self.cin, D, Hh, W, self.cout, self.stride)
-                 else H.CONV_BF16X3)
+                 else (H.CONV_BF16X3_D32 if self._d32(B, D, Hh, W) else H.CONV_BF16X3))
             wp16, sc16 = self._f16(layout)
             return H.conv3d(x_ndhwc, self.w, wp16, sc16, self.shift, res=res, stride=self.stride, neg_slope=self.neg_slope,
                             impl=layout | H.CONV_F16)
@@ -71,6 +74,10 @@ class ConvLaunch:
                     impl, wp = H.CONV_BF16X3_C16, self._wp_c16()
                 elif _USE_V32 and self.cout % 32 == 0 and H.conv3d_v32_applies(B, self.cin, D, Hh, W, self.cout, self.stride):
                     impl, wp = H.CONV_BF16X3_V32, self._wp_v32()
+                elif self._d32(B, D, Hh, W):
+                    if getattr(self, "wp_d32", None) is None:
+                        self.wp_d32 = H.pack_conv_weights_bf16x3_d32(self.w)
+                    impl, wp = H.CONV_BF16X3_D32, self.wp_d32
                 else:
                     if self.wp_b3 is None:
                         self.wp_b3 = H.pack_conv_weights_bf16x3(self.w)
@@ -91,6 +98,11 @@ class ConvLaunch:
             wp, unscale = H.pack_conv_weights_f16x3(self.w, layout)
             self.f16[layout] = (wp, (self.scale * unscale).contiguous())
         return self.f16[layout]
+
+    def _d32(self, B: int, D: int, Hh: int, W: int) -> bool:
+        """32-channel slices (MVSGI_CONV_BF16X3_D32) serve this launch: Cin % 32 == 0, stride 1, a large launch."""
+        return _USE_D32 and self.stride == 1 and self.cin % 32 == 0 and self.cout % 16 == 0 and \
+            H.conv3d_d32_applies(B, self.cin, D, Hh, W, self.cout, self.stride)
 
     def _c16(self) -> bool:
         """Cout == 16, stride 1: the plane-schedule kernel (MVSGI_CONV_BF16X3_C16)."""
@@ -327,6 +339,7 @@ def lower_conv_block(blk) -> ConvLaunch:
     L.wp_b3 = None
     L.wp_c16 = None
     L.wp_v32 = None
+    L.wp_d32 = None
     L.wp_rs = None
     L.wp_s2 = None
     L.wp_poly = None

@@ -13,7 +13,7 @@ from . import _lib
 
 import os
 
-CONV_AUTO, CONV_DIRECT, CONV_MFMA, CONV_BF16X3, CONV_BF16X3_C16, CONV_BF16X3_V32 = 0, 1, 2, 3, 4, 5
+CONV_AUTO, CONV_DIRECT, CONV_MFMA, CONV_BF16X3, CONV_BF16X3_C16, CONV_BF16X3_V32, CONV_BF16X3_D32 = 0, 1, 2, 3, 4, 5, 6
 SPLIT_F16 = 1          # `fmt` of the *_fmt entry points (include/mvsgi.h MVSGI_SPLIT_F16): split-padded data / weights hold fp16 pairs
 CONV_F16 = 0x100       # flag OR-ed into CONV_BF16X3 / _C16 / _V32: the same kernel in the fp16 split (include/mvsgi.h MVSGI_CONV_F16)
 
@@ -404,18 +404,38 @@ def pack_conv_weights_f16x3(w_oidhw: torch.Tensor, layout: int = CONV_BF16X3):
     w = _dev(w_oidhw, "conv weight")
     Cout, Cin = w.shape[:2]
     if tuple(w.shape[2:]) != (3, 3, 3) or Cin % 16 or Cout % 16 or (layout == CONV_BF16X3_C16 and Cout != 16) or \
-            (layout == CONV_BF16X3_V32 and Cout % 32):
+            (layout == CONV_BF16X3_V32 and Cout % 32) or (layout == CONV_BF16X3_D32 and Cin % 32):
         return None
     amax = w.abs().amax(dim=(1, 2, 3, 4))
     k = torch.where(amax > 0, torch.floor(torch.log2(1024.0 / amax.clamp_min(1e-37))), torch.zeros_like(amax)).clamp(-100.0, 100.0)
     ws = (w * torch.exp2(k).view(-1, 1, 1, 1, 1)).contiguous()
     n = {CONV_BF16X3: lambda: lib.mvsgi_conv3d_packed_weight_bytes_bf16x3(Cout, Cin),
          CONV_BF16X3_C16: lambda: lib.mvsgi_conv3d_packed_weight_bytes_bf16x3_c16(Cin),
+         CONV_BF16X3_D32: lambda: lib.mvsgi_conv3d_packed_weight_bytes_bf16x3(Cout, Cin),
          CONV_BF16X3_V32: lambda: lib.mvsgi_conv3d_packed_weight_bytes_bf16x3_v32(Cout, Cin)}[layout]()
     wp = torch.empty(n, device=w.device, dtype=torch.uint8)
     _lib.check(lib.mvsgi_conv3d_pack_weights_split(ws.data_ptr(), wp.data_ptr(), Cout, Cin, layout | CONV_F16, _stream_ptr(w)),
                "mvsgi_conv3d_pack_weights_split")
     return wp, torch.exp2(-k).contiguous()
+
+
+def conv3d_d32_applies(B, Cin, Din, Hin, Win, Cout, stride=1) -> bool:
+    """Whether the split kernel on 32-channel slices (impl CONV_BF16X3_D32: 27 k-steps per 32 channels instead of 28, half the
+    slices per unit) serves this problem: Cin % 32 == 0, stride 1, a launch large enough for its 128- / 160-voxel bricks."""
+    return bool(_lib.load().mvsgi_conv3d_d32_applies(B, Cin, Din, Hin, Win, Cout, stride))
+
+
+def pack_conv_weights_bf16x3_d32(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
+    """[Cout, Cin, 3, 3, 3] -> the bf16 split's weights in the 32-channel-slice layout (CONV_BF16X3_D32), or None (Cin % 32, Cout % 16)."""
+    lib = _lib.load()
+    w = _dev(w_oidhw, "conv weight")
+    Cout, Cin = w.shape[:2]
+    if tuple(w.shape[2:]) != (3, 3, 3) or Cin % 32 or Cout % 16:
+        return None
+    wp = torch.empty(lib.mvsgi_conv3d_packed_weight_bytes_bf16x3(Cout, Cin), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.mvsgi_conv3d_pack_weights_split(w.data_ptr(), wp.data_ptr(), Cout, Cin, CONV_BF16X3_D32, _stream_ptr(w)),
+               "mvsgi_conv3d_pack_weights_split")
+    return wp
 
 
 def conv3d_v32_applies(B, Cin, Din, Hin, Win, Cout, stride=1) -> bool:

@@ -198,6 +198,13 @@ CONV_SHAPES = [
     (64, 16, 192, 8, 16, 24, 2, False, 0.0),    # stride 2 in 192-cout units
     (1, 32, 384, 1, 10, 40, 1, True, 0.01),     # one-plane volume at ONE frame (E8's level 2 on the latency path): the small-launch rule, not 18 128-cout units
     (2, 32, 384, 1, 10, 40, 1, False, 0.01),    # ... at two frames
+    (20, 64, 96, 4, 20, 80, 1, True, 0.01),     # 96-cout units on 2 x 4 x 16 bricks; with the rows above and below every brick of the 32-channel-slice kernels
+    (40, 64, 96, 3, 15, 21, 1, False, 0.01),    # ... 2 x 5 x 16, ragged
+    (40, 32, 96, 4, 10, 24, 1, True, 0.01),     # ... 2 x 10 x 8
+    (96, 32, 128, 1, 7, 21, 1, True, 0.0),      # one-plane 1 x 4 x 16 x 128 couts on 32 input channels
+    (24, 64, 128, 1, 15, 21, 1, True, 0.01),    # one-plane 1 x 5 x 16 x 128
+    (64, 32, 192, 1, 15, 21, 1, False, 0.01),   # one-plane 1 x 5 x 16 x 192
+    (64, 32, 192, 1, 10, 40, 1, False, 0.01),   # one-plane 1 x 10 x 8 x 192
     (1, 64, 128, 4, 20, 80, 2, False, 0.01),    # the stride-2 conv into UNet level 2 at one frame: 60 units of 32 couts, not 30 of 64
     (8, 64, 128, 4, 20, 80, 2, False, 0.01),    # ... at eight frames: 64-cout units
     (1, 64, 64, 4, 20, 80, 1, True, 0.01),      # UNet level 1 at one frame: 200 units of 32 couts, waves as (voxel half, cout tile)
@@ -270,6 +277,13 @@ def test_conv3d_bf16x3_vs_oracle(shape):
     y = H.conv3d(xg, wg, wp, _g(scale), _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3)
     err = _rel(_ncdhw(y), yref)
     assert err <= 1e-4, err
+    if H.conv3d_d32_applies(B, Cin, D, Hh, W, Cout, stride):      # the same bricks on 32-channel slices (27 k-steps per 32 channels)
+        assert Cin % 32 == 0 and stride == 1
+        name = H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3_D32)
+        assert name.startswith("conv3d_bf16x3_d32_kernel<") and name.split("<")[1].rstrip(">") in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3)
+        yd = H.conv3d(xg, wg, H.pack_conv_weights_bf16x3_d32(wg), _g(scale), _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3_D32)
+        assert _rel(_ncdhw(yd), yref) <= 1e-4
+        assert _rel(_ncdhw(yd), _ncdhw(y)) <= 4e-6      # same products, another summation order
     if Cout == 16 and stride == 1:       # the plane-schedule kernel of the Cout == 16 layers
         assert "true, false, false>" in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3_C16)
         yp = H.conv3d(xg, wg, H.pack_conv_weights_bf16x3_c16(wg), _g(scale), _g(shift), res=rg, stride=stride,
@@ -306,6 +320,11 @@ def test_conv3d_f16x3_vs_oracle(shape):
     yb = H.conv3d(xg, wg, H.pack_conv_weights_bf16x3(wg), _g(scale), _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3)
     eb = _rel(_ncdhw(yb), yref)                          # ... and closer than the bf16 split on the same problem (a residual of
     assert (eb > 1.5 * err) if not res else (eb >= err or err <= 2.5e-7), (eb, err)   # O(1) beside the x 0.01 convolution hides both splits behind the final add's rounding: an ulp either way)
+    if H.conv3d_d32_applies(B, Cin, D, Hh, W, Cout, stride):
+        wpd, und = H.pack_conv_weights_f16x3(wg, H.CONV_BF16X3_D32)
+        assert H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3_D32 | H.CONV_F16).startswith("conv3d_f16x3_d32_kernel<")
+        yd = H.conv3d(xg, wg, wpd, _g(scale) * und, _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3_D32 | H.CONV_F16)
+        assert _rel(_ncdhw(yd), yref) <= 5e-6 and _rel(_ncdhw(yd), _ncdhw(y)) <= 2e-6
     if Cout == 16 and stride == 1:
         wpc, un = H.pack_conv_weights_f16x3(wg, H.CONV_BF16X3_C16)
         yp = H.conv3d(xg, wg, wpc, _g(scale) * un, _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3_C16 | H.CONV_F16)
