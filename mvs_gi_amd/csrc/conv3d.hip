@@ -413,6 +413,8 @@ int d32_variant(const ConvArgs& a) {
         case B3_N128_PW8: return B3D_N128_PW8;
         case B3_N192_PH5: return B3D_N192_PH5;
         case B3_N192_PW8: return B3D_N192_PW8;
+        case B3_N32_TB: return B3D_N32_TB;
+        case B3_N64_S: return B3D_N64_S;
         default: return V_COUNT;
     }
 }
