@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MVSGI_ABI_VERSION 3   /* 3: mvsgi_conv3d_d32_applies + MVSGI_CONV_BF16X3_D32; 2: mvsgi_saturation_flags; the symbol set of round 5 */
+#define MVSGI_ABI_VERSION 3   /* 3: mvsgi_conv3d_d32_applies, mvsgi_conv3d_up2_d32_applies + MVSGI_CONV_BF16X3_D32; 2: mvsgi_saturation_flags; the symbol set of round 5 */
 
 typedef void* mvsgi_stream_t;
 
@@ -186,6 +186,8 @@ int mvsgi_conv3d_v32_applies(int B, int Cin, int Din, int Hin, int Win, int Cout
 /* 1 when mvsgi_conv3d_f32 accepts impl = MVSGI_CONV_BF16X3_D32 [| MVSGI_CONV_F16] for this problem (replaces nothing in the reference:
  * a second schedule of BaseConvBlk3d's convolution, dsta_mvs/model/common/common_modules.py:107-115) */
 int mvsgi_conv3d_d32_applies(int B, int Cin, int Din, int Hin, int Win, int Cout, int stride);
+/* ... and mvsgi_conv3d_up2_f32 with w_layout = MVSGI_CONV_BF16X3_D32 (ResizeConv3d, common_modules.py:332-355; low-resolution sizes) */
+int mvsgi_conv3d_up2_d32_applies(int B, int Cin, int Dl, int Hl, int Wl, int Cout);
 size_t mvsgi_conv3d_packed_weight_bytes_bf16x3_v32(int Cout, int Cin);
 int mvsgi_conv3d_pack_weights_bf16x3_v32(const float* w_oidhw, void* w_packed, int Cout, int Cin, mvsgi_stream_t stream);
 /* weights of a Cout == 16 layer in the plane-schedule layout (MVSGI_CONV_BF16X3_C16) */

@@ -46,6 +46,7 @@ SIGNATURES = {
     "mvsgi_conv3d_up2_variant_f32": (c_char_p, [c_int] * 7),
     "mvsgi_conv3d_v32_applies": (c_int, [c_int] * 7),
     "mvsgi_conv3d_d32_applies": (c_int, [c_int] * 7),
+    "mvsgi_conv3d_up2_d32_applies": (c_int, [c_int] * 6),
     "mvsgi_conv3d_packed_weight_bytes_bf16x3_v32": (c_size_t, [c_int, c_int]),
     "mvsgi_conv3d_pack_weights_bf16x3_v32": (c_int, [_P, _P, c_int, c_int, _P]),
     "mvsgi_conv3d_packed_weight_bytes_bf16x3_c16": (c_size_t, [c_int]),

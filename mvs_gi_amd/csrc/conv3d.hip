@@ -341,6 +341,9 @@ const char* const kVariantNames[] = {
 #define MVSGI_B3D(V, ...) "conv3d_bf16x3_d32_kernel<" #__VA_ARGS__ ">",
 #include "conv3d_b3d_variants.inc"
 #undef MVSGI_B3D
+#define MVSGI_B3DU(V, ...) "conv3d_bf16x3_d32u_kernel<" #__VA_ARGS__ ">",
+#include "conv3d_b3du_variants.inc"
+#undef MVSGI_B3DU
 };
 static_assert(sizeof(kVariantNames) / sizeof(kVariantNames[0]) == V_COUNT, "one name per variant");
 
@@ -354,6 +357,13 @@ bool v32_applies(const ConvArgs& a) {
 
 // variant of the fused upsample + conv (a holds the UPSAMPLED input size); V_COUNT when unsupported
 int select_variant_up2(const ConvArgs& a, int w_layout) {
+    if (w_layout == MVSGI_CONV_BF16X3_D32) {      // 32-channel slices: the sibling of the 2 x 4 x 16-brick variant, where that is the choice
+        const int base = (a.Cin % 32 || mvsgi::exp_env("MVSGI_NO_D32")) ? V_COUNT : select_variant_up2(a, MVSGI_CONV_BF16X3);
+        if (base == B3U_N64) return B3DU_N64;
+        if (base == B3U_N96) return B3DU_N96;
+        mvsgi::fail("mvsgi_conv3d_up2_f32: the 32-channel-slice kernels do not apply to this problem (see mvsgi_conv3d_up2_d32_applies)");
+        return V_COUNT;
+    }
     const bool c16_layout = w_layout == MVSGI_CONV_BF16X3_C16;
     if (w_layout == MVSGI_CONV_BF16X3_V32) {
         if (!v32_applies(a) || !a.wp) { mvsgi::fail("mvsgi_conv3d_up2_f32: the 32x32x16 kernel does not apply to this problem"); return V_COUNT; }
@@ -605,6 +615,9 @@ int launch_variant(int v, const ConvArgs& a, hipStream_t st) {
 #define MVSGI_B3D(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, false, false, false, false, false, true>(a, st);
 #include "conv3d_b3d_variants.inc"
 #undef MVSGI_B3D
+#define MVSGI_B3DU(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, true, false, false, false, false, true>(a, st);
+#include "conv3d_b3du_variants.inc"
+#undef MVSGI_B3DU
 #ifdef MVSGI_EXPERIMENTAL      // the dispatcher's 16-cout units are B3_N16_TW; this one is the A/B reference of tools/wlds_probe.py
         case B3_N16_T: return launch_bf16x3<1, 1, 4, 1, 1, 4, 16, 1>(a, st);
 #else
@@ -832,7 +845,7 @@ extern "C" int mvsgi_conv3d_up2_f32(const float* x, const void* w_packed, int w_
     const bool f16 = (w_layout & MVSGI_CONV_F16) != 0;
     w_layout &= ~MVSGI_CONV_F16;
     MVSGI_REQUIRE(w_layout == MVSGI_CONV_BF16X3 || (w_layout == MVSGI_CONV_BF16X3_C16 && Cout == 16) ||
-                      (w_layout == MVSGI_CONV_BF16X3_V32 && Cout % 32 == 0),
+                      (w_layout == MVSGI_CONV_BF16X3_V32 && Cout % 32 == 0) || (w_layout == MVSGI_CONV_BF16X3_D32 && Cin % 32 == 0),
                   "mvsgi_conv3d_up2_f32: w_layout %d not valid for Cout %d", w_layout, Cout);
     MVSGI_REQUIRE(x && y && scale && shift && w_packed, "mvsgi_conv3d_up2_f32: null pointer");
     MVSGI_REQUIRE(Dl > 0 && Hl > 0 && Wl > 0 && Dl < (1 << 20) && Hl < (1 << 20) && Wl < (1 << 20),
@@ -867,6 +880,17 @@ extern "C" int mvsgi_conv3d_up2_f32_out_split(const float* x, const void* w_pack
     const int v = select_variant_up2(a, w_layout);
     if (v == V_COUNT) return 1;
     return launch_variant(v, a, mvsgi::as_stream(stream));
+}
+
+// 1 when mvsgi_conv3d_up2_f32 accepts w_layout = MVSGI_CONV_BF16X3_D32 [| MVSGI_CONV_F16] for this problem (low-resolution sizes)
+extern "C" int mvsgi_conv3d_up2_d32_applies(int B, int Cin, int Dl, int Hl, int Wl, int Cout) {
+    ConvArgs a{};
+    static const float dummy = 0.f;
+    if (Cin % 32 || Cout % 16 || Dl <= 0 || Hl <= 0 || Wl <= 0 || mvsgi::exp_env("MVSGI_NO_D32") ||
+        fill_args(a, &dummy, nullptr, &dummy, &dummy, &dummy, nullptr, nullptr, B, Cin, 2 * Dl, 2 * Hl, 2 * Wl, Cout, 1, 1.f))
+        return 0;
+    const int base = select_variant_up2(a, MVSGI_CONV_BF16X3);
+    return (base == B3U_N64 || base == B3U_N96) ? 1 : 0;
 }
 
 extern "C" const char* mvsgi_conv3d_up2_variant_f32(int B, int Cin, int Dl, int Hl, int Wl, int Cout, int w_layout) {

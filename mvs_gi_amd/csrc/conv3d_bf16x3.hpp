@@ -318,7 +318,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
     // D32: 32-channel slices -- an MFMA's K = 32 is one tap of TWO 16-channel sub-images (the slice's LDS image is the two side by
     // side, sub-image 1 at +SUB; the lane groups that take a pair's second tap take the second sub-image): 27 slots per 32 channels
     // instead of 2 x 14, half the slices (barriers) per unit.  `kPairs` is then the number of taps.
-    static_assert(!D32 || (KD == 3 && S == 1 && !UPS && !PLANE && !V32 && !WLDS), "32-channel slices: plain stride-1 3x3x3 variants only");
+    static_assert(!D32 || (KD == 3 && S == 1 && !PLANE && !V32 && !WLDS), "32-channel slices: stride-1 3x3x3 variants (plain or fused upsample) only");
     constexpr int kTaps = KD * 9, kPairs = D32 ? KD * 9 : pairs_of(KD);
     constexpr int ITD = (TD - 1) * SD + KD, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
     constexpr int IV = ITD * ITH * ITW;
@@ -418,14 +418,15 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
         const int ptid = tid - 256;
         if constexpr (UPS) {
             constexpr int CD = ITD / 2, CH = ITH / 2, CW = ITW / 2, NC = CD * CH * CW;
-            constexpr int NITU = (NC * 4 + 255) / 256;         // cell items (cell, channel quad) per producer thread
+            constexpr int NCQ = NC << QB;                      // cell items of a unit: (cell, channel quad), 4 | 8 quads per cell
+            constexpr int NITU = (NCQ + 255) / 256;            // ... per producer thread
             // The last round is rarely full (324 items on 256 threads: 68 left).  When at most half of the threads
             // would be busy, its items are split in two along D -- thread pairs share a cell item, each blends and
             // writes the 4 upsampled voxels of one kd -- so the critical wave does 1 + 0.45 instead of 2 items.
-            constexpr int RF = NC * 4 / 256, REM = NC * 4 - RF * 256;
+            constexpr int RF = NCQ / 256, REM = NCQ - RF * 256;
             constexpr bool HALF = REM > 0 && 2 * REM <= 256;
 #define MVSGI_UPS_CQ(IT) ((HALF && (IT) == RF) ? RF * 256 + (ptid >> 1) : ptid + (IT) * 256)      /* cell-quad index */
-#define MVSGI_UPS_LIVE(IT) ((HALF && (IT) == RF) ? (ptid >> 1) < REM : ptid + (IT) * 256 < NC * 4)
+#define MVSGI_UPS_LIVE(IT) ((HALF && (IT) == RF) ? (ptid >> 1) < REM : ptid + (IT) * 256 < NCQ)
             const int Dl = a.Din >> 1, Hl = a.Hin >> 1, Wl = a.Win >> 1;
             const int sH_ = Wl * a.Cin, sD_ = Hl * sH_;        // element strides of the low-resolution frame (< 2^23: launcher)
             int lo_d[NITU], lo_h[NITU], lo_w[NITU];             // lower low-res corner of the cell (may be -1)
@@ -439,7 +440,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
                 MVSGI_DECODE(UNIT, cb_, b_, od_, oh_, ow_)                                              \
                 (void)cb_;                                                                              \
                 _Pragma("unroll") for (int it = 0; it < NITU; ++it) {                                   \
-                    const int c = MVSGI_UPS_CQ(it) >> 2;                                                \
+                    const int c = MVSGI_UPS_CQ(it) >> QB;                                               \
                     const int cw = c % CW, ch = (c / CW) % CH, cd = c / (CW * CH);                      \
                     const int gd = od_ - 1 + 2 * cd, gh = oh_ - 1 + 2 * ch, gw = ow_ - 1 + 2 * cw;      \
                     lo_d[it] = (gd - 1) >> 1;                                                           \
@@ -457,12 +458,12 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
             if (cc2 == 0 && k2 > 0) { MVSGI_PLAN_UPS((int)blockIdx.x + k2 * G) }
 #define MVSGI_ISSUE_UPS1(CR, IM, IT)                                                                    \
             {                                                                                           \
-                const int q = MVSGI_UPS_CQ(IT) & 3;                                                     \
+                const int q = MVSGI_UPS_CQ(IT) & ((1 << QB) - 1);                                       \
                 const bool live = MVSGI_UPS_LIVE(IT);                                                   \
                 const int d0 = live ? MVSGI_CLAMP(lo_d[IT], Dl) : 0, d1 = live ? MVSGI_CLAMP(lo_d[IT] + 1, Dl) : 0; \
                 const int h0 = live ? MVSGI_CLAMP(lo_h[IT], Hl) : 0, h1 = live ? MVSGI_CLAMP(lo_h[IT] + 1, Hl) : 0; \
                 const int w0 = live ? MVSGI_CLAMP(lo_w[IT], Wl) : 0, w1 = live ? MVSGI_CLAMP(lo_w[IT] + 1, Wl) : 0; \
-                const int cofs = cc2 * 16 + q * 4;                                                      \
+                const int cofs = cc2 * (D32 ? 32 : 16) + q * 4;                                         \
                 /* element offset = d sD + h sH + w sW: six full-rate 24-bit multiplies instead of 14 quarter-rate v_mul_lo_u32 */ \
                 const int od_[2] = {__mul24(d0, sD_), __mul24(d1, sD_)}, oh_[2] = {__mul24(h0, sH_), __mul24(h1, sH_)};   \
                 const int ow_[2] = {__mul24(w0, a.Cin) + cofs, __mul24(w1, a.Cin) + cofs};              \
@@ -491,7 +492,8 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
             if (HALF && (IT) == RF) {                                                                   \
                 /* half item: this thread's kd = ptid & 1; blend along D first (one output plane), then H, then W */ \
                 if (MVSGI_UPS_LIVE(IT)) {                                                               \
-                    const int cq_ = MVSGI_UPS_CQ(IT), c = cq_ >> 2, q = cq_ & 3, kd = ptid & 1;         \
+                    const int cq_ = MVSGI_UPS_CQ(IT), c = cq_ >> QB, q = cq_ & 3, kd = ptid & 1;        \
+                    const int sub_ = D32 ? ((cq_ >> 2) & 1) * SUB : 0;                                  \
                     const int cw = c % CW, ch = (c / CW) % CH, cd = c / (CW * CH);                      \
                     const float f_ = kd ? 0.75f : 0.25f;                                                \
                     const f32x4 f4_ = {f_, f_, f_, f_};                                                 \
@@ -511,14 +513,14 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
                             split_x4<F16>(xo[kh][kw], hi, lo, satm);                                           \
                             if (!ok) hi = lo = u32x2{0u, 0u};                                           \
                             const int vo_ = ((2 * cd + kd) * ITH + 2 * ch + kh) * ROWP + (2 * cw + kw) * kVSB; \
-                            *reinterpret_cast<u32x2*>((DST) + vo_ + q * 8) = hi;                        \
-                            *reinterpret_cast<u32x2*>((DST) + vo_ + 32 + q * 8) = lo;                   \
+                            *reinterpret_cast<u32x2*>((DST) + sub_ + vo_ + q * 8) = hi;                 \
+                            *reinterpret_cast<u32x2*>((DST) + sub_ + vo_ + 32 + q * 8) = lo;            \
                         }                                                                               \
                 }                                                                                       \
             } else {                                                                                    \
                 const int e = ptid + (IT) * 256;                                                        \
-                if (e < NC * 4) {                                                                       \
-                    const int c = e >> 2, q = e & 3;                                                    \
+                if (e < NCQ) {                                                                          \
+                    const int c = e >> QB, q = e & 3, sub_ = D32 ? ((e >> 2) & 1) * SUB : 0;            \
                     const int cw = c % CW, ch = (c / CW) % CH, cd = c / (CW * CH);                      \
                     /* separable blend: along W, then H, then D; index bit = upsampled voxel 0 / 1 of the cell */ \
                     f32x4 xw[4][2], xh[2][2][2], xo[2][2][2];                                           \
@@ -538,8 +540,8 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
                                 split_x4<F16>(xo[kd][kh][kw], hi, lo, satm);                                   \
                                 if (!ok) hi = lo = u32x2{0u, 0u};                                       \
                                 const int vo_ = ((2 * cd + kd) * ITH + 2 * ch + kh) * ROWP + (2 * cw + kw) * kVSB; \
-                                *reinterpret_cast<u32x2*>((DST) + vo_ + q * 8) = hi;                    \
-                                *reinterpret_cast<u32x2*>((DST) + vo_ + 32 + q * 8) = lo;               \
+                                *reinterpret_cast<u32x2*>((DST) + sub_ + vo_ + q * 8) = hi;             \
+                                *reinterpret_cast<u32x2*>((DST) + sub_ + vo_ + 32 + q * 8) = lo;        \
                             }                                                                           \
                 }                                                                                       \
             }
@@ -1321,17 +1323,29 @@ __global__ __launch_bounds__(512, 2) void conv3d_f16x3_d32_kernel(ConvArgs a) {
     conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, false, false, false, false, true, true>(a);
 }
 
+// ... with the trilinear x2 upsample in the producers (UPS)
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW>
+__global__ __launch_bounds__(512, 2) void conv3d_bf16x3_d32u_kernel(ConvArgs a) {
+    conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, true, false, false, false, false, true>(a);
+}
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW>
+__global__ __launch_bounds__(512, 2) void conv3d_f16x3_d32u_kernel(ConvArgs a) {
+    conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, true, false, false, false, true, true>(a);
+}
+
 template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false, bool PLANE = false,
           bool V32 = false, bool WLDS = false, bool F16 = false, bool D32 = false>
 int launch_bf16x3(ConvArgs a, hipStream_t st) {
     constexpr int ITD = (TD - 1) * (KD == 1 ? 1 : S) + KD, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
     constexpr int ROWP = V32 ? ((ITW * kVSB + 255) / 256) * 256 : ITW * kVSB;
     constexpr bool WARM = MVSGI_WARM && KD == 3 && !UPS && !PLANE && !V32 && !WLDS && S == 1 && MW * NW <= 2;      // (conv3d_x3_body)
-    static_assert(!D32 || (S == 1 && KD == 3 && !UPS && !PLANE && !V32 && !WLDS), "32-channel slices: plain stride-1 3x3x3 variants");
+    static_assert(!D32 || (S == 1 && KD == 3 && !PLANE && !V32 && !WLDS), "32-channel slices: stride-1 3x3x3 variants");
     constexpr size_t lds_bytes = (size_t)2 * ((D32 ? 2 : 1) * ITD * ITH * ROWP + (WLDS ? NW * pairs_of(KD) * 2048 : 0)) + (WARM ? 4096 : 0);   // double-buffered image (+ weight slice) (+ the warm-up's dummy KiB per producer wave)
     static_assert(lds_bytes <= 160 * 1024, "LDS images too large");
     void (*kern)(ConvArgs);
-    if constexpr (D32 && F16) kern = conv3d_f16x3_d32_kernel<NW, MW, WM, WN, TD, TH, TW>;
+    if constexpr (D32 && UPS && F16) kern = conv3d_f16x3_d32u_kernel<NW, MW, WM, WN, TD, TH, TW>;
+    else if constexpr (D32 && UPS) kern = conv3d_bf16x3_d32u_kernel<NW, MW, WM, WN, TD, TH, TW>;
+    else if constexpr (D32 && F16) kern = conv3d_f16x3_d32_kernel<NW, MW, WM, WN, TD, TH, TW>;
     else if constexpr (D32) kern = conv3d_bf16x3_d32_kernel<NW, MW, WM, WN, TD, TH, TW>;
     else if constexpr (F16) kern = conv3d_f16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32, WLDS>;
     else kern = conv3d_bf16x3_kernel<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32, WLDS>;

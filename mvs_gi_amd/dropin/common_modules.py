@@ -48,6 +48,7 @@ _USE_V32 = H.exp_env("MVSGI_V32", "0") != "0"
 # MVSGI_D32=0: keep the Cin % 32 == 0 stride-1 layers of large launches on the tap-pair layout (default: 32-channel slices,
 # csrc/conv3d_bf16x3.hpp D32 -- 27 k-steps per 32 channels instead of 28 and half the slices per unit: 6-9 % of those layers)
 _USE_D32 = os.environ.get("MVSGI_D32", "1") != "0"
+_NO_D32U = H.exp_env("MVSGI_NO_D32U", "0") != "0"      # (tools: the fused-upsample layers alone back on tap pairs)
 
 
 class ConvLaunch:
@@ -241,14 +242,19 @@ class ConvLaunch:
 
     def run_up2(self, x_lowres_ndhwc: Tensor, res: Optional[Tensor] = None) -> Tensor:
         """conv(trilinear_x2(x)) in one launch (mvsgi_conv3d_up2_f32)."""
+        B, Dl, Hl, Wl, _ = x_lowres_ndhwc.shape
+        d32 = _USE_D32 and not _NO_D32U and not self._c16() and self.cin % 32 == 0 and H.conv3d_up2_d32_applies(B, self.cin, Dl, Hl, Wl, self.cout)
         if H.get_conv_mode() == "f16x3":
-            layout = H.CONV_BF16X3_C16 if self._c16() else H.CONV_BF16X3
+            layout = H.CONV_BF16X3_C16 if self._c16() else (H.CONV_BF16X3_D32 if d32 else H.CONV_BF16X3)
             wp16, sc16 = self._f16(layout)
             return H.conv3d_up2(x_lowres_ndhwc, wp16, sc16, self.shift, res=res, neg_slope=self.neg_slope, w_layout=layout | H.CONV_F16)
         if self._c16():
             return H.conv3d_up2(x_lowres_ndhwc, self._wp_c16(), self.scale, self.shift, res=res,
                                 neg_slope=self.neg_slope, w_layout=H.CONV_BF16X3_C16)
-        B, Dl, Hl, Wl, _ = x_lowres_ndhwc.shape
+        if d32 and H.get_conv_mode() == "bf16x3":
+            if getattr(self, "wp_d32", None) is None:
+                self.wp_d32 = H.pack_conv_weights_bf16x3_d32(self.w)
+            return H.conv3d_up2(x_lowres_ndhwc, self.wp_d32, self.scale, self.shift, res=res, neg_slope=self.neg_slope, w_layout=H.CONV_BF16X3_D32)
         if _USE_V32 and self.cout % 32 == 0 and H.conv3d_v32_applies(B, self.cin, 2 * Dl, 2 * Hl, 2 * Wl, self.cout, 1):
             return H.conv3d_up2(x_lowres_ndhwc, self._wp_v32(), self.scale, self.shift, res=res,
                                 neg_slope=self.neg_slope, w_layout=H.CONV_BF16X3_V32)

@@ -425,6 +425,11 @@ def conv3d_d32_applies(B, Cin, Din, Hin, Win, Cout, stride=1) -> bool:
     return bool(_lib.load().mvsgi_conv3d_d32_applies(B, Cin, Din, Hin, Win, Cout, stride))
 
 
+def conv3d_up2_d32_applies(B, Cin, Dl, Hl, Wl, Cout) -> bool:
+    """... and the fused upsample + conv (conv3d_up2 with w_layout CONV_BF16X3_D32; low-resolution sizes)."""
+    return bool(_lib.load().mvsgi_conv3d_up2_d32_applies(B, Cin, Dl, Hl, Wl, Cout))
+
+
 def pack_conv_weights_bf16x3_d32(w_oidhw: torch.Tensor) -> Optional[torch.Tensor]:
     """[Cout, Cin, 3, 3, 3] -> the bf16 split's weights in the 32-channel-slice layout (CONV_BF16X3_D32), or None (Cin % 32, Cout % 16)."""
     lib = _lib.load()

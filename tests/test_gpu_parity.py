@@ -424,6 +424,9 @@ def test_conv3d_v32_schedule_vs_oracle(shape):
     (1, 128, 64, 2, 10, 40, True),     # an up block at one frame: 2 x 2 x 16 bricks x 32 couts (200 units, one round of the chip)
     (2, 128, 64, 2, 10, 40, True),     # ... at two frames: 2 x 4 x 16 bricks x 64 couts
     (1, 64, 64, 3, 5, 9, False),       # the one-round units on ragged bricks
+    (8, 128, 64, 2, 10, 40, True),     # 2 x 4 x 16 bricks x 64 couts at eight frames: also on 32-channel slices
+    (12, 64, 96, 3, 5, 9, False),      # ... 96 couts in 64-cout units, ragged
+    (16, 64, 96, 4, 10, 10, False),    # ... x 96 couts
     (1, 64, 32, 4, 20, 80, True),      # the last up block at one frame: 200 units of 4 x 4 x 16 in one round, not 400 of 2 x 4 x 16 in two
 ])
 def test_conv3d_fused_upsample_vs_interpolate_then_conv(shape):
@@ -456,6 +459,14 @@ def test_conv3d_fused_upsample_vs_interpolate_then_conv(shape):
         gp = H.conv3d_up2(xg, H.pack_conv_weights_bf16x3_c16(_g(w)), _g(scale), _g(shift), res=rg, neg_slope=0.01,
                           w_layout=H.CONV_BF16X3_C16)
         assert _rel(_ncdhw(gp), yref) <= 1e-4
+    if H.conv3d_up2_d32_applies(B, Cin, Dl, Hl, Wl, Cout):      # the same launch on 32-channel slices, both splits
+        assert H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, H.CONV_BF16X3_D32).startswith("conv3d_bf16x3_d32u_kernel<")
+        gd = H.conv3d_up2(xg, H.pack_conv_weights_bf16x3_d32(_g(w)), _g(scale), _g(shift), res=rg, neg_slope=0.01, w_layout=H.CONV_BF16X3_D32)
+        assert _rel(_ncdhw(gd), yref) <= 1e-4 and _rel(_ncdhw(gd), _ncdhw(got)) <= 4e-6
+        wpd, und = H.pack_conv_weights_f16x3(_g(w), H.CONV_BF16X3_D32)
+        assert H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, H.CONV_BF16X3_D32 | H.CONV_F16).startswith("conv3d_f16x3_d32u_kernel<")
+        gd16 = H.conv3d_up2(xg, wpd, _g(scale) * und, _g(shift), res=rg, neg_slope=0.01, w_layout=H.CONV_BF16X3_D32 | H.CONV_F16)
+        assert _rel(_ncdhw(gd16), yref) <= 1e-5
     wp16, un16 = H.pack_conv_weights_f16x3(_g(w))      # the fp16 split of the same launch
     g16 = H.conv3d_up2(xg, wp16, _g(scale) * un16, _g(shift), res=rg, neg_slope=0.01, w_layout=H.CONV_BF16X3 | H.CONV_F16)
     assert H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, H.CONV_BF16X3 | H.CONV_F16).startswith("conv3d_f16x3_kernel<")
