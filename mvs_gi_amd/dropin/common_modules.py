@@ -49,6 +49,7 @@ _USE_V32 = H.exp_env("MVSGI_V32", "0") != "0"
 # csrc/conv3d_bf16x3.hpp D32 -- 27 k-steps per 32 channels instead of 28 and half the slices per unit: 6-9 % of those layers)
 _USE_D32 = os.environ.get("MVSGI_D32", "1") != "0"
 _NO_D32U = H.exp_env("MVSGI_NO_D32U", "0") != "0"      # (tools: the fused-upsample layers alone back on tap pairs)
+_D32_OK: Dict[tuple, bool] = {}       # (cin, cout, B, D, H, W) -> mvsgi_conv3d_d32_applies; ("up2", ...) -> mvsgi_conv3d_up2_d32_applies
 
 
 class ConvLaunch:
@@ -102,8 +103,13 @@ class ConvLaunch:
 
     def _d32(self, B: int, D: int, Hh: int, W: int) -> bool:
         """32-channel slices (MVSGI_CONV_BF16X3_D32) serve this launch: Cin % 32 == 0, stride 1, a large launch."""
-        return _USE_D32 and self.stride == 1 and self.cin % 32 == 0 and self.cout % 16 == 0 and \
-            H.conv3d_d32_applies(B, self.cin, D, Hh, W, self.cout, self.stride)
+        if not (_USE_D32 and self.stride == 1 and self.cin % 32 == 0 and self.cout % 16 == 0):
+            return False
+        key = (B, D, Hh, W)                      # (one library query per launch shape, not per launch)
+        ok = _D32_OK.get((self.cin, self.cout) + key)
+        if ok is None:
+            ok = _D32_OK[(self.cin, self.cout) + key] = H.conv3d_d32_applies(B, self.cin, D, Hh, W, self.cout, self.stride)
+        return ok
 
     def _c16(self) -> bool:
         """Cout == 16, stride 1: the plane-schedule kernel (MVSGI_CONV_BF16X3_C16)."""
@@ -243,7 +249,12 @@ class ConvLaunch:
     def run_up2(self, x_lowres_ndhwc: Tensor, res: Optional[Tensor] = None) -> Tensor:
         """conv(trilinear_x2(x)) in one launch (mvsgi_conv3d_up2_f32)."""
         B, Dl, Hl, Wl, _ = x_lowres_ndhwc.shape
-        d32 = _USE_D32 and not _NO_D32U and not self._c16() and self.cin % 32 == 0 and H.conv3d_up2_d32_applies(B, self.cin, Dl, Hl, Wl, self.cout)
+        d32 = False
+        if _USE_D32 and not _NO_D32U and not self._c16() and self.cin % 32 == 0:
+            key = ("up2", self.cin, self.cout, B, Dl, Hl, Wl)
+            d32 = _D32_OK.get(key)
+            if d32 is None:
+                d32 = _D32_OK[key] = H.conv3d_up2_d32_applies(B, self.cin, Dl, Hl, Wl, self.cout)
         if H.get_conv_mode() == "f16x3":
             layout = H.CONV_BF16X3_C16 if self._c16() else (H.CONV_BF16X3_D32 if d32 else H.CONV_BF16X3)
             wp16, sc16 = self._f16(layout)
