@@ -974,6 +974,10 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
         // =========================== consumers: LDS + L2 weights -> MFMA ===========================
         const int wm = wave % WM, wn = wave / WM;
         const int col = lane & 15, kg = lane >> 4;
+#ifndef MVSGI_DHW
+#define MVSGI_DHW 1      // 0: the 10 x 8 bricks' tiles as two rows of one plane (the A/B of tools/: a diagnostic build)
+#endif
+        constexpr bool DHW = MVSGI_DHW && TW == 8 && TD == 2 && S == 1 && !PLANE && !V32 && (ITH * ITW * (kVSB / 16)) % 16 == 8;
         const bool second = kg & 1;       // this lane's k-range belongs to the pair's second tap
         const char* wpb = reinterpret_cast<const char*>(a.wp);    // uniform base; per-lane part is lane*16
         const unsigned lane16 = lane * 16;
@@ -982,7 +986,10 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
 #pragma unroll
         for (int i = 0; i < MW; ++i) {
             const int v = (wm * MW + i) * 16 + col;
-            const int w_ = v % TW, h_ = (v / TW) % TH, d_ = v / (TW * TH);
+            // stride-1 two-plane bricks 8 wide: a tile is the SAME row of both planes (voxel order h, d, w) -- its halves are a plane
+            // apart (ITH * ITW * 5 sixteen-byte units = 8 mod 16 for the 10 x 8 bricks: the two halves take disjoint units of a
+            // bank row) where two rows of one plane (50 units = 2 mod 16 apart) collide on two of eight units
+            const int w_ = v % TW, h_ = DHW ? v / (TW * TD) : (v / TW) % TH, d_ = DHW ? (v / TW) % TD : v / (TW * TH);
             base[i] = (((d_ * SD) * ITH + h_ * S) * ITW + w_ * S) * kVSB + (kg >> 1) * 16;
         }
         // position of this lane's voxel of each tile inside the brick (unit-independent)
@@ -991,8 +998,8 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
         for (int i = 0; i < MW; ++i) {
             const int v = PLANE ? (i * TH + wm) * TW + col : (wm * MW + i) * 16 + col;     // PLANE: tile i = plane i of row wm
             twv[i] = v % TW;
-            thv[i] = (v / TW) % TH;
-            tdv[i] = v / (TW * TH);
+            thv[i] = DHW ? v / (TW * TD) : (v / TW) % TH;
+            tdv[i] = DHW ? (v / TW) % TD : v / (TW * TH);
         }
         const long long frame_elems = (long long)a.Do * a.Ho * a.Wo * a.Cout;     // < 2^31 (checked on the host)
         int ctc[NW], ctn[NW];             // clamped cout tiles of the current / the next unit
