@@ -339,11 +339,15 @@ const char* const kVariantNames[] = {
     "conv3d_bf16x3_kernel<1, 4, 2, 2, 4, 4, 16, 1, 3, false, false, true, false>",
     "conv3d_bf16x3_kernel<1, 2, 4, 1, 4, 4, 16, 1, 3, true, false, true, false>", "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 16, 1, 3, true, false, true, false>",
 #define MVSGI_B3D(V, ...) "conv3d_bf16x3_d32_kernel<" #__VA_ARGS__ ">",
+#define MVSGI_B3DK(V, ...) "conv3d_bf16x3_d32_dk_kernel<" #__VA_ARGS__ ">",
 #include "conv3d_b3d_variants.inc"
 #undef MVSGI_B3D
+#undef MVSGI_B3DK
 #define MVSGI_B3DU(V, ...) "conv3d_bf16x3_d32u_kernel<" #__VA_ARGS__ ">",
+#define MVSGI_B3DUK(V, ...) "conv3d_bf16x3_d32u_dk_kernel<" #__VA_ARGS__ ">",
 #include "conv3d_b3du_variants.inc"
 #undef MVSGI_B3DU
+#undef MVSGI_B3DUK
 };
 static_assert(sizeof(kVariantNames) / sizeof(kVariantNames[0]) == V_COUNT, "one name per variant");
 
@@ -359,8 +363,9 @@ bool v32_applies(const ConvArgs& a) {
 int select_variant_up2(const ConvArgs& a, int w_layout) {
     if (w_layout == MVSGI_CONV_BF16X3_D32) {      // 32-channel slices: the sibling of the 2 x 4 x 16-brick variant, where that is the choice
         const int base = (a.Cin % 32 || mvsgi::exp_env("MVSGI_NO_D32")) ? V_COUNT : select_variant_up2(a, MVSGI_CONV_BF16X3);
-        if (base == B3U_N64) return B3DU_N64;
-        if (base == B3U_N96) return B3DU_N96;
+        const bool d2 = a.Do == 2 && !mvsgi::exp_env("MVSGI_NO_DSKIP");
+        if (base == B3U_N64) return d2 ? B3DU2_N64 : B3DU_N64;
+        if (base == B3U_N96) return d2 ? B3DU2_N96 : B3DU_N96;
         mvsgi::fail("mvsgi_conv3d_up2_f32: the 32-channel-slice kernels do not apply to this problem (see mvsgi_conv3d_up2_d32_applies)");
         return V_COUNT;
     }
@@ -411,13 +416,14 @@ int d32_variant(const ConvArgs& a) {
     ConvArgs b = a;
     static const float dummy = 0.f;
     if (!b.wp) b.wp = reinterpret_cast<const f32x4*>(&dummy);      // (the query form has no weights)
+    const bool d2 = a.Do == 2 && !mvsgi::exp_env("MVSGI_NO_DSKIP");      // a volume two planes deep: the depth-skip siblings
     switch (select_variant(b, MVSGI_CONV_BF16X3)) {
-        case B3_N64: return B3D_N64;
-        case B3_N64_H5: return B3D_N64_H5;
-        case B3_N64_W8: return B3D_N64_W8;
-        case B3_N96: return B3D_N96;
-        case B3_N96_H5: return B3D_N96_H5;
-        case B3_N96_W8: return B3D_N96_W8;
+        case B3_N64: return d2 ? B3D2_N64 : B3D_N64;
+        case B3_N64_H5: return d2 ? B3D2_N64_H5 : B3D_N64_H5;
+        case B3_N64_W8: return d2 ? B3D2_N64_W8 : B3D_N64_W8;
+        case B3_N96: return d2 ? B3D2_N96 : B3D_N96;
+        case B3_N96_H5: return d2 ? B3D2_N96_H5 : B3D_N96_H5;
+        case B3_N96_W8: return d2 ? B3D2_N96_W8 : B3D_N96_W8;
         case B3_N128_P: return B3D_N128_P;
         case B3_N128_PH5: return B3D_N128_PH5;
         case B3_N128_PW8: return B3D_N128_PW8;
@@ -613,11 +619,15 @@ int launch_variant(int v, const ConvArgs& a, hipStream_t st) {
 #include "conv3d_b3_variants.inc"
 #undef MVSGI_B3
 #define MVSGI_B3D(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, false, false, false, false, false, true>(a, st);
+#define MVSGI_B3DK(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, false, false, false, false, false, true, true>(a, st);
 #include "conv3d_b3d_variants.inc"
 #undef MVSGI_B3D
+#undef MVSGI_B3DK
 #define MVSGI_B3DU(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, true, false, false, false, false, true>(a, st);
+#define MVSGI_B3DUK(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, true, false, false, false, false, true, true>(a, st);
 #include "conv3d_b3du_variants.inc"
 #undef MVSGI_B3DU
+#undef MVSGI_B3DUK
 #ifdef MVSGI_EXPERIMENTAL      // the dispatcher's 16-cout units are B3_N16_TW; this one is the A/B reference of tools/wlds_probe.py
         case B3_N16_T: return launch_bf16x3<1, 1, 4, 1, 1, 4, 16, 1>(a, st);
 #else

@@ -302,7 +302,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // stage the unit's weight slice (NW x 28 KiB, contiguous in the packed layout) into LDS beside the activation image, once per
 // workgroup, under the same per-unit barrier; the consumers read weight fragments like activation fragments (XB-deep, restarted
 // per unit): 16 ds_read_b128 per slot and CU instead of 8 KiB of vector-memory returns.
-template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD, bool UPS, bool PLANE, bool V32, bool WLDS, bool F16, bool D32 = false>
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD, bool UPS, bool PLANE, bool V32, bool WLDS, bool F16, bool D32 = false, int DK = 3>
 __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
     // (NW == 1: the producers stage the tiles from pct0 = min(cb * NW, CT - NW) on, the consumers clamp tile by tile -- the two agree for one tile)
     static_assert(!WLDS || (WN == 1 && KD == 3 && !UPS && !PLANE && !V32 && S == 1 && NW == 1 && MW <= 2), "LDS-staged weights: one shared cout tile, one or two voxel tiles per wave");
@@ -319,7 +319,14 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
     // side, sub-image 1 at +SUB; the lane groups that take a pair's second tap take the second sub-image): 27 slots per 32 channels
     // instead of 2 x 14, half the slices (barriers) per unit.  `kPairs` is then the number of taps.
     static_assert(!D32 || (KD == 3 && S == 1 && !PLANE && !V32 && !WLDS), "32-channel slices: stride-1 3x3x3 variants (plain or fused upsample) only");
-    constexpr int kTaps = KD * 9, kPairs = D32 ? KD * 9 : pairs_of(KD);
+    // DK < 3 (D32 only): the depth skip.  A volume no deeper than the brick (UNet's coarsest levels, D = 2 and D = 1) has ONE brick along
+    // D, and a wave whose tiles all lie in plane o of it needs the taps kd with 0 <= o + kd - 1 < D only -- the others meet the zero
+    // padding: DK = 2 of 3 kd at D = 2, 1 of 3 at D = 1, for every wave of the workgroup alike.  With one tap per slot and the taps
+    // kd-major that is a WINDOW of 9 DK slots: the wave's weight pointer and its fragment offsets start kd_lo taps (= planes of the
+    // LDS image) in.  A tap PAIR straddles two kd: only the 32-channel-slice form can do this.
+    static_assert(DK == 3 || (D32 && DK >= 1 && (TD == 1 ? DK == 1 : (TD == 2 && WM == 2 && MW * 16 == TH * TW))), "depth skip: one- or two-plane bricks whose waves own whole planes");
+    constexpr int kTaps = KD * 9, kPairs = D32 ? 9 * DK : pairs_of(KD);
+    constexpr int kWBlk = D32 ? 27 : kPairs;       // weight fragments per (slice, cout tile) block of the packed weights
     constexpr int ITD = (TD - 1) * SD + KD, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
     constexpr int IV = ITD * ITH * ITW;
     constexpr int QB = D32 ? 3 : 2;                // a staged voxel is 1 << QB items of 4 channels
@@ -975,7 +982,8 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
         const int wm = wave % WM, wn = wave / WM;
         const int col = lane & 15, kg = lane >> 4;
 #ifndef MVSGI_DHW
-#define MVSGI_DHW 1      // 0: the 10 x 8 bricks' tiles as two rows of one plane (the A/B of tools/: a diagnostic build)
+#define MVSGI_DHW 0      // 1: the 10 x 8 bricks' tiles as one row of BOTH planes (conflict-free fragment reads, measured 0-1.7 %: DESIGN.md section 3);
+                         // off since the depth skip (DK) wants every wave's tiles in ONE plane
 #endif
         constexpr bool DHW = MVSGI_DHW && TW == 8 && TD == 2 && S == 1 && !PLANE && !V32 && (ITH * ITW * (kVSB / 16)) % 16 == 8;
         const bool second = kg & 1;       // this lane's k-range belongs to the pair's second tap
@@ -1001,6 +1009,13 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
             thv[i] = DHW ? v / (TW * TD) : (v / TW) % TH;
             tdv[i] = DHW ? (v / TW) % TD : v / (TW * TH);
         }
+        if constexpr (D32 && DK < 3) {      // (the launcher checked a.Do == DK: one brick along D, its origin plane 0)
+            static_assert(!DHW, "depth skip: plane-pure waves");
+            const int kd_lo = (TD == 2 ? wm : 0) == 0 ? 1 : 0;      // plane 0 starts at kd = 1, plane 1 of a two-plane volume at kd = 0
+            wpb += kd_lo * 9 * 2048;
+#pragma unroll
+            for (int i = 0; i < MW; ++i) base[i] += kd_lo * (ITH * ITW * kVSB);
+        }
         const long long frame_elems = (long long)a.Do * a.Ho * a.Wo * a.Cout;     // < 2^31 (checked on the host)
         int ctc[NW], ctn[NW];             // clamped cout tiles of the current / the next unit
 #define MVSGI_CTILES(DST, CB)                                                         \
@@ -1017,7 +1032,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
         bf16x8 xh[XB][MW], xl[XB][MW];
 #define MVSGI_LOADW(BUFI, CC, P, CTS)                                                                 \
         _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                              \
-            const char* q_ = wpb + (((long long)(CC) * CT + CTS[j]) * kPairs) * 2048;  /* wave-uniform */ \
+            const char* q_ = wpb + (((long long)(CC) * CT + CTS[j]) * kWBlk) * 2048;  /* wave-uniform */ \
             wh[BUFI][j] = *reinterpret_cast<const bf16x8*>(q_ + (l16 + (unsigned)(P) * 2048u));          \
             wl[BUFI][j] = *reinterpret_cast<const bf16x8*>(q_ + (l16 + (unsigned)(P) * 2048u + 1024u));  \
         }
@@ -1330,6 +1345,24 @@ __global__ __launch_bounds__(512, 2) void conv3d_f16x3_d32_kernel(ConvArgs a) {
     conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, false, false, false, false, true, true>(a);
 }
 
+// ... with the depth skip (DK = 2: two-plane volumes on two-plane bricks; DK = 1: one-plane volumes on one-plane bricks)
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW>
+__global__ __launch_bounds__(512, 2) void conv3d_bf16x3_d32_dk_kernel(ConvArgs a) {
+    conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, false, false, false, false, false, true, TD>(a);
+}
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW>
+__global__ __launch_bounds__(512, 2) void conv3d_f16x3_d32_dk_kernel(ConvArgs a) {
+    conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, false, false, false, false, true, true, TD>(a);
+}
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW>
+__global__ __launch_bounds__(512, 2) void conv3d_bf16x3_d32u_dk_kernel(ConvArgs a) {
+    conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, true, false, false, false, false, true, TD>(a);
+}
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW>
+__global__ __launch_bounds__(512, 2) void conv3d_f16x3_d32u_dk_kernel(ConvArgs a) {
+    conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, true, false, false, false, true, true, TD>(a);
+}
+
 // ... with the trilinear x2 upsample in the producers (UPS)
 template <int NW, int MW, int WM, int WN, int TD, int TH, int TW>
 __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_d32u_kernel(ConvArgs a) {
@@ -1341,7 +1374,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_f16x3_d32u_kernel(ConvArgs a) {
 }
 
 template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false, bool PLANE = false,
-          bool V32 = false, bool WLDS = false, bool F16 = false, bool D32 = false>
+          bool V32 = false, bool WLDS = false, bool F16 = false, bool D32 = false, bool DSK = false>
 int launch_bf16x3(ConvArgs a, hipStream_t st) {
     constexpr int ITD = (TD - 1) * (KD == 1 ? 1 : S) + KD, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
     constexpr int ROWP = V32 ? ((ITW * kVSB + 255) / 256) * 256 : ITW * kVSB;
@@ -1350,7 +1383,13 @@ int launch_bf16x3(ConvArgs a, hipStream_t st) {
     constexpr size_t lds_bytes = (size_t)2 * ((D32 ? 2 : 1) * ITD * ITH * ROWP + (WLDS ? NW * pairs_of(KD) * 2048 : 0)) + (WARM ? 4096 : 0);   // double-buffered image (+ weight slice) (+ the warm-up's dummy KiB per producer wave)
     static_assert(lds_bytes <= 160 * 1024, "LDS images too large");
     void (*kern)(ConvArgs);
-    if constexpr (D32 && UPS && F16) kern = conv3d_f16x3_d32u_kernel<NW, MW, WM, WN, TD, TH, TW>;
+    static_assert(!DSK || (D32 && TD <= 2), "depth skip: 32-channel slices, one- or two-plane bricks");
+    MVSGI_REQUIRE(!DSK || a.Do == TD, "conv3d: the depth-skip kernels serve volumes exactly as deep as their brick (%d planes, got %d)", TD, a.Do);
+    if constexpr (DSK && UPS && F16) kern = conv3d_f16x3_d32u_dk_kernel<NW, MW, WM, WN, TD, TH, TW>;
+    else if constexpr (DSK && UPS) kern = conv3d_bf16x3_d32u_dk_kernel<NW, MW, WM, WN, TD, TH, TW>;
+    else if constexpr (DSK && F16) kern = conv3d_f16x3_d32_dk_kernel<NW, MW, WM, WN, TD, TH, TW>;
+    else if constexpr (DSK) kern = conv3d_bf16x3_d32_dk_kernel<NW, MW, WM, WN, TD, TH, TW>;
+    else if constexpr (D32 && UPS && F16) kern = conv3d_f16x3_d32u_kernel<NW, MW, WM, WN, TD, TH, TW>;
     else if constexpr (D32 && UPS) kern = conv3d_bf16x3_d32u_kernel<NW, MW, WM, WN, TD, TH, TW>;
     else if constexpr (D32 && F16) kern = conv3d_f16x3_d32_kernel<NW, MW, WM, WN, TD, TH, TW>;
     else if constexpr (D32) kern = conv3d_bf16x3_d32_kernel<NW, MW, WM, WN, TD, TH, TW>;

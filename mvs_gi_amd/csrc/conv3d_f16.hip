@@ -26,11 +26,15 @@ int conv3d_launch_b3_f16(int variant, const void* args, hipStream_t st) {
 #undef MVSGI_B3
         case B3_N16_T: return launch_bf16x3<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true, true>(a, st);
 #define MVSGI_B3D(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, false, false, false, false, true, true>(a, st);
+#define MVSGI_B3DK(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, false, false, false, false, true, true, true>(a, st);
 #include "conv3d_b3d_variants.inc"
 #undef MVSGI_B3D
+#undef MVSGI_B3DK
 #define MVSGI_B3DU(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, true, false, false, false, true, true>(a, st);
+#define MVSGI_B3DUK(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, true, false, false, false, true, true, true>(a, st);
 #include "conv3d_b3du_variants.inc"
 #undef MVSGI_B3DU
+#undef MVSGI_B3DUK
     }
     return fail("mvsgi_conv3d_f32: variant %d has no fp16-split form (MVSGI_CONV_F16 goes with MVSGI_CONV_BF16X3 / _C16 / _V32)", variant);
 }
@@ -42,11 +46,15 @@ const char* conv3d_b3_f16_name(int variant) {
 #undef MVSGI_B3
         case B3_N16_T: return "conv3d_f16x3_kernel<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>";
 #define MVSGI_B3D(V, ...) case V: return "conv3d_f16x3_d32_kernel<" #__VA_ARGS__ ">";
+#define MVSGI_B3DK(V, ...) case V: return "conv3d_f16x3_d32_dk_kernel<" #__VA_ARGS__ ">";
 #include "conv3d_b3d_variants.inc"
 #undef MVSGI_B3D
+#undef MVSGI_B3DK
 #define MVSGI_B3DU(V, ...) case V: return "conv3d_f16x3_d32u_kernel<" #__VA_ARGS__ ">";
+#define MVSGI_B3DUK(V, ...) case V: return "conv3d_f16x3_d32u_dk_kernel<" #__VA_ARGS__ ">";
 #include "conv3d_b3du_variants.inc"
 #undef MVSGI_B3DU
+#undef MVSGI_B3DUK
     }
     return nullptr;
 }

@@ -226,6 +226,12 @@ EXPECTED_VARIANT = {        # (B, Cin, Cout, D, H, W) -> brick / unit shape the 
 }
 
 
+def _dk_expected(name: str, D: int) -> bool:
+    """The depth-skip form of a 32-channel-slice kernel: a brick as deep as the volume (template args ..., TD, TH, TW)."""
+    td = int(name.split("<")[1].rstrip(">").split(",")[4])
+    return D == td and D <= 2 and "1, 2, 2, 2, 1, 4, 16" not in name and "2, 2, 2, 2, 1, 4, 16" not in name      # (the small-launch units: any depth)
+
+
 def _conv_case(rng, B, Cin, Cout, D, Hh, W, stride, res, slope, bias=False):
     x = rng.standard_normal((B, Cin, D, Hh, W)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, 3, 3, 3)) / np.sqrt(27 * Cin)).astype(np.float32)
@@ -280,7 +286,9 @@ def test_conv3d_bf16x3_vs_oracle(shape):
     if H.conv3d_d32_applies(B, Cin, D, Hh, W, Cout, stride):      # the same bricks on 32-channel slices (27 k-steps per 32 channels)
         assert Cin % 32 == 0 and stride == 1
         name = H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3_D32)
-        assert name.startswith("conv3d_bf16x3_d32_kernel<") and name.split("<")[1].rstrip(">") in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3)
+        # (volumes one or two planes deep: the depth-skip kernels, which multiply only the kd taps that meet a plane of the volume)
+        assert name.startswith("conv3d_bf16x3_d32_dk_kernel<" if _dk_expected(name, D) else "conv3d_bf16x3_d32_kernel<"), name
+        assert name.split("<")[1].rstrip(">") in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3)
         yd = H.conv3d(xg, wg, H.pack_conv_weights_bf16x3_d32(wg), _g(scale), _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3_D32)
         assert _rel(_ncdhw(yd), yref) <= 1e-4
         assert _rel(_ncdhw(yd), _ncdhw(y)) <= 4e-6      # same products, another summation order
@@ -322,7 +330,8 @@ def test_conv3d_f16x3_vs_oracle(shape):
     assert (eb > 1.5 * err) if not res else (eb >= err or err <= 2.5e-7), (eb, err)   # O(1) beside the x 0.01 convolution hides both splits behind the final add's rounding: an ulp either way)
     if H.conv3d_d32_applies(B, Cin, D, Hh, W, Cout, stride):
         wpd, und = H.pack_conv_weights_f16x3(wg, H.CONV_BF16X3_D32)
-        assert H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3_D32 | H.CONV_F16).startswith("conv3d_f16x3_d32_kernel<")
+        n16 = H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3_D32 | H.CONV_F16)
+        assert n16.startswith("conv3d_f16x3_d32_dk_kernel<" if _dk_expected(n16, D) else "conv3d_f16x3_d32_kernel<"), n16
         yd = H.conv3d(xg, wg, wpd, _g(scale) * und, _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3_D32 | H.CONV_F16)
         assert _rel(_ncdhw(yd), yref) <= 5e-6 and _rel(_ncdhw(yd), _ncdhw(y)) <= 2e-6
     if Cout == 16 and stride == 1:
@@ -427,6 +436,8 @@ def test_conv3d_v32_schedule_vs_oracle(shape):
     (8, 128, 64, 2, 10, 40, True),     # 2 x 4 x 16 bricks x 64 couts at eight frames: also on 32-channel slices
     (12, 64, 96, 3, 5, 9, False),      # ... 96 couts in 64-cout units, ragged
     (16, 64, 96, 4, 10, 10, False),    # ... x 96 couts
+    (48, 64, 96, 1, 10, 40, True),     # out of a ONE-plane level (the upsampled volume is two planes deep): the depth-skip form of those kernels
+    (64, 32, 64, 1, 10, 40, True),     # ... 64 couts
     (1, 64, 32, 4, 20, 80, True),      # the last up block at one frame: 200 units of 4 x 4 x 16 in one round, not 400 of 2 x 4 x 16 in two
 ])
 def test_conv3d_fused_upsample_vs_interpolate_then_conv(shape):
@@ -460,11 +471,11 @@ def test_conv3d_fused_upsample_vs_interpolate_then_conv(shape):
                           w_layout=H.CONV_BF16X3_C16)
         assert _rel(_ncdhw(gp), yref) <= 1e-4
     if H.conv3d_up2_d32_applies(B, Cin, Dl, Hl, Wl, Cout):      # the same launch on 32-channel slices, both splits
-        assert H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, H.CONV_BF16X3_D32).startswith("conv3d_bf16x3_d32u_kernel<")
+        assert H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, H.CONV_BF16X3_D32).startswith("conv3d_bf16x3_d32u_dk_kernel<" if Dl == 1 else "conv3d_bf16x3_d32u_kernel<")
         gd = H.conv3d_up2(xg, H.pack_conv_weights_bf16x3_d32(_g(w)), _g(scale), _g(shift), res=rg, neg_slope=0.01, w_layout=H.CONV_BF16X3_D32)
         assert _rel(_ncdhw(gd), yref) <= 1e-4 and _rel(_ncdhw(gd), _ncdhw(got)) <= 4e-6
         wpd, und = H.pack_conv_weights_f16x3(_g(w), H.CONV_BF16X3_D32)
-        assert H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, H.CONV_BF16X3_D32 | H.CONV_F16).startswith("conv3d_f16x3_d32u_kernel<")
+        assert H.conv3d_up2_variant(B, Cin, Dl, Hl, Wl, Cout, H.CONV_BF16X3_D32 | H.CONV_F16).startswith("conv3d_f16x3_d32u_dk_kernel<" if Dl == 1 else "conv3d_f16x3_d32u_kernel<")
         gd16 = H.conv3d_up2(xg, wpd, _g(scale) * und, _g(shift), res=rg, neg_slope=0.01, w_layout=H.CONV_BF16X3_D32 | H.CONV_F16)
         assert _rel(_ncdhw(gd16), yref) <= 1e-5
     wp16, un16 = H.pack_conv_weights_f16x3(_g(w))      # the fp16 split of the same launch
