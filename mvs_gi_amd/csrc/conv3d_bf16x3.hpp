@@ -302,7 +302,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // stage the unit's weight slice (NW x 28 KiB, contiguous in the packed layout) into LDS beside the activation image, once per
 // workgroup, under the same per-unit barrier; the consumers read weight fragments like activation fragments (XB-deep, restarted
 // per unit): 16 ds_read_b128 per slot and CU instead of 8 KiB of vector-memory returns.
-template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD, bool UPS, bool PLANE, bool V32, bool WLDS, bool F16, bool D32 = false, int DK = 3>
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD, bool UPS, bool PLANE, bool V32, bool WLDS, bool F16, bool D32 = false, int DK = 3, int BRD = 0>
 __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
     // (NW == 1: the producers stage the tiles from pct0 = min(cb * NW, CT - NW) on, the consumers clamp tile by tile -- the two agree for one tile)
     static_assert(!WLDS || (WN == 1 && KD == 3 && !UPS && !PLANE && !V32 && S == 1 && NW == 1 && MW <= 2), "LDS-staged weights: one shared cout tile, one or two voxel tiles per wave");
@@ -406,9 +406,9 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
 // digit order of a unit id above the w-tile: D before H (bricks stacked along D share halo planes and stay an XCD round apart)
 // or, in the -DMVSGI_ORDER_HD diagnostic build, H before D (round 1's order)
 #ifdef MVSGI_ORDER_HD
-#define MVSGI_DECODE_DH(T, OD, OH, B) { OH = (T % a.tiles_h) * TH; T /= a.tiles_h; OD = (T % a.tiles_d) * TD; B = T / a.tiles_d; }
+#define MVSGI_DECODE_DH(T, OD, OH, B) { OH = (T % a.tiles_h) * TH; T /= a.tiles_h; OD = (T % a.tiles_d) * TD + a.od_off; B = T / a.tiles_d; }
 #else
-#define MVSGI_DECODE_DH(T, OD, OH, B) { OD = (T % a.tiles_d) * TD; T /= a.tiles_d; OH = (T % a.tiles_h) * TH; B = T / a.tiles_h; }
+#define MVSGI_DECODE_DH(T, OD, OH, B) { OD = (T % a.tiles_d) * TD + a.od_off; T /= a.tiles_d; OH = (T % a.tiles_h) * TH; B = T / a.tiles_h; }
 #endif
 #define MVSGI_DECODE(ID, CB, B, OD, OH, OW)                       \
     {                                                             \
@@ -986,6 +986,14 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
                          // off since the depth skip (DK) wants every wave's tiles in ONE plane
 #endif
         constexpr bool DHW = MVSGI_DHW && TW == 8 && TD == 2 && S == 1 && !PLANE && !V32 && (ITH * ITW * (kVSB / 16)) % 16 == 8;
+        // BRD, the border-plane skip of the 2 x 4 x 16 bricks on 32-channel slices: a brick at the bottom of a volume (BRD = 1) spends the
+        // kd = 0 taps of its plane 0 on the zero padding, a brick at the top (BRD = 2) the kd = 2 taps of its plane 1 -- a sixth of such
+        // a brick's MFMAs.  Each wave owns two rows of BOTH planes (tiles 0, 1 in plane 0, tiles 2, 3 in plane 1) and the nine slots of
+        // that kd read and multiply the tiles of the other plane only -- at COMPILE time (a wave-uniform run-time branch around a slot's
+        // MFMAs was built first: 1-23 k spilled registers): the launcher covers the bottom bricks, the top bricks and the bricks between
+        // with one launch each (ConvArgs::od_off, tiles_d).  Every 2 x 4 x 16 brick of a 32-channel-slice kernel has the tile order.
+        constexpr bool BSK = D32 && DK == 3 && TD == 2 && WM == 2 && MW == 4 && TH == 4 && TW == 16 && S == 1;
+        static_assert(BRD == 0 || BSK, "border-plane skip: the 2 x 4 x 16 bricks of the 32-channel-slice kernels");
         const bool second = kg & 1;       // this lane's k-range belongs to the pair's second tap
         const char* wpb = reinterpret_cast<const char*>(a.wp);    // uniform base; per-lane part is lane*16
         const unsigned lane16 = lane * 16;
@@ -997,7 +1005,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
             // stride-1 two-plane bricks 8 wide: a tile is the SAME row of both planes (voxel order h, d, w) -- its halves are a plane
             // apart (ITH * ITW * 5 sixteen-byte units = 8 mod 16 for the 10 x 8 bricks: the two halves take disjoint units of a
             // bank row) where two rows of one plane (50 units = 2 mod 16 apart) collide on two of eight units
-            const int w_ = v % TW, h_ = DHW ? v / (TW * TD) : (v / TW) % TH, d_ = DHW ? (v / TW) % TD : v / (TW * TH);
+            const int w_ = v % TW, h_ = BSK ? 2 * wm + (i & 1) : DHW ? v / (TW * TD) : (v / TW) % TH, d_ = BSK ? (BRD == 2 ? 1 - (i >> 1) : (i >> 1)) : DHW ? (v / TW) % TD : v / (TW * TH);
             base[i] = (((d_ * SD) * ITH + h_ * S) * ITW + w_ * S) * kVSB + (kg >> 1) * 16;
         }
         // position of this lane's voxel of each tile inside the brick (unit-independent)
@@ -1006,8 +1014,8 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
         for (int i = 0; i < MW; ++i) {
             const int v = PLANE ? (i * TH + wm) * TW + col : (wm * MW + i) * 16 + col;     // PLANE: tile i = plane i of row wm
             twv[i] = v % TW;
-            thv[i] = DHW ? v / (TW * TD) : (v / TW) % TH;
-            tdv[i] = DHW ? (v / TW) % TD : v / (TW * TH);
+            thv[i] = BSK ? 2 * wm + (i & 1) : DHW ? v / (TW * TD) : (v / TW) % TH;
+            tdv[i] = BSK ? (BRD == 2 ? 1 - (i >> 1) : (i >> 1)) : DHW ? (v / TW) % TD : v / (TW * TH);
         }
         if constexpr (D32 && DK < 3) {      // (the launcher checked a.Do == DK: one brick along D, its origin plane 0)
             static_assert(!DHW, "depth skip: plane-pure waves");
@@ -1030,11 +1038,14 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
         constexpr int XLA = XB > 1 ? XB - 1 : 1;       // slots ahead
         constexpr int MH = XB >= 2 ? MW : MW / 2;      // voxel tiles per half
         bf16x8 xh[XB][MW], xl[XB][MW];
+// (BRD = 2, the bricks at the top of the volume: the slots walk kd = 2, 1, 0 and tiles 0, 1 lie in plane 1 -- the mirror image of
+// BRD = 1, so that the skipped tiles are the first two of the first nine slots in both; the other order spilled hundreds of registers)
+#define MVSGI_TAP(P) (BRD == 2 ? (2 - (P) / 9) * 9 + (P) % 9 : (P))
 #define MVSGI_LOADW(BUFI, CC, P, CTS)                                                                 \
         _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                              \
             const char* q_ = wpb + (((long long)(CC) * CT + CTS[j]) * kWBlk) * 2048;  /* wave-uniform */ \
-            wh[BUFI][j] = *reinterpret_cast<const bf16x8*>(q_ + (l16 + (unsigned)(P) * 2048u));          \
-            wl[BUFI][j] = *reinterpret_cast<const bf16x8*>(q_ + (l16 + (unsigned)(P) * 2048u + 1024u));  \
+            wh[BUFI][j] = *reinterpret_cast<const bf16x8*>(q_ + (l16 + (unsigned)MVSGI_TAP(P) * 2048u));          \
+            wl[BUFI][j] = *reinterpret_cast<const bf16x8*>(q_ + (l16 + (unsigned)MVSGI_TAP(P) * 2048u + 1024u));  \
         }
 #define MVSGI_READX(BUFI, P, I0, I1)                                                                  \
         {                                                                                             \
@@ -1042,7 +1053,8 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
             const int t0_ = 2 * p_, t1_ = (2 * p_ + 1 < kTaps) ? 2 * p_ + 1 : 2 * p_;                 \
             const int o0_ = (((t0_ / 9) * ITH + (t0_ / 3) % 3) * ITW + t0_ % 3) * kVSB;               \
             const int o1_ = (((t1_ / 9) * ITH + (t1_ / 3) % 3) * ITW + t1_ % 3) * kVSB;               \
-            const int od_ = (((p_ / 9) * ITH + (p_ / 3) % 3) * ITW + p_ % 3) * kVSB;      /* D32: tap p_ of sub-image 0 | 1 */ \
+            const int tp_ = MVSGI_TAP(p_);                                                            \
+            const int od_ = (((tp_ / 9) * ITH + (tp_ / 3) % 3) * ITW + tp_ % 3) * kVSB;   /* D32: tap tp_ of sub-image 0 | 1 */ \
             const int off_ = D32 ? od_ + (second ? SUB : 0) : (second ? o1_ : o0_);                   \
             _Pragma("unroll") for (int i = (I0); i < (I1); ++i) {                                     \
                 xh[BUFI][i] = *reinterpret_cast<const bf16x8*>(img + base[i] + off_);                 \
@@ -1235,16 +1247,24 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
                         // one scheduling region per slot: the fragment requests of a later slot (2*NW weight
                         // loads, 2*MW LDS reads) are interleaved one per RATIO MFMAs, so their issue
                         // cycles hide in the MFMA gaps instead of draining the matrix pipe between slots
-                        if (s_ + XLA < kPairs && !(MVSGI_ABL & 2)) MVSGI_READX(xnxt, s_ + XLA, 0, MW)
-                        if (!(MVSGI_ABL & 16)) { MVSGI_MFMAS(wcur, xcur, 0, MW) }
+                        // (BRD: the tiles of the plane whose tap of this slot meets the padding are neither read nor multiplied)
+#define MVSGI_T0(SL) ((BRD != 0 && (SL) < 9) ? MW / 2 : 0)
+#define MVSGI_T1(SL) (MW)
+                        if (s_ + XLA < kPairs && !(MVSGI_ABL & 2)) MVSGI_READX(xnxt, s_ + XLA, MVSGI_T0(s_ + XLA), MVSGI_T1(s_ + XLA))
+                        if (!(MVSGI_ABL & 16)) { MVSGI_MFMAS(wcur, xcur, MVSGI_T0(s_), MVSGI_T1(s_)) }
                         constexpr int NMEM = 2 * NW + 2 * MW, NMFMA = 3 * MW * NW;
                         constexpr int RATIO = NMFMA / NMEM > 0 ? NMFMA / NMEM : 1;
+                        // (the interleave pattern counts a FULL slot: the border-skipped slots, which hold half the tiles, and the slot
+                        // before them are left to the compiler -- with the pattern on them the BRD = 2 kernels spilled hundreds of registers)
+                        const bool full_ = MVSGI_T1(s_) - MVSGI_T0(s_) == MW && (s_ + XLA >= kPairs || MVSGI_T1(s_ + XLA) - MVSGI_T0(s_ + XLA) == MW);
+                        if (full_) {
 #pragma unroll
                         for (int q_ = 0; q_ < NMEM; ++q_) {
                             __builtin_amdgcn_sched_group_barrier(0x008, RATIO, 0);      // MFMA
                             __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);          // VMEM read | DS read
                         }
                         __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);          // the rest
+                        }
                     } else {
                         __builtin_amdgcn_sched_barrier(0);
                         MVSGI_MFMAS(wcur, 0, 0, MH)
@@ -1309,6 +1329,9 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
             __syncthreads();                               // image of unit u+1 complete, image u free
             STAMP()
         }
+#undef MVSGI_T0
+#undef MVSGI_T1
+#undef MVSGI_TAP
 #undef MVSGI_PL_LOADW
 #undef MVSGI_PL_READX
 #undef MVSGI_PL_MFMAS
@@ -1363,6 +1386,24 @@ __global__ __launch_bounds__(512, 2) void conv3d_f16x3_d32u_dk_kernel(ConvArgs a
     conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, true, false, false, false, true, true, TD>(a);
 }
 
+// ... the bricks at the bottom (BRD = 1) / at the top (BRD = 2) of a volume: the border-plane skip
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int BRD>
+__global__ __launch_bounds__(512, 2) void conv3d_bf16x3_d32_brd_kernel(ConvArgs a) {
+    conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, false, false, false, false, false, true, 3, BRD>(a);
+}
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int BRD>
+__global__ __launch_bounds__(512, 2) void conv3d_f16x3_d32_brd_kernel(ConvArgs a) {
+    conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, false, false, false, false, true, true, 3, BRD>(a);
+}
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int BRD>
+__global__ __launch_bounds__(512, 2) void conv3d_bf16x3_d32u_brd_kernel(ConvArgs a) {
+    conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, true, false, false, false, false, true, 3, BRD>(a);
+}
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int BRD>
+__global__ __launch_bounds__(512, 2) void conv3d_f16x3_d32u_brd_kernel(ConvArgs a) {
+    conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, true, false, false, false, true, true, 3, BRD>(a);
+}
+
 // ... with the trilinear x2 upsample in the producers (UPS)
 template <int NW, int MW, int WM, int WN, int TD, int TH, int TW>
 __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_d32u_kernel(ConvArgs a) {
@@ -1374,7 +1415,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_f16x3_d32u_kernel(ConvArgs a) {
 }
 
 template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int S, int KD = 3, bool UPS = false, bool PLANE = false,
-          bool V32 = false, bool WLDS = false, bool F16 = false, bool D32 = false, bool DSK = false>
+          bool V32 = false, bool WLDS = false, bool F16 = false, bool D32 = false, bool DSK = false, int BRD = 0>
 int launch_bf16x3(ConvArgs a, hipStream_t st) {
     constexpr int ITD = (TD - 1) * (KD == 1 ? 1 : S) + KD, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
     constexpr int ROWP = V32 ? ((ITW * kVSB + 255) / 256) * 256 : ITW * kVSB;
@@ -1385,7 +1426,11 @@ int launch_bf16x3(ConvArgs a, hipStream_t st) {
     void (*kern)(ConvArgs);
     static_assert(!DSK || (D32 && TD <= 2), "depth skip: 32-channel slices, one- or two-plane bricks");
     MVSGI_REQUIRE(!DSK || a.Do == TD, "conv3d: the depth-skip kernels serve volumes exactly as deep as their brick (%d planes, got %d)", TD, a.Do);
-    if constexpr (DSK && UPS && F16) kern = conv3d_f16x3_d32u_dk_kernel<NW, MW, WM, WN, TD, TH, TW>;
+    if constexpr (BRD != 0 && UPS && F16) kern = conv3d_f16x3_d32u_brd_kernel<NW, MW, WM, WN, TD, TH, TW, BRD>;
+    else if constexpr (BRD != 0 && UPS) kern = conv3d_bf16x3_d32u_brd_kernel<NW, MW, WM, WN, TD, TH, TW, BRD>;
+    else if constexpr (BRD != 0 && F16) kern = conv3d_f16x3_d32_brd_kernel<NW, MW, WM, WN, TD, TH, TW, BRD>;
+    else if constexpr (BRD != 0) kern = conv3d_bf16x3_d32_brd_kernel<NW, MW, WM, WN, TD, TH, TW, BRD>;
+    else if constexpr (DSK && UPS && F16) kern = conv3d_f16x3_d32u_dk_kernel<NW, MW, WM, WN, TD, TH, TW>;
     else if constexpr (DSK && UPS) kern = conv3d_bf16x3_d32u_dk_kernel<NW, MW, WM, WN, TD, TH, TW>;
     else if constexpr (DSK && F16) kern = conv3d_f16x3_d32_dk_kernel<NW, MW, WM, WN, TD, TH, TW>;
     else if constexpr (DSK) kern = conv3d_bf16x3_d32_dk_kernel<NW, MW, WM, WN, TD, TH, TW>;
@@ -1399,10 +1444,32 @@ int launch_bf16x3(ConvArgs a, hipStream_t st) {
     static mvsgi::PersistentGeom geo_cache[mvsgi::kMaxDevices] = {};
     mvsgi::PersistentGeom geo;
     if (mvsgi::persistent_geometry(kern, 512, lds_bytes, 2, geo_cache, "conv3d(bf16x3)", geo)) return 1;
-    a.tiles_d = (int)mvsgi::cdiv(a.Do, TD);
     a.tiles_h = (int)mvsgi::cdiv(a.Ho, TH);
     a.tiles_w = (int)mvsgi::cdiv(a.Wo, TW);
     const int CT = a.Cout / (V32 ? 32 : 16);
+    // The border-plane skip (conv3d_x3_body, BRD): the bricks at the bottom and at the top of the volume as launches of their own on
+    // kernels that leave out the taps meeting the padding, the bricks between on this one -- where a layer of bricks is rounds of
+    // the chip by itself (a few-round launch would pay three prologues and three tails for it)
+    constexpr bool kBorderSplit = D32 && !DSK && BRD == 0 && TD == 2 && WM == 2 && MW == 4 && TH == 4 && TW == 16 && S == 1;
+    if constexpr (kBorderSplit) {
+        const long long layer = (long long)a.B * a.tiles_h * a.tiles_w * mvsgi::cdiv(CT, WN * NW);
+        // (measured, tools/d32_probe.py: at D = 4 -- two launches, every brick a border brick -- 64 -> 64 [4,20,80] x 128 0.94 -> 0.90 of
+        // the tap-pair kernel; at D = 8, 16 the third launch and the shorter walks cost what the skipped sixth of 2 of 4 / 2 of 8
+        // bricks saves: 96 -> 96 [16,80,320] x 8 0.931 -> 0.964.  So: volumes four planes deep.)
+        const char* dmax_ = mvsgi::exp_env("MVSGI_BSK_DMAX");
+        if (a.od_cnt == 0 && a.Do >= 4 && a.Do <= (dmax_ ? atoi(dmax_) : 4) && a.Do % 2 == 0 && layer >= 4ll * geo.cus && !mvsgi::exp_env("MVSGI_NO_BSK")) {
+            ConvArgs b = a;
+            b.od_cnt = 1;
+            b.od_off = 0;
+            if (launch_bf16x3<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32, WLDS, F16, D32, DSK, 1>(b, st)) return 1;
+            b.od_off = a.Do - 2;
+            if (launch_bf16x3<NW, MW, WM, WN, TD, TH, TW, S, KD, UPS, PLANE, V32, WLDS, F16, D32, DSK, 2>(b, st)) return 1;
+            if (a.Do == 4) return 0;
+            a.od_off = 2;
+            a.od_cnt = a.Do / 2 - 2;
+        }
+    }
+    a.tiles_d = a.od_cnt > 0 ? a.od_cnt : (int)mvsgi::cdiv(a.Do, TD);
     const long long nb = (long long)a.B * a.tiles_d * a.tiles_h * a.tiles_w * mvsgi::cdiv(CT, WN * NW);
     MVSGI_REQUIRE(nb < (1ll << 31), "conv3d: too many units");
     MVSGI_REQUIRE((long long)a.Din * a.Hin * a.Win * a.Cin < (1ll << 29), "conv3d: volume too large for 32-bit byte offsets");

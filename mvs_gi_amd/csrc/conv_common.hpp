@@ -15,6 +15,8 @@ struct ConvArgs {
     int B, Cin, Din, Hin, Win, Cout, Do, Ho, Wo, stride;
     float neg_slope;   // act(v) = v > 0 ? v : v * neg_slope; 1.0 = identity
     int tiles_d, tiles_h, tiles_w;
+    int od_off, od_cnt; // first output plane and number of depth bricks of this launch (a launch over a range of depth bricks: the
+                       // border-plane skip); od_cnt = 0: the whole depth
     int total_units;   // persistent bf16x3 kernel: bricks x cout blocks
     unsigned char* y_split;    // bf16x3 kernels: when set, the output goes here in the split-padded format (conv3d_rs.hip) instead of y
     unsigned long long* dbg;   // MVSGI_STAMPS diagnostic build only

@@ -205,6 +205,8 @@ CONV_SHAPES = [
     (24, 64, 128, 1, 15, 21, 1, True, 0.01),    # one-plane 1 x 5 x 16 x 128
     (64, 32, 192, 1, 15, 21, 1, False, 0.01),   # one-plane 1 x 5 x 16 x 192
     (64, 32, 192, 1, 10, 40, 1, False, 0.01),   # one-plane 1 x 10 x 8 x 192
+    (48, 32, 64, 4, 20, 80, 1, True, 0.01),     # a volume FOUR planes deep in layers of >= 4 rounds of bricks: the border-plane skip (bottom bricks and top
+    (44, 32, 96, 4, 18, 70, 1, False, 0.01),    # bricks as launches of their own on kernels without the taps that meet the padding), 64- and 96-cout units, ragged
     (1, 64, 128, 4, 20, 80, 2, False, 0.01),    # the stride-2 conv into UNet level 2 at one frame: 60 units of 32 couts, not 30 of 64
     (8, 64, 128, 4, 20, 80, 2, False, 0.01),    # ... at eight frames: 64-cout units
     (1, 64, 64, 4, 20, 80, 1, True, 0.01),      # UNet level 1 at one frame: 200 units of 32 couts, waves as (voxel half, cout tile)
@@ -436,6 +438,7 @@ def test_conv3d_v32_schedule_vs_oracle(shape):
     (8, 128, 64, 2, 10, 40, True),     # 2 x 4 x 16 bricks x 64 couts at eight frames: also on 32-channel slices
     (12, 64, 96, 3, 5, 9, False),      # ... 96 couts in 64-cout units, ragged
     (16, 64, 96, 4, 10, 10, False),    # ... x 96 couts
+    (48, 32, 64, 2, 10, 40, True),     # onto a volume FOUR planes deep, layers of >= 4 rounds of bricks: the border-plane skip of the fused form
     (48, 64, 96, 1, 10, 40, True),     # out of a ONE-plane level (the upsampled volume is two planes deep): the depth-skip form of those kernels
     (64, 32, 64, 1, 10, 40, True),     # ... 64 couts
     (1, 64, 32, 4, 20, 80, True),      # the last up block at one frame: 200 units of 4 x 4 x 16 in one round, not 400 of 2 x 4 x 16 in two
