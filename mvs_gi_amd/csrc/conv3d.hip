@@ -340,9 +340,11 @@ const char* const kVariantNames[] = {
     "conv3d_bf16x3_kernel<1, 2, 4, 1, 4, 4, 16, 1, 3, true, false, true, false>", "conv3d_bf16x3_kernel<1, 2, 2, 2, 2, 4, 16, 1, 3, true, false, true, false>",
 #define MVSGI_B3D(V, ...) "conv3d_bf16x3_d32_kernel<" #__VA_ARGS__ ">",
 #define MVSGI_B3DK(V, ...) "conv3d_bf16x3_d32_dk_kernel<" #__VA_ARGS__ ">",
+#define MVSGI_B3DK2(V, ...) "conv3d_bf16x3_d32_dk2_kernel<" #__VA_ARGS__ ">",
 #include "conv3d_b3d_variants.inc"
 #undef MVSGI_B3D
 #undef MVSGI_B3DK
+#undef MVSGI_B3DK2
 #define MVSGI_B3DU(V, ...) "conv3d_bf16x3_d32u_kernel<" #__VA_ARGS__ ">",
 #define MVSGI_B3DUK(V, ...) "conv3d_bf16x3_d32u_dk_kernel<" #__VA_ARGS__ ">",
 #include "conv3d_b3du_variants.inc"
@@ -429,8 +431,11 @@ int d32_variant(const ConvArgs& a) {
         case B3_N128_PW8: return B3D_N128_PW8;
         case B3_N192_PH5: return B3D_N192_PH5;
         case B3_N192_PW8: return B3D_N192_PW8;
-        case B3_N32_TB: return B3D_N32_TB;
-        case B3_N64_S: return B3D_N64_S;
+        // (a volume two planes deep on the one-plane small-launch units: 18 of 27 slots; also instead of the 16-cout units with their
+        // weight slice in LDS, which are tap-pair kernels: 128 -> 128 on one [2,10,40] frame 13.2 us)
+        case B3_N16_TW: return d2 && a.Cout % 32 == 0 ? B3D2_N32_TB : V_COUNT;
+        case B3_N32_TB: return d2 ? B3D2_N32_TB : B3D_N32_TB;
+        case B3_N64_S: return d2 ? B3D2_N64_S : B3D_N64_S;
         default: return V_COUNT;
     }
 }
@@ -620,9 +625,11 @@ int launch_variant(int v, const ConvArgs& a, hipStream_t st) {
 #undef MVSGI_B3
 #define MVSGI_B3D(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, false, false, false, false, false, true>(a, st);
 #define MVSGI_B3DK(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, false, false, false, false, false, true, true>(a, st);
+#define MVSGI_B3DK2(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, false, false, false, false, false, true, true, 3>(a, st);
 #include "conv3d_b3d_variants.inc"
 #undef MVSGI_B3D
 #undef MVSGI_B3DK
+#undef MVSGI_B3DK2
 #define MVSGI_B3DU(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, true, false, false, false, false, true>(a, st);
 #define MVSGI_B3DUK(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, true, false, false, false, false, true, true>(a, st);
 #include "conv3d_b3du_variants.inc"

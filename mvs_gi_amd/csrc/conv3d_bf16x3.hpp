@@ -324,7 +324,10 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
     // padding: DK = 2 of 3 kd at D = 2, 1 of 3 at D = 1, for every wave of the workgroup alike.  With one tap per slot and the taps
     // kd-major that is a WINDOW of 9 DK slots: the wave's weight pointer and its fragment offsets start kd_lo taps (= planes of the
     // LDS image) in.  A tap PAIR straddles two kd: only the 32-channel-slice form can do this.
-    static_assert(DK == 3 || (D32 && DK >= 1 && (TD == 1 ? DK == 1 : (TD == 2 && WM == 2 && MW * 16 == TH * TW))), "depth skip: one- or two-plane bricks whose waves own whole planes");
+    static_assert(DK == 3 || (D32 && DK >= 1 && (TD == 1 ? DK <= 2 : (TD == 2 && WM == 2 && MW * 16 == TH * TW))), "depth skip: one- or two-plane bricks whose waves own whole planes");
+    // (TD == 1 && DK == 2: ONE-plane bricks of a TWO-plane volume -- the small-launch units at UNet's level 2: the window of 18 slots starts
+    // at kd = 1 for a brick of plane 0 and at kd = 0 for a brick of plane 1, per UNIT)
+    constexpr bool DKU = D32 && TD == 1 && DK == 2;
     constexpr int kTaps = KD * 9, kPairs = D32 ? 9 * DK : pairs_of(KD);
     constexpr int kWBlk = D32 ? 27 : kPairs;       // weight fragments per (slice, cout tile) block of the packed weights
     constexpr int ITD = (TD - 1) * SD + KD, ITH = (TH - 1) * S + 3, ITW = (TW - 1) * S + 3;
@@ -1017,7 +1020,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
             thv[i] = BSK ? 2 * wm + (i & 1) : DHW ? v / (TW * TD) : (v / TW) % TH;
             tdv[i] = BSK ? (BRD == 2 ? 1 - (i >> 1) : (i >> 1)) : DHW ? (v / TW) % TD : v / (TW * TH);
         }
-        if constexpr (D32 && DK < 3) {      // (the launcher checked a.Do == DK: one brick along D, its origin plane 0)
+        if constexpr (D32 && DK < 3 && !DKU) {      // (the launcher checked a.Do == DK: one brick along D, its origin plane 0)
             static_assert(!DHW, "depth skip: plane-pure waves");
             const int kd_lo = (TD == 2 ? wm : 0) == 0 ? 1 : 0;      // plane 0 starts at kd = 1, plane 1 of a two-plane volume at kd = 0
             wpb += kd_lo * 9 * 2048;
@@ -1041,9 +1044,10 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
 // (BRD = 2, the bricks at the top of the volume: the slots walk kd = 2, 1, 0 and tiles 0, 1 lie in plane 1 -- the mirror image of
 // BRD = 1, so that the skipped tiles are the first two of the first nine slots in both; the other order spilled hundreds of registers)
 #define MVSGI_TAP(P) (BRD == 2 ? (2 - (P) / 9) * 9 + (P) % 9 : (P))
-#define MVSGI_LOADW(BUFI, CC, P, CTS)                                                                 \
+#define MVSGI_LOADW(BUFI, CC, P, CTS) MVSGI_LOADWB(wpb, BUFI, CC, P, CTS)
+#define MVSGI_LOADWB(WPB, BUFI, CC, P, CTS)                                                           \
         _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                              \
-            const char* q_ = wpb + (((long long)(CC) * CT + CTS[j]) * kWBlk) * 2048;  /* wave-uniform */ \
+            const char* q_ = (WPB) + (((long long)(CC) * CT + CTS[j]) * kWBlk) * 2048;  /* wave-uniform */ \
             wh[BUFI][j] = *reinterpret_cast<const bf16x8*>(q_ + (l16 + (unsigned)MVSGI_TAP(P) * 2048u));          \
             wl[BUFI][j] = *reinterpret_cast<const bf16x8*>(q_ + (l16 + (unsigned)MVSGI_TAP(P) * 2048u + 1024u));  \
         }
@@ -1130,14 +1134,14 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
         } else if constexpr (!WLDS) {
             unsigned l16 = lane16;
 #pragma unroll
-            for (int s0 = 0; s0 < LA; ++s0) { MVSGI_LOADW(s0, 0, s0, ctc) }
+            for (int s0 = 0; s0 < LA; ++s0) { MVSGI_LOADWB(wpb + (DKU && od0 == 0 ? 9 * 2048 : 0), s0, 0, s0, ctc) }
         }
         STAMP()
         __syncthreads();                                   // image 0 holds unit 0
         STAMP()
         int k = 0, cc = 0;
         for (int u = 0; u < U; ++u) {
-            const unsigned char* img = ldsb + (u & 1) * BUFW;
+            const unsigned char* img = ldsb + (u & 1) * BUFW + (DKU && od0 == 0 ? ITH * ITW * kVSB : 0);      // (DKU: plane 0 starts at kd = 1)
             const bool last = cc + 1 == nchunks;
             const bool more = u + 1 < U;
             const int ncc = last ? 0 : cc + 1;
@@ -1149,6 +1153,9 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
 #pragma unroll
                 for (int j = 0; j < NW; ++j) ctn[j] = ctc[j];
             }
+            // weight bases of this unit's slice and of the slice after it (DKU: the unit's window of taps starts at kd = 1 in plane 0)
+            const char* const wpc_ = wpb + (DKU && od0 == 0 ? 9 * 2048 : 0);
+            const char* const wpn_ = wpb + (DKU && nod0 == 0 ? 9 * 2048 : 0);
             // per-channel scale / shift of this wave's cout tiles: requested before the last slice is
             // multiplied so the epilogue does not wait for them one tile at a time
             f32x4 esc[NW], esh[NW], rres[RPRE ? MW : 1][RPRE ? NW : 1];
@@ -1225,11 +1232,11 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
                 // weight fragments LA slots ahead (this slice, or the first slots of the next unit)
                 if (!(MVSGI_ABL & 1) && !WLDS) {
                     if (s_ + LA < NSLOT) {
-                        if (s_ + LA < kPairs) { MVSGI_LOADW((s_ + LA) % WB, cc, s_ + LA, ctc) }
+                        if (s_ + LA < kPairs) { MVSGI_LOADWB(wpc_, (s_ + LA) % WB, cc, s_ + LA, ctc) }
                     } else {
                         // unconditional (past the last unit: chunk 0 of this one again, unused): under `if (more)` the
                         // compiler must assume the requests were never made and waits for far younger loads than needed
-                        MVSGI_LOADW((s_ + LA - NSLOT) % WB, ncc, s_ + LA - NSLOT, ctn)
+                        MVSGI_LOADWB(wpn_, (s_ + LA - NSLOT) % WB, ncc, s_ + LA - NSLOT, ctn)
                     }
                 }
                 if (RPRE && s_ == kPairs - 1 && last && a.res) {
@@ -1386,6 +1393,16 @@ __global__ __launch_bounds__(512, 2) void conv3d_f16x3_d32u_dk_kernel(ConvArgs a
     conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, true, false, false, false, true, true, TD>(a);
 }
 
+// ... one-plane bricks in a TWO-plane volume (the small-launch units at UNet's level 2): 18 slots, the window starts per unit
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW>
+__global__ __launch_bounds__(512, 2) void conv3d_bf16x3_d32_dk2_kernel(ConvArgs a) {
+    conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, false, false, false, false, false, true, 2>(a);
+}
+template <int NW, int MW, int WM, int WN, int TD, int TH, int TW>
+__global__ __launch_bounds__(512, 2) void conv3d_f16x3_d32_dk2_kernel(ConvArgs a) {
+    conv3d_x3_body<NW, MW, WM, WN, TD, TH, TW, 1, 3, false, false, false, false, true, true, 2>(a);
+}
+
 // ... the bricks at the bottom (BRD = 1) / at the top (BRD = 2) of a volume: the border-plane skip
 template <int NW, int MW, int WM, int WN, int TD, int TH, int TW, int BRD>
 __global__ __launch_bounds__(512, 2) void conv3d_bf16x3_d32_brd_kernel(ConvArgs a) {
@@ -1425,8 +1442,12 @@ int launch_bf16x3(ConvArgs a, hipStream_t st) {
     static_assert(lds_bytes <= 160 * 1024, "LDS images too large");
     void (*kern)(ConvArgs);
     static_assert(!DSK || (D32 && TD <= 2), "depth skip: 32-channel slices, one- or two-plane bricks");
-    MVSGI_REQUIRE(!DSK || a.Do == TD, "conv3d: the depth-skip kernels serve volumes exactly as deep as their brick (%d planes, got %d)", TD, a.Do);
-    if constexpr (BRD != 0 && UPS && F16) kern = conv3d_f16x3_d32u_brd_kernel<NW, MW, WM, WN, TD, TH, TW, BRD>;
+    constexpr bool DKU = DSK && BRD == 3;      // one-plane bricks in a two-plane volume (BRD = 3 here: the launcher's name for that mode)
+    static_assert(!DKU || (TD == 1 && !UPS), "per-unit depth skip: one-plane bricks");
+    MVSGI_REQUIRE(!DSK || a.Do == (DKU ? 2 : TD), "conv3d: the depth-skip kernels serve volumes exactly %d planes deep (got %d)", DKU ? 2 : TD, a.Do);
+    if constexpr (DKU && F16) kern = conv3d_f16x3_d32_dk2_kernel<NW, MW, WM, WN, TD, TH, TW>;
+    else if constexpr (DKU) kern = conv3d_bf16x3_d32_dk2_kernel<NW, MW, WM, WN, TD, TH, TW>;
+    else if constexpr (BRD != 0 && UPS && F16) kern = conv3d_f16x3_d32u_brd_kernel<NW, MW, WM, WN, TD, TH, TW, BRD>;
     else if constexpr (BRD != 0 && UPS) kern = conv3d_bf16x3_d32u_brd_kernel<NW, MW, WM, WN, TD, TH, TW, BRD>;
     else if constexpr (BRD != 0 && F16) kern = conv3d_f16x3_d32_brd_kernel<NW, MW, WM, WN, TD, TH, TW, BRD>;
     else if constexpr (BRD != 0) kern = conv3d_bf16x3_d32_brd_kernel<NW, MW, WM, WN, TD, TH, TW, BRD>;

@@ -27,9 +27,11 @@ int conv3d_launch_b3_f16(int variant, const void* args, hipStream_t st) {
         case B3_N16_T: return launch_bf16x3<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true, true>(a, st);
 #define MVSGI_B3D(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, false, false, false, false, true, true>(a, st);
 #define MVSGI_B3DK(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, false, false, false, false, true, true, true>(a, st);
+#define MVSGI_B3DK2(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, false, false, false, false, true, true, true, 3>(a, st);
 #include "conv3d_b3d_variants.inc"
 #undef MVSGI_B3D
 #undef MVSGI_B3DK
+#undef MVSGI_B3DK2
 #define MVSGI_B3DU(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, true, false, false, false, true, true>(a, st);
 #define MVSGI_B3DUK(V, ...) case V: return launch_bf16x3<__VA_ARGS__, 1, 3, true, false, false, false, true, true, true>(a, st);
 #include "conv3d_b3du_variants.inc"
@@ -47,9 +49,11 @@ const char* conv3d_b3_f16_name(int variant) {
         case B3_N16_T: return "conv3d_f16x3_kernel<1, 1, 4, 1, 1, 4, 16, 1, 3, false, false, false, true>";
 #define MVSGI_B3D(V, ...) case V: return "conv3d_f16x3_d32_kernel<" #__VA_ARGS__ ">";
 #define MVSGI_B3DK(V, ...) case V: return "conv3d_f16x3_d32_dk_kernel<" #__VA_ARGS__ ">";
+#define MVSGI_B3DK2(V, ...) case V: return "conv3d_f16x3_d32_dk2_kernel<" #__VA_ARGS__ ">";
 #include "conv3d_b3d_variants.inc"
 #undef MVSGI_B3D
 #undef MVSGI_B3DK
+#undef MVSGI_B3DK2
 #define MVSGI_B3DU(V, ...) case V: return "conv3d_f16x3_d32u_kernel<" #__VA_ARGS__ ">";
 #define MVSGI_B3DUK(V, ...) case V: return "conv3d_f16x3_d32u_dk_kernel<" #__VA_ARGS__ ">";
 #include "conv3d_b3du_variants.inc"

@@ -26,6 +26,7 @@ enum Variant {
     // the large-launch bricks only (conv3d_b3d_variants.inc)
     B3D_N64, B3D_N64_H5, B3D_N64_W8, B3D_N96, B3D_N96_H5, B3D_N96_W8, B3D_N128_P, B3D_N128_PH5, B3D_N128_PW8, B3D_N192_PH5, B3D_N192_PW8, B3D_N32_TB, B3D_N64_S,
     B3D2_N64, B3D2_N64_H5, B3D2_N64_W8, B3D2_N96, B3D2_N96_H5, B3D2_N96_W8,      // ... two-plane volumes: the depth skip
+    B3D2_N32_TB, B3D2_N64_S,
     B3DU_N64, B3DU_N96, B3DU2_N64, B3DU2_N96,      // ... with the fused upsample (conv3d_b3du_variants.inc)
     V_COUNT
 };

@@ -205,6 +205,8 @@ CONV_SHAPES = [
     (24, 64, 128, 1, 15, 21, 1, True, 0.01),    # one-plane 1 x 5 x 16 x 128
     (64, 32, 192, 1, 15, 21, 1, False, 0.01),   # one-plane 1 x 5 x 16 x 192
     (64, 32, 192, 1, 10, 40, 1, False, 0.01),   # one-plane 1 x 10 x 8 x 192
+    (1, 128, 128, 2, 10, 40, 1, True, 0.01),    # UNet level 2 at one frame: the one-plane 32-cout units with the depth skip per unit (18 of 27 slots)
+    (5, 64, 128, 2, 10, 40, 1, True, 0.01),     # ... 64-cout units
     (48, 32, 64, 4, 20, 80, 1, True, 0.01),     # a volume FOUR planes deep in layers of >= 4 rounds of bricks: the border-plane skip (bottom bricks and top
     (44, 32, 96, 4, 18, 70, 1, False, 0.01),    # bricks as launches of their own on kernels without the taps that meet the padding), 64- and 96-cout units, ragged
     (1, 64, 128, 4, 20, 80, 2, False, 0.01),    # the stride-2 conv into UNet level 2 at one frame: 60 units of 32 couts, not 30 of 64
@@ -228,10 +230,15 @@ EXPECTED_VARIANT = {        # (B, Cin, Cout, D, H, W) -> brick / unit shape the 
 }
 
 
-def _dk_expected(name: str, D: int) -> bool:
-    """The depth-skip form of a 32-channel-slice kernel: a brick as deep as the volume (template args ..., TD, TH, TW)."""
-    td = int(name.split("<")[1].rstrip(">").split(",")[4])
-    return D == td and D <= 2 and "1, 2, 2, 2, 1, 4, 16" not in name and "2, 2, 2, 2, 1, 4, 16" not in name      # (the small-launch units: any depth)
+def _d32_kernel_expected(prefix: str, name: str, D: int) -> str:
+    """The name a 32-channel-slice launch must carry (`name`: what the library says; template args ..., TD, TH, TW): the depth-skip
+    forms where the volume is as deep as the brick (_dk_) or two planes deep on a one-plane small-launch unit (_dk2_)."""
+    args = name.split("<")[1].rstrip(">")
+    td = int(args.split(",")[4])
+    small = args in ("1, 2, 2, 2, 1, 4, 16", "2, 2, 2, 2, 1, 4, 16")
+    if small:
+        return prefix + ("_d32_dk2_kernel<" if D == 2 else "_d32_kernel<")
+    return prefix + ("_d32_dk_kernel<" if (D == td and D <= 2) else "_d32_kernel<")
 
 
 def _conv_case(rng, B, Cin, Cout, D, Hh, W, stride, res, slope, bias=False):
@@ -289,8 +296,11 @@ def test_conv3d_bf16x3_vs_oracle(shape):
         assert Cin % 32 == 0 and stride == 1
         name = H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3_D32)
         # (volumes one or two planes deep: the depth-skip kernels, which multiply only the kd taps that meet a plane of the volume)
-        assert name.startswith("conv3d_bf16x3_d32_dk_kernel<" if _dk_expected(name, D) else "conv3d_bf16x3_d32_kernel<"), name
-        assert name.split("<")[1].rstrip(">") in H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3)
+        assert name.startswith(_d32_kernel_expected("conv3d_bf16x3", name, D)), name
+        base = H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3)
+        # the same brick as the tap-pair choice -- except a two-plane volume's one-round launch, which takes the 32-cout units with the
+        # depth skip instead of the 16-cout units with their weight slice in LDS
+        assert name.split("<")[1].rstrip(">") in base or ("dk2" in name and "<1, 1, 4, 1, 1, 4, 16" in base), (name, base)
         yd = H.conv3d(xg, wg, H.pack_conv_weights_bf16x3_d32(wg), _g(scale), _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3_D32)
         assert _rel(_ncdhw(yd), yref) <= 1e-4
         assert _rel(_ncdhw(yd), _ncdhw(y)) <= 4e-6      # same products, another summation order
@@ -333,7 +343,7 @@ def test_conv3d_f16x3_vs_oracle(shape):
     if H.conv3d_d32_applies(B, Cin, D, Hh, W, Cout, stride):
         wpd, und = H.pack_conv_weights_f16x3(wg, H.CONV_BF16X3_D32)
         n16 = H.conv3d_variant(B, Cin, D, Hh, W, Cout, stride, H.CONV_BF16X3_D32 | H.CONV_F16)
-        assert n16.startswith("conv3d_f16x3_d32_dk_kernel<" if _dk_expected(n16, D) else "conv3d_f16x3_d32_kernel<"), n16
+        assert n16.startswith(_d32_kernel_expected("conv3d_f16x3", n16, D)), n16
         yd = H.conv3d(xg, wg, wpd, _g(scale) * und, _g(shift), res=rg, stride=stride, neg_slope=slope, impl=H.CONV_BF16X3_D32 | H.CONV_F16)
         assert _rel(_ncdhw(yd), yref) <= 5e-6 and _rel(_ncdhw(yd), _ncdhw(y)) <= 2e-6
     if Cout == 16 and stride == 1:
