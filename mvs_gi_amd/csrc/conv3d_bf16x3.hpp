@@ -692,11 +692,14 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
             _Pragma("unroll") for (int it = 0; it < WNIT; ++it)                                         \
                 *reinterpret_cast<f32x4*>((DST) + BUF + (wave - 4) * 1024 + lane * 16 + it * 4096) = WPRE[it]; \
         }
+// (BRD: the image plane below a bottom brick / above a top brick lies outside the volume and its only readers are the skipped slots:
+// the items that lie wholly in it -- a fifth of a unit's staging -- are neither requested nor written)
+#define MVSGI_ITEM_DEAD(IT) (BRD == 1 ? ((IT) + 1) * 256 <= ITH * ITW * (1 << QB) : BRD == 2 ? (IT) * 256 >= (ITD - 1) * ITH * ITW * (1 << QB) : false)
 #define MVSGI_ISSUE(PRE, OK, WPRE)                                                                      \
         {                                                                                               \
             MVSGI_ISSUE_BEGIN()                                                                         \
             MVSGI_WISSUE(WPRE)                                                                          \
-            _Pragma("unroll") for (int it = 0; it < NIT; ++it) { MVSGI_ISSUE1(PRE, it) }                \
+            _Pragma("unroll") for (int it = 0; it < NIT; ++it) { if (!MVSGI_ITEM_DEAD(it)) MVSGI_ISSUE1(PRE, it) } \
             MVSGI_ISSUE_END(OK)                                                                         \
         }
 #define MVSGI_PUT1(PRE, OK, DST, IT)                                                                    \
@@ -717,7 +720,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
             }                                                                                           \
         }
 #define MVSGI_PUT(PRE, OK, DST)                                                                         \
-        { _Pragma("unroll") for (int it = 0; it < NIT; ++it) MVSGI_PUT1(PRE, OK, DST, it) }
+        { _Pragma("unroll") for (int it = 0; it < NIT; ++it) if (!MVSGI_ITEM_DEAD(it)) MVSGI_PUT1(PRE, OK, DST, it) }
 // one producer step: request unit u+2 into NEW while unit u+1 (OLD, in flight since the last step) is split and
 // written, ITEM BY ITEM.  A burst of NIT x 4 waves x 1 KiB requests would sit in the CU's vector-memory queue in
 // front of the consumers' weight fragments (measured: the burst form of this pipeline was 7 % SLOWER end to end).
@@ -728,6 +731,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
             MVSGI_WISSUE(WNEW)                                                                          \
             if (DOPUT) { MVSGI_WPUT(WOLD, DST) }                                                        \
             _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                        \
+                if (MVSGI_ITEM_DEAD(it)) continue;                                                      \
                 MVSGI_ISSUE1(NEW, it)                                                                   \
                 if (DOPUT) MVSGI_PUT1(OLD, OKOLD, DST, it)                                              \
                 __builtin_amdgcn_sched_barrier(0);                                                      \
@@ -806,6 +810,7 @@ __device__ __forceinline__ void conv3d_x3_body(const ConvArgs& a) {
 #undef MVSGI_ISSUE1
 #undef MVSGI_ISSUE_END
 #undef MVSGI_PUT1
+#undef MVSGI_ITEM_DEAD
 #undef MVSGI_STEP
 #undef MVSGI_PLAN
         }
